@@ -1,0 +1,83 @@
+"""KMC1-format database writer (numpy) -- test/bench plumbing.
+
+Written from the format description in SURVEY.md Appendix B.3 (what the reference's vendored
+reader consumes in listing mode: kmc_file.cpp:66-99 OpenForListing, :236-290 KMC1 header parse,
+:428-515 ReadNextKmer).  The reference has no writer (databases come from the external KMC
+binary, main.cpp:137), so this lets the real reference (oracle/_ref), the CPU oracle and the HIP
+product all eat the same synthetic input.
+
+Layout
+  <db>.kmc_pre : "KMCP" | u64 LUT[4^p] | 64-byte header | u32 header_offset(=64) | "KMCP"
+  <db>.kmc_suf : "KMCS" | records | "KMCS";  record = (k-p)/4 suffix bytes (4 bases/byte,
+                 first base in the top 2 bits) + counter_size little-endian count bytes.
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+from .synth import words_for_k
+
+
+def lut_prefix_len(k: int) -> int:
+    """Largest p in 7..1 with (k - p) % 4 == 0 (the reader only needs divisibility by 4)."""
+    for p in range(7, 0, -1):
+        if (k - p) % 4 == 0:
+            return p
+    raise ValueError(k)
+
+
+def _suffix_bytes(kmers: np.ndarray, k: int, p: int) -> np.ndarray:
+    """uint8[n, (k-p)/4]: big-endian bytes of the low 2(k-p) bits."""
+    W = words_for_k(k)
+    a = kmers.reshape(-1, W)
+    nb = (k - p) // 4
+    out = np.empty((a.shape[0], nb), dtype=np.uint8)
+    for j in range(nb):
+        bit = 8 * (nb - 1 - j)
+        w = W - 1 - bit // 64
+        out[:, j] = ((a[:, w] >> np.uint64(bit % 64)) & np.uint64(0xFF)).astype(np.uint8)
+    return out
+
+
+def _prefix(kmers: np.ndarray, k: int, p: int) -> np.ndarray:
+    W = words_for_k(k)
+    a = kmers.reshape(-1, W)
+    sh = 2 * (k - p)
+    if W == 1:
+        return (a[:, 0] >> np.uint64(sh)).astype(np.int64)
+    assert sh >= 64
+    return (a[:, 0] >> np.uint64(sh - 64)).astype(np.int64)
+
+
+def write_kmc1(path_prefix: str, kmers: np.ndarray, counts: np.ndarray, k: int, ci: int, cs: int,
+               counter_size: int | None = None, total_override: int | None = None) -> None:
+    """Write ``<path_prefix>.kmc_pre/.kmc_suf``.  ``kmers`` must already be in listing order."""
+    p = lut_prefix_len(k)
+    if counter_size is None:
+        counter_size = 1
+        while cs >= (1 << (8 * counter_size)):
+            counter_size += 1
+    n = len(counts)
+    suf = _suffix_bytes(kmers, k, p)
+    rec = np.empty((n, suf.shape[1] + counter_size), dtype=np.uint8)
+    rec[:, :suf.shape[1]] = suf
+    c = counts.astype(np.uint64)
+    for b in range(counter_size):
+        rec[:, suf.shape[1] + b] = ((c >> np.uint64(8 * b)) & np.uint64(0xFF)).astype(np.uint8)
+    with open(path_prefix + ".kmc_suf", "wb") as f:
+        f.write(b"KMCS")
+        f.write(rec.tobytes())
+        f.write(b"KMCS")
+    pre = _prefix(kmers, k, p)
+    lut = np.searchsorted(pre, np.arange(4 ** p, dtype=np.int64), side="left").astype(np.uint64)
+    total = n if total_override is None else total_override
+    hdr = struct.pack("<IIIIIIQB3xI", k, 0, counter_size, p, ci, cs & 0xFFFFFFFF, total, 0, cs >> 32)
+    hdr = hdr + b"\0" * (64 - len(hdr))          # zero pad; last 4 bytes = kmc_version 0 (KMC1)
+    with open(path_prefix + ".kmc_pre", "wb") as f:
+        f.write(b"KMCP")
+        f.write(lut.tobytes())
+        f.write(hdr)
+        f.write(struct.pack("<I", 64))
+        f.write(b"KMCP")

@@ -1,0 +1,694 @@
+/* oracle/kmx_oracle.c -- TEST INFRASTRUCTURE ONLY (see kmx_oracle.h).
+ *
+ * Sequential-semantics CPU restatement of the kmcEx KModel build/query path.  Each function cites
+ * the reference file:line (relative to /root/reference) whose behaviour it restates.  It keeps the
+ * reference's observable quirks: MSB-first bit order, f64 Bloom sizing, the
+ * reorder permutation, the stale-slot duplicate in rest.bin, k>32 canonicalisation overflow,
+ * find_bitarray_one returning 0, and the inclusive upper bound in the rest-table search.
+ *
+ * Documented divergences (the reference has undefined behaviour or crashes there):
+ *   D1  N_km an exact multiple of nb*2^18 (or 0): reference writes out of bounds
+ *       (kmodel.hpp:521-523); here the empty final block is skipped.
+ *   D2  zero-length filters (N_bf[i]==0 or <8, N_km<16): reference divides by zero
+ *       (kmodel.hpp:378,503); here an empty filter holds nothing and rejects every probe.
+ *   D3  the rest-table search may compare against one row past the last group
+ *       (rest.hpp:237-239, out-of-bounds read on the last group); here that row never matches.
+ *   D4  counts outside [ci, cs]: reference indexes out of bounds (kmodel.hpp:427,
+ *       occu_bin.hpp:70); here kmo_build returns an error.
+ */
+#define _GNU_SOURCE
+#include "kmx_oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <omp.h>
+
+#define BUCKET (1u << 18)          /* kmodel.hpp:276 bucket_size */
+#define MAXLEN 256
+
+/* tools.hpp:9 -- the 128 consecutive primes used as hash seeds (data, not code) */
+static const uint32_t SEEDS[128] = {
+	46757, 46769, 46771, 46807, 46811, 46817, 46819, 46829, 46831, 46853, 46861, 46867, 46877, 46889, 46901, 46919,
+	46933, 46957, 46993, 46997, 47017, 47041, 47051, 47057, 47059, 47087, 47093, 47111, 47119, 47123, 47129, 47137,
+	47143, 47147, 47149, 47161, 47189, 47207, 47221, 47237, 47251, 47269, 47279, 47287, 47293, 47297, 47303, 47309,
+	47317, 47339, 47351, 47353, 47363, 47381, 47387, 47389, 47407, 47417, 47419, 47431, 47441, 47459, 47491, 47497,
+	47501, 47507, 47513, 47521, 47527, 47533, 47543, 47563, 47569, 47581, 47591, 47599, 47609, 47623, 47629, 47639,
+	47653, 47657, 47659, 47681, 47699, 47701, 47711, 47713, 47717, 47737, 47741, 47743, 47777, 47779, 47791, 47797,
+	47807, 47809, 47819, 47837, 47843, 47857, 47869, 47881, 47903, 47911, 47917, 47933, 47939, 47947, 47951, 47963,
+	47969, 47977, 47981, 48017, 48023, 48029, 48049, 48073, 48079, 48091, 48109, 48119, 48121, 48131, 48157, 48163};
+
+uint32_t kmo_hash_seed(int index) { return SEEDS[index & 127]; }
+
+/* MurmurHash64A (Austin Appleby, public domain) exactly as instantiated at tools.hpp:16-50:
+ * h0 = seed ^ (len * m) with len widened to u64; little-endian 8-byte blocks; tail; finaliser. */
+uint64_t kmo_murmur64(const void *key, int len, uint32_t seed)
+{
+	const uint64_t m = 0xc6a4a7935bd1e995ULL;
+	const unsigned char *p = (const unsigned char *)key;
+	uint64_t h = (uint64_t)seed ^ ((uint64_t)(int64_t)len * m);
+	int nblk = len / 8;
+	for (int b = 0; b < nblk; b++) {
+		uint64_t w;
+		memcpy(&w, p + 8 * b, 8);
+		w *= m;
+		w ^= w >> 47;
+		w *= m;
+		h ^= w;
+		h *= m;
+	}
+	int rem = len & 7;
+	if (rem) {
+		uint64_t t = 0;
+		for (int i = rem - 1; i >= 0; i--) t = (t << 8) | p[8 * nblk + i];
+		h ^= t;
+		h *= m;
+	}
+	h ^= h >> 47;
+	h *= m;
+	h ^= h >> 47;
+	return h;
+}
+
+void kmo_packed_to_ascii(const uint64_t *w, int k, char *out)
+{
+	int W = (k + 31) / 32;
+	for (int pos = 0; pos < k; pos++) {
+		int bit = 2 * (k - 1 - pos);
+		out[pos] = "ACGT"[(w[W - 1 - bit / 64] >> (bit % 64)) & 3];
+	}
+}
+
+/* ---- canonicalisation through one u64, tools.hpp:63-76,130-139,90-100,160-167 (A.7) ---- */
+static uint64_t str_to_u64(const char *s, int len)
+{
+	uint64_t v = 0;
+	for (int i = 0; i < len && s[i]; i++) {
+		v <<= 2;
+		if (s[i] == 'C') v |= 1;
+		else if (s[i] == 'G') v |= 2;
+		else if (s[i] == 'T') v |= 3;
+	}
+	return v;
+}
+
+static uint64_t complement_u64(uint64_t v, int len)
+{
+	uint64_t r = 0;
+	for (int i = 0; i < len; i++) {
+		r = (r << 2) | ((~v) & 3);
+		v >>= 2;
+	}
+	return r;
+}
+
+void kmo_min_kmer(const char *s, int len, char *out)
+{
+	uint64_t u = str_to_u64(s, len);
+	uint64_t rc = complement_u64(u, len);
+	if (u <= rc) {
+		memcpy(out, s, (size_t)len);
+		return;
+	}
+	for (int i = len - 1; i >= 0; i--) {
+		out[i] = "ACGT"[rc & 3];
+		rc >>= 2;
+	}
+}
+
+/* ---- occurrence bins, occu_bin.hpp:27-83 ---- */
+int kmo_occubin_table(int max_counter, int nh, uint32_t *bin_of_occ, uint32_t *mean_of_bin)
+{
+	int e3 = 1 << nh, e1 = e3 / 4, e2 = e1 + e3 / 2;
+	uint32_t *mean_of_occ = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)max_counter);
+	for (int i = 0; i < max_counter; i++) { bin_of_occ[i] = 0xFFFFFFFFu; mean_of_occ[i] = 0xFFFFFFFFu; }
+	int start = e1;
+	for (int i = 0; i < e3 / 2; i++) {            /* zone 2: bins 3 wide (:35-44) */
+		for (int j = 0; j < 3; j++) {
+			if (start + j >= max_counter) { free(mean_of_occ); return -1; }   /* Q11: cs too small for nh */
+			mean_of_occ[start + j] = (uint32_t)(start + 1);
+			bin_of_occ[start + j] = (uint32_t)(e1 + i);
+		}
+		start += 3;
+	}
+	int nz3 = e3 / 4, cap = (max_counter - start) / nz3;  /* zone 3 (:46-54) */
+	for (int i = 0; i < nz3; i++) {
+		for (int j = 0; j < cap; j++) {
+			mean_of_occ[start + j] = (uint32_t)((2 * start + cap) / 2);
+			bin_of_occ[start + j] = (uint32_t)(e2 + i);
+		}
+		start += cap;
+	}
+	for (int i = start; i < max_counter; i++) {   /* leftovers (:56-59) */
+		mean_of_occ[i] = (uint32_t)((2 * start - cap) / 2);
+		bin_of_occ[i] = (uint32_t)(e3 - 1);
+	}
+	for (int i = 0; i < e1 && i < max_counter; i++) bin_of_occ[i] = (uint32_t)i;   /* occ_to_bin identity zone (:68-69) */
+	for (int b = 0; b < e3; b++) mean_of_bin[b] = b < e1 ? (uint32_t)b : 0;       /* bin_to_mean (:79-83); missing key -> 0 */
+	char *seen = (char *)calloc((size_t)e3, 1);
+	for (int i = e1; i < max_counter; i++) {       /* unordered_map::insert keeps the first (:61-63) */
+		uint32_t b = bin_of_occ[i];
+		if (b < (uint32_t)e3 && !seen[b]) { seen[b] = 1; if ((int)b >= e1) mean_of_bin[b] = mean_of_occ[i]; }
+	}
+	free(seen);
+	free(mean_of_occ);
+	return 0;
+}
+
+/* ---- model ---- */
+typedef struct { uint64_t w[2]; uint32_t occ; } kbuf_t;            /* KmerBuff, kmodel.hpp:26-29 */
+typedef struct { uint64_t w[2]; int32_t count; } rest_ent_t;
+
+struct kmo_model {
+	int ci, cs, nh, nb, k, bf_num, max_counter, e1;
+	uint32_t *bin_of_occ, *mean_of_bin;
+	uint64_t total, n_km, n_bf[3];
+	uint64_t byte_bf[3], len_bf[3], byte_bf_back[3], len_bf_back[3];
+	uint8_t *bf[3], *bf_back[3];
+	uint64_t km_byte_size, km_bit_size, byte_km_back, bit_km_back;
+	uint8_t *km_back, **val, **tag;
+	uint32_t *seed;                 /* [nb][nh] */
+	/* rest table, rest.hpp:46-65 */
+	int rest_k, pre_len, map_size, pre_buffer_size, suff_group;
+	uint64_t suff_bin_size, entries;
+	int32_t *hash2index, *pre_buffer, *count_bin;
+	uint8_t *suffix_bin;
+	uint64_t attempts, successes;
+};
+
+kmo_model *kmo_create(int ci, int cs, int nh, int nb)
+{
+	if (nh < 3 || nh > 16 || nb < 1 || nb > 32 || ci < 1 || cs < ci) return NULL;
+	kmo_model *m = (kmo_model *)calloc(1, sizeof(*m));
+	m->ci = ci; m->cs = cs; m->nh = nh; m->nb = nb;
+	m->max_counter = cs + 1;                    /* kmodel.hpp:675 */
+	m->bf_num = ci == 1 ? 1 : 3;                /* kmodel.hpp:50 */
+	m->e1 = (1 << nh) / 4;
+	m->bin_of_occ = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)m->max_counter);
+	m->mean_of_bin = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(1 << nh));
+	if (kmo_occubin_table(m->max_counter, nh, m->bin_of_occ, m->mean_of_bin)) { kmo_destroy(m); return NULL; }
+	return m;
+}
+
+void kmo_destroy(kmo_model *m)
+{
+	if (!m) return;
+	for (int i = 0; i < 3; i++) { free(m->bf[i]); free(m->bf_back[i]); }
+	if (m->val) for (int a = 0; a < m->nb; a++) { free(m->val[a]); free(m->tag[a]); }
+	free(m->val); free(m->tag); free(m->km_back); free(m->seed);
+	free(m->hash2index); free(m->pre_buffer); free(m->count_bin); free(m->suffix_bin);
+	free(m->bin_of_occ); free(m->mean_of_bin);
+	free(m);
+}
+
+static uint8_t *zalloc(uint64_t n) { return (uint8_t *)calloc(n ? n : 1, 1); }
+
+/* kmodel.hpp:402-420 */
+static void init_bf_parameter(kmo_model *m)
+{
+	for (int i = 0; i < m->bf_num; i++) {
+		m->byte_bf[i] = (uint64_t)((double)m->n_bf[i] / 5.5 * (double)(m->nh - 1));   /* Q5: f64, truncation */
+		m->len_bf[i] = m->byte_bf[i] << 3;
+		m->byte_bf_back[i] = (m->n_bf[i] >> 3) * (uint64_t)(m->nh - 2);
+		m->len_bf_back[i] = m->byte_bf_back[i] << 3;
+		free(m->bf[i]); free(m->bf_back[i]);
+		m->bf[i] = zalloc(m->byte_bf[i]);
+		m->bf_back[i] = zalloc(m->byte_bf_back[i]);
+	}
+}
+
+/* kmodel.hpp:436-456 */
+static void init_km_parameter(kmo_model *m)
+{
+	m->km_byte_size = (m->n_km >> 4) * (uint64_t)m->nh;
+	m->km_bit_size = m->km_byte_size << 3;
+	m->byte_km_back = (m->n_km >> 4) * (uint64_t)(m->nh - 2);
+	m->bit_km_back = m->byte_km_back << 3;
+	m->km_back = zalloc(m->byte_km_back);
+	m->val = (uint8_t **)calloc((size_t)m->nb, sizeof(uint8_t *));
+	m->tag = (uint8_t **)calloc((size_t)m->nb, sizeof(uint8_t *));
+	m->seed = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(m->nb * m->nh));
+	for (int a = 0; a < m->nb; a++) {
+		m->val[a] = zalloc(m->km_byte_size);
+		m->tag[a] = zalloc(m->km_byte_size);
+		for (int j = 0; j < m->nh; j++) m->seed[a * m->nh + j] = SEEDS[(a * m->nh + j) % 128];
+	}
+}
+
+/* kmodel.hpp:576-588 (Q6: MSB-first inside a byte; set is an atomic OR) */
+static inline void set_bit(uint8_t *bits, uint64_t pos) { __sync_fetch_and_or(bits + (pos >> 3), (uint8_t)(0x80u >> (pos & 7))); }
+static inline int get_bit(const uint8_t *bits, uint64_t pos) { return (bits[pos >> 3] >> (7 - (pos & 7))) & 1; }
+
+/* kmodel.hpp:498-506 / :373-383 with divergence D2 for empty filters */
+static void bloom_insert(const char *s, int len, uint8_t *bits, uint64_t nbits, int nhash)
+{
+	if (!nbits) return;
+	for (int i = 0; i < nhash; i++) set_bit(bits, kmo_murmur64(s, len, SEEDS[i]) % nbits);
+}
+static int bloom_check(const char *s, int len, const uint8_t *bits, uint64_t nbits, int nhash)
+{
+	if (!nbits) return 0;
+	for (int i = 0; i < nhash; i++)
+		if (!get_bit(bits, kmo_murmur64(s, len, SEEDS[i]) % nbits)) return 0;
+	return 1;
+}
+/* kmodel.hpp:386-390: the (k-2)-mer is the k-mer without its first and last base */
+static int back_check(const char *s, int len, const uint8_t *bits, uint64_t nbits, int nhash)
+{
+	int n = len >= 2 ? len - 2 : 0;
+	return bloom_check(len >= 1 ? s + 1 : s, n, bits, nbits, nhash);
+}
+
+/* kmodel.hpp:590-622 */
+static int insert_to_array(kmo_model *m, const char *s, int len, uint32_t bin, int a)
+{
+	uint64_t pos[16];
+	const uint32_t *sd = m->seed + a * m->nh;
+	for (int j = 0; j < m->nh; j++) pos[j] = kmo_murmur64(s, len, sd[j]) % m->km_bit_size;
+	for (int j = 0; j < m->nh; j++)
+		if (get_bit(m->tag[a], pos[j]) && get_bit(m->val[a], pos[j]) != (int)((bin >> j) & 1)) return 0;
+	for (int j = 0; j < m->nh; j++) {
+		if ((bin >> j) & 1) set_bit(m->val[a], pos[j]);
+		set_bit(m->tag[a], pos[j]);
+	}
+	return 1;
+}
+
+/* kmodel.hpp:529-540 (Q2: this exact permutation; n==0 reads a stale slot) */
+static int reorder_buffer(kbuf_t *a, int n)
+{
+	int il = 0, ir = n - 1;
+	while (il < ir) {
+		while (il < ir && !a[ir].occ) ir--;
+		while (il < ir && a[il].occ) il++;
+		if (il < ir) { a[il] = a[ir]; a[ir].occ = 0; }
+	}
+	return a[il].occ ? il + 1 : 0;
+}
+
+/* kmodel.hpp:543-555 */
+static void insert_array(kmo_model *m, kbuf_t *buf, int a, int *n, uint64_t *att, uint64_t *suc)
+{
+	char s[MAXLEN];
+	int k = m->k;
+	for (int c = 0; c < *n; c++) {
+		kmo_packed_to_ascii(buf[c].w + (k <= 32 ? 1 : 0), k, s);
+		(*att)++;
+		if (insert_to_array(m, s, k, m->bin_of_occ[buf[c].occ], a)) {
+			(*suc)++;
+			bloom_insert(s + 1, k - 2, m->km_back, m->bit_km_back, m->nh - 2);
+			buf[c].occ = 0;
+		}
+	}
+	*n = reorder_buffer(buf, *n);
+}
+
+typedef struct { rest_ent_t *v; uint64_t n, cap; } rest_vec;
+static void rest_push(rest_vec *r, const kbuf_t *e)
+{
+	if (r->n == r->cap) { r->cap = r->cap ? r->cap * 2 : 1024; r->v = (rest_ent_t *)realloc(r->v, r->cap * sizeof(rest_ent_t)); }
+	r->v[r->n].w[0] = e->w[0]; r->v[r->n].w[1] = e->w[1]; r->v[r->n].count = (int32_t)e->occ; r->n++;
+}
+
+/* kmodel.hpp:557-573 */
+static void insert_with_thread(kmo_model *m, kbuf_t **buf, int *n, rest_vec *rest)
+{
+	int nb = m->nb;
+	for (int t = 0; t < nb; t++) {
+		uint64_t att = 0, suc = 0;
+#pragma omp parallel for num_threads(nb) reduction(+ : att, suc) schedule(static, 1)
+		for (int i = 0; i < nb; i++) insert_array(m, buf[i], (i + t) % nb, &n[i], &att, &suc);
+		m->attempts += att; m->successes += suc;
+	}
+	for (int i = 0; i < nb; i++) {
+		for (int j = 0; j < n[i]; j++) rest_push(rest, &buf[i][j]);
+		n[i] = (int)BUCKET;
+	}
+}
+
+static int rest_cmp(const void *a, const void *b)
+{
+	const rest_ent_t *x = (const rest_ent_t *)a, *y = (const rest_ent_t *)b;
+	if (x->w[0] != y->w[0]) return x->w[0] < y->w[0] ? -1 : 1;
+	if (x->w[1] != y->w[1]) return x->w[1] < y->w[1] ? -1 : 1;
+	return 0;
+}
+
+static int rest_prefix_len(int k) { for (int i = 7; i >= 3; i--) if ((k - i) % 4 == 0) return i; return 3; }   /* rest.hpp:78-83 */
+
+static inline unsigned base_at(const uint64_t *w2, int k, int pos)       /* w2 = {hi, lo} 128-bit view */
+{
+	int bit = 2 * (k - 1 - pos);
+	return (unsigned)((w2[1 - bit / 64] >> (bit % 64)) & 3);
+}
+
+/* rest.hpp:95-135,157-161: groups ascending by prefix, rows ascending by suffix bytes.  Sorting the
+ * whole list by packed value yields the same arrays (prefix is the top 2*pre_len bits). */
+static void rest_build(kmo_model *m, rest_vec *r)
+{
+	int k = m->k;
+	m->rest_k = k;
+	m->pre_len = rest_prefix_len(k);
+	m->map_size = 1 << (2 * m->pre_len);
+	m->suff_group = (k - m->pre_len) / 4;
+	qsort(r->v, r->n, sizeof(rest_ent_t), rest_cmp);
+	m->entries = r->n;
+	m->suff_bin_size = r->n * (uint64_t)m->suff_group;
+	m->hash2index = (int32_t *)malloc(sizeof(int32_t) * (size_t)m->map_size);
+	for (int i = 0; i < m->map_size; i++) m->hash2index[i] = -1;
+	m->suffix_bin = zalloc(m->suff_bin_size);
+	m->count_bin = (int32_t *)malloc(sizeof(int32_t) * (size_t)(r->n ? r->n : 1));
+	int32_t *pb = (int32_t *)malloc(sizeof(int32_t) * (size_t)(m->map_size + 1));
+	int groups = 0;
+	pb[0] = 0;
+	int64_t prev = -1;
+	for (uint64_t e = 0; e < r->n; e++) {
+		int64_t pre = 0;
+		for (int p = 0; p < m->pre_len; p++) pre = (pre << 2) | base_at(r->v[e].w, k, p);
+		if (pre != prev) { m->hash2index[pre] = groups++; prev = pre; }
+		pb[groups] = (int32_t)(e + 1);
+		for (int g = 0; g < m->suff_group; g++) {
+			unsigned b = 0;
+			for (int q = 0; q < 4; q++) b = (b << 2) | base_at(r->v[e].w, k, m->pre_len + 4 * g + q);
+			m->suffix_bin[e * (uint64_t)m->suff_group + (uint64_t)g] = (uint8_t)b;
+		}
+		m->count_bin[e] = r->v[e].count;
+	}
+	m->pre_buffer_size = groups + 1;
+	m->pre_buffer = (int32_t *)malloc(sizeof(int32_t) * (size_t)m->pre_buffer_size);
+	memcpy(m->pre_buffer, pb, sizeof(int32_t) * (size_t)m->pre_buffer_size);
+	free(pb);
+}
+
+/* kmodel.hpp:57-86 + :423-434 + :458-527 */
+int kmo_build(kmo_model *m, int k, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint64_t total_kmers)
+{
+	if (!m || k < 3 || k > 64) return -1;
+	int W = (k + 31) / 32, nb = m->nb;
+	m->k = k;
+	/* pass 1 (:423-434) */
+	memset(m->n_bf, 0, sizeof(m->n_bf));
+	for (uint64_t i = 0; i < n; i++) {
+		if (counts[i] < (uint32_t)m->ci || counts[i] > (uint32_t)m->cs) return -4;      /* D4 */
+		if (counts[i] < (uint32_t)(m->ci + m->bf_num)) m->n_bf[counts[i] - (uint32_t)m->ci]++;
+	}
+	m->total = total_kmers;
+	init_bf_parameter(m);
+	uint64_t nbf = 0;
+	for (int i = 0; i < m->bf_num; i++) nbf += m->n_bf[i];
+	m->n_km = m->total - nbf;
+	init_km_parameter(m);
+	/* buffers (:458-471); fresh pages read as zero (Q1) */
+	kbuf_t **buf = (kbuf_t **)malloc(sizeof(kbuf_t *) * (size_t)nb);
+	int *bn = (int *)malloc(sizeof(int) * (size_t)nb);
+	for (int i = 0; i < nb; i++) { buf[i] = (kbuf_t *)calloc(BUCKET, sizeof(kbuf_t)); bn[i] = (int)BUCKET; }
+	uint32_t idx = 0, buff_size = BUCKET * (uint32_t)nb;
+	rest_vec rest = {0, 0, 0};
+	m->attempts = m->successes = 0;
+	char s[MAXLEN];
+	/* pass 2 (:68-74) */
+	for (uint64_t i = 0; i < n; i++) {
+		const uint64_t *w = kmers + i * (uint64_t)W;
+		uint32_t c = counts[i];
+		if (c < (uint32_t)(m->ci + m->bf_num)) {            /* :473-477 (buffering at :479-496 is order-free) */
+			int f = (int)(c - (uint32_t)m->ci);
+			kmo_packed_to_ascii(w, k, s);
+			bloom_insert(s, k, m->bf[f], m->len_bf[f], m->nh - 1);
+			bloom_insert(s + 1, k - 2, m->bf_back[f], m->len_bf_back[f], m->nh - 2);
+		} else {                                            /* :508-518 */
+			if (m->km_bit_size == 0) continue;              /* D2 */
+			kbuf_t *e = &buf[idx / BUCKET][idx % BUCKET];
+			e->w[0] = W == 2 ? w[0] : 0; e->w[1] = W == 2 ? w[1] : w[0]; e->occ = c;
+			if (++idx >= buff_size) { insert_with_thread(m, buf, bn, &rest); idx = 0; }
+		}
+	}
+	/* :520-527, with divergence D1 for idx == 0 */
+	if (idx != 0) {
+		int row = (int)((idx - 1) / BUCKET), col = (int)((idx - 1) % BUCKET);
+		bn[row] = col + 1;
+		for (int i = row + 1; i < nb; i++) bn[i] = 0;
+		insert_with_thread(m, buf, bn, &rest);
+	}
+	rest_build(m, &rest);
+	free(rest.v);
+	for (int i = 0; i < nb; i++) free(buf[i]);
+	free(buf); free(bn);
+	return 0;
+}
+
+void kmo_get_stats(const kmo_model *m, kmo_stats *st)
+{
+	memset(st, 0, sizeof(*st));
+	st->n_total = m->total; st->n_km = m->n_km;
+	for (int i = 0; i < 3; i++) { st->n_bf[i] = m->n_bf[i]; st->byte_bf[i] = m->byte_bf[i]; st->byte_bf_back[i] = m->byte_bf_back[i]; }
+	st->attempts = m->attempts; st->successes = m->successes; st->rest_entries = m->entries;
+	st->km_byte_size = m->km_byte_size; st->byte_km_back = m->byte_km_back;
+}
+
+const uint8_t *kmo_bf(const kmo_model *m, int i) { return m->bf[i]; }
+const uint8_t *kmo_bf_back(const kmo_model *m, int i) { return m->bf_back[i]; }
+const uint8_t *kmo_km_back(const kmo_model *m) { return m->km_back; }
+const uint8_t *kmo_value_array(const kmo_model *m, int a) { return m->val[a]; }
+const uint8_t *kmo_tag_array(const kmo_model *m, int a) { return m->tag[a]; }
+
+/* ---- persistence, kmodel.hpp:173-206 / rest.hpp:197-221 (Appendix B.1, B.2) ---- */
+int kmo_save(const kmo_model *m, const char *dir)
+{
+	char path[4096];
+	snprintf(path, sizeof path, "%s/header", dir);
+	FILE *f = fopen(path, "w");
+	if (!f) return -1;
+	fprintf(f, "number_hash %d\nnumber_bit %d\nci %d\ncs %d\n", m->nh, m->nb, m->ci, m->cs);
+	fclose(f);
+	snprintf(path, sizeof path, "%s/km.bin", dir);
+	if (!(f = fopen(path, "wb"))) return -1;
+	fwrite(&m->n_km, 8, 1, f);
+	for (int i = 0; i < m->bf_num; i++) fwrite(&m->n_bf[i], 8, 1, f);
+	for (int i = 0; i < m->bf_num; i++) { fwrite(m->bf[i], 1, m->byte_bf[i], f); fwrite(m->bf_back[i], 1, m->byte_bf_back[i], f); }
+	fwrite(m->km_back, 1, m->byte_km_back, f);
+	for (int a = 0; a < m->nb; a++) { fwrite(m->val[a], 1, m->km_byte_size, f); fwrite(m->tag[a], 1, m->km_byte_size, f); }
+	fclose(f);
+	snprintf(path, sizeof path, "%s/rest.bin", dir);
+	if (!(f = fopen(path, "wb"))) return -1;
+	int32_t h[4] = {m->rest_k, m->pre_len, m->map_size, m->pre_buffer_size};
+	fwrite(h, 4, 4, f);
+	fwrite(&m->suff_bin_size, 8, 1, f);
+	fwrite(&m->entries, 8, 1, f);
+	fwrite(m->hash2index, 4, (size_t)m->map_size, f);
+	fwrite(m->pre_buffer, 4, (size_t)m->pre_buffer_size, f);
+	fwrite(m->suffix_bin, 1, m->suff_bin_size, f);
+	fwrite(m->count_bin, 4, m->entries, f);
+	fclose(f);
+	return 0;
+}
+
+/* kmodel.hpp:680-696, :209-235; rest.hpp:163-195 */
+kmo_model *kmo_load(const char *dir)
+{
+	char path[4096], key[64];
+	int nh, nb, ci, cs;
+	snprintf(path, sizeof path, "%s/header", dir);
+	FILE *f = fopen(path, "r");
+	if (!f) return NULL;
+	if (fscanf(f, "%63s %d %63s %d %63s %d %63s %d", key, &nh, key, &nb, key, &ci, key, &cs) != 8) { fclose(f); return NULL; }
+	fclose(f);
+	kmo_model *m = kmo_create(ci, cs, nh, nb);
+	if (!m) return NULL;
+	snprintf(path, sizeof path, "%s/km.bin", dir);
+	if (!(f = fopen(path, "rb"))) { kmo_destroy(m); return NULL; }
+	size_t ok = fread(&m->n_km, 8, 1, f);
+	for (int i = 0; i < m->bf_num; i++) ok += fread(&m->n_bf[i], 8, 1, f);
+	init_bf_parameter(m);
+	for (int i = 0; i < m->bf_num; i++) { ok += fread(m->bf[i], 1, m->byte_bf[i], f); ok += fread(m->bf_back[i], 1, m->byte_bf_back[i], f); }
+	init_km_parameter(m);
+	ok += fread(m->km_back, 1, m->byte_km_back, f);
+	for (int a = 0; a < m->nb; a++) { ok += fread(m->val[a], 1, m->km_byte_size, f); ok += fread(m->tag[a], 1, m->km_byte_size, f); }
+	fclose(f);
+	m->total = m->n_km;
+	for (int i = 0; i < m->bf_num; i++) m->total += m->n_bf[i];
+	snprintf(path, sizeof path, "%s/rest.bin", dir);
+	if (!(f = fopen(path, "rb"))) { kmo_destroy(m); return NULL; }
+	int32_t h[4];
+	ok += fread(h, 4, 4, f);
+	m->rest_k = h[0]; m->pre_len = h[1]; m->map_size = h[2]; m->pre_buffer_size = h[3];
+	ok += fread(&m->suff_bin_size, 8, 1, f);
+	ok += fread(&m->entries, 8, 1, f);
+	m->suff_group = (m->rest_k - m->pre_len) / 4;
+	m->k = m->rest_k;
+	m->hash2index = (int32_t *)malloc(4 * (size_t)m->map_size);
+	m->pre_buffer = (int32_t *)malloc(4 * (size_t)m->pre_buffer_size);
+	m->suffix_bin = zalloc(m->suff_bin_size);
+	m->count_bin = (int32_t *)malloc(4 * (size_t)(m->entries ? m->entries : 1));
+	ok += fread(m->hash2index, 4, (size_t)m->map_size, f);
+	ok += fread(m->pre_buffer, 4, (size_t)m->pre_buffer_size, f);
+	ok += fread(m->suffix_bin, 1, m->suff_bin_size, f);
+	ok += fread(m->count_bin, 4, m->entries, f);
+	fclose(f);
+	(void)ok;
+	return m;
+}
+
+/* ---- query ---- */
+static unsigned code_of(char c) { return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u; }   /* rest.hpp:22-34 */
+
+/* rest.hpp:223-251 (+ :67-76).  The upper bound is inclusive, so the row after the group may be
+ * compared; divergence D3 when that row lies past the table. */
+static int rest_check(const kmo_model *m, const char *s, int len)
+{
+	if (m->rest_k != len) return 0;                          /* Q7 */
+	uint8_t key[64];
+	int sg = m->suff_group;
+	for (int j = 0, i = m->pre_len; i < m->rest_k; i += 4, j++) {
+		unsigned b = 0;
+		for (int q = 0; q < 4; q++) b = (b << 2) | code_of(s[i + q]);
+		key[j] = (uint8_t)b;
+	}
+	uint32_t hi = 0;
+	for (int i = 0; i < m->pre_len; i++) hi = (hi << 2) | code_of(s[i]);
+	int g = m->hash2index[hi];
+	if (g < 0) return 0;
+	int low = m->pre_buffer[g], high = m->pre_buffer[g + 1], mid = 0, found = 0;
+	while (low <= high) {
+		mid = (low + high) / 2;
+		if ((uint64_t)mid >= m->entries) break;              /* D3 */
+		int c = memcmp(key, m->suffix_bin + (uint64_t)mid * (uint64_t)sg, (size_t)sg);
+		if (c < 0) high = mid - 1;
+		else if (c > 0) low = mid + 1;
+		else { found = 1; break; }
+	}
+	return found ? m->count_bin[mid] : 0;
+}
+
+/* kmodel.hpp:361-371; filter order {0} for ci==1 else {1,0,2} (:246,:363) */
+static int check_all_bf(const kmo_model *m, const char *s, int len)
+{
+	static const int order3[3] = {1, 0, 2};
+	for (int j = 0; j < m->bf_num; j++) {
+		int i = m->ci == 1 ? j : order3[j];
+		int a = bloom_check(s, len, m->bf[i], m->len_bf[i], m->nh - 1);
+		int b = back_check(s, len, m->bf_back[i], m->len_bf_back[i], m->nh - 2);
+		if (a && b) return i + m->ci;
+	}
+	return 0;
+}
+
+/* decode one array: returns -1 if some tag is missing, else the value bits LSB-first
+ * (kmodel.hpp:630-642 / tools.hpp:54-61) */
+static int decode_array(const kmo_model *m, const char *s, int len, int a)
+{
+	if (!m->km_bit_size) return -1;                          /* D2 */
+	int ok = 1, v = 0;
+	for (int j = 0; j < m->nh; j++) {
+		uint64_t pos = kmo_murmur64(s, len, m->seed[a * m->nh + j]) % m->km_bit_size;
+		v |= get_bit(m->val[a], pos) << j;
+		if (!get_bit(m->tag[a], pos)) ok = 0;
+	}
+	return ok ? v : -1;
+}
+
+/* kmodel.hpp:650-671 (Q3) */
+static int find_bitarray_one(const kmo_model *m, const char *s, int len)
+{
+	int result = -1;
+	for (int a = 0; a < m->nb; a++) {
+		int v = decode_array(m, s, len, a);
+		if (v >= 0) { result = v; if (v != 0) break; }
+	}
+	return result;
+}
+
+/* kmodel.hpp:326-342 */
+static void get_candidates(const kmo_model *m, const char *s, int len, int *cand, int *nc)
+{
+	char c[MAXLEN];
+	kmo_min_kmer(s, len, c);
+	int r = rest_check(m, c, len);
+	if (r > 0) { cand[(*nc)++] = (int)m->bin_of_occ[r]; return; }
+	int occ = check_all_bf(m, c, len);
+	if (occ != 0) { cand[(*nc)++] = occ; return; }
+	if (back_check(c, len, m->km_back, m->bit_km_back, m->nh - 2)) {
+		int v = find_bitarray_one(m, c, len);
+		if (v > -1) cand[(*nc)++] = v;
+	}
+}
+
+/* kmodel.hpp:344-359: 4 successors (drop first base, append X) then 4 predecessors */
+static int neighbor_bins(const kmo_model *m, const char *s, int len, int *cand)
+{
+	char t[MAXLEN];
+	int nc = 0;
+	for (int x = 0; x < 4; x++) {
+		memcpy(t, s + 1, (size_t)(len - 1));
+		t[len - 1] = "ACGT"[x];
+		get_candidates(m, t, len, cand, &nc);
+	}
+	for (int x = 0; x < 4; x++) {
+		t[0] = "ACGT"[x];
+		memcpy(t + 1, s, (size_t)(len - 1));
+		get_candidates(m, t, len, cand, &nc);
+	}
+	return nc;
+}
+
+/* kmodel.hpp:286-323 */
+static int kmer_to_bin(const kmo_model *m, const char *s, int len, int occ)
+{
+	int v[32], nv = 0, cand[8];
+	for (int a = 0; a < m->nb; a++) {                       /* find_bitarray :625-646 */
+		int d = decode_array(m, s, len, a);
+		if (d > 0) v[nv++] = d;
+	}
+	if (nv == 0) return occ;
+	if (nv == 1) {
+		if (occ) {
+			int nc = neighbor_bins(m, s, len, cand), cnt = 0;
+			for (int i = 0; i < nc; i++) if (cand[i] < m->ci + m->bf_num) cnt++;
+			if (cnt >= nc / 2) return occ;
+		}
+		return v[0];
+	}
+	int nc = neighbor_bins(m, s, len, cand);
+	if (nc <= 0) return 0;
+	int min_dist = 2 << 20, best = v[0];
+	for (int i = 0; i < nv; i++) {
+		int cur_min = 2 << 20;
+		for (int j = 0; j < nc; j++) { int d = abs(v[i] - cand[j]); if (d < cur_min) cur_min = d; }
+		if (min_dist > cur_min) { min_dist = cur_min; best = v[i]; }
+	}
+	return best;
+}
+
+/* kmodel.hpp:100-116 */
+static int query_one(const kmo_model *m, const char *raw, int len)
+{
+	char s[MAXLEN];
+	kmo_min_kmer(raw, len, s);
+	int occ = rest_check(m, s, len);
+	if (occ != 0) return occ;
+	int in_back = back_check(s, len, m->km_back, m->bit_km_back, m->nh - 2);
+	occ = check_all_bf(m, s, len);
+	if (occ != 0 && !in_back) return occ;
+	if (!in_back) return 0;
+	int bin = kmer_to_bin(m, s, len, occ);
+	return (int)m->mean_of_bin[bin];
+}
+
+int kmo_query_ascii(const kmo_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out, int threads)
+{
+	if (len < 2 || len >= MAXLEN) return -1;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 1024)
+	for (int64_t i = 0; i < (int64_t)n; i++) out[i] = query_one(m, strs + (uint64_t)i * (uint64_t)stride, len);
+	return 0;
+}
+
+int kmo_query_packed(const kmo_model *m, int k, const uint64_t *kmers, uint64_t n, int32_t *out, int threads)
+{
+	if (k < 3 || k > 64) return -1;
+	int W = (k + 31) / 32;
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(dynamic, 1024)
+	for (int64_t i = 0; i < (int64_t)n; i++) {
+		char s[MAXLEN];
+		kmo_packed_to_ascii(kmers + (uint64_t)i * (uint64_t)W, k, s);
+		out[i] = query_one(m, s, k);
+	}
+	return 0;
+}

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REAL reference (oracle/_ref/ref_driver).
+
+Run in the build container only (needs /root/reference to have been compiled by `make -C oracle ref`).
+For every case below it
+  1. builds a synthetic KMC1 database (kmcex_amd.synth + kmcex_amd.kmcdb),
+  2. runs the reference: get_model(ci,cs,nh,nb) -> init(db) -> save(dir)        (kmodel.hpp:674,57,173)
+     and get_model(dir) -> kmer_to_occ(vector<string>, 8)                         (kmodel.hpp:680,90)
+  3. runs the CPU oracle (oracle/kmx_oracle.c) on the same input and REFUSES to write goldens unless
+     header/km.bin/rest.bin and the occ vector are identical,
+  4. records sha256 of the three model files and of the int32 occ vector in golden.json.
+The smallest case is also committed whole (database + model files + query strings + occ vector) under
+tests/golden/tiny/.  Only data is stored -- no reference source.
+"""
+import hashlib
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle_lib as O  # noqa: E402
+from kmcex_amd import kmcdb, synth  # noqa: E402
+
+# name, k, ci, cs, nh, nb, n_draws
+CASES = [
+    ("tiny_k31", 31, 1, 1023, 7, 5, 20000),
+    ("k31_ci2_200k", 31, 2, 1023, 7, 5, 200000),
+    ("k55_nh9_nb6", 55, 1, 4095, 9, 6, 30000),
+    ("k21_nh6_nb3", 21, 2, 255, 6, 3, 5000),
+    ("k31_multiblock_ci1", 31, 1, 1023, 7, 5, 3200000),      # 2 full blocks + partial with unused rows (Q1)
+    ("k31_multiblock_ci2", 31, 2, 1023, 7, 5, 4000000),      # RS-scale plumbing stand-in (BASELINE configs[0])
+    ("k55_multiblock", 55, 1, 4095, 9, 6, 2000000),          # 1 full block (6*2^18) + partial, two-word k-mers
+    ("k32_nb4", 32, 1, 1023, 7, 4, 50000),                   # k == 32 boundary, pre_len 4
+]
+
+
+def query_set(km, k, seed=7, max_present=None):
+    """Inserted k-mers in a seeded shuffle, first half reverse-complemented, + 10 % absent draws."""
+    rng = np.random.default_rng(seed)
+    idx = rng.permutation(len(km))
+    if max_present is not None:
+        idx = idx[:max_present]
+    q = km[idx].copy()
+    h = len(q) // 2
+    q[:h] = synth.revcomp(q[:h], k)
+    absent = synth.random_kmers(max(len(q) // 10, 10), k, seed_k=999)
+    return np.concatenate([q, absent])
+
+
+def sha_file(p):
+    h = hashlib.sha256()
+    with open(p, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def main():
+    if not O.have_ref():
+        sys.exit("oracle/_ref/ref_driver missing: run `make -C oracle ref` where /root/reference exists")
+    out = {"generator": "tests/golden/make_golden.py", "seed_k": 1, "seed_c": 2, "cases": {}}
+    tmp = tempfile.mkdtemp(prefix="kmx_golden_")
+    for name, k, ci, cs, nh, nb, n in CASES:
+        km, cnt = synth.make_stream(n, k, ci, cs)
+        db = os.path.join(tmp, name)
+        kmcdb.write_kmc1(db, km, cnt, k, ci, cs)
+        O.ref_build(db, db + ".ref", ci, cs, nh, nb)
+        m = O.OracleModel(ci, cs, nh, nb)
+        m.build(k, km, cnt)
+        m.save(db + ".ora")
+        q = query_set(km, k, max_present=400000)
+        qs = synth.to_strings(q, k)
+        r_ref = O.ref_query(db + ".ref", qs, db)
+        r_ora = m.query_packed(k, q)
+        files = {}
+        for f in ("header", "km.bin", "rest.bin"):
+            a, b = sha_file(f"{db}.ref/{f}"), sha_file(f"{db}.ora/{f}")
+            if a != b:
+                sys.exit(f"{name}: oracle {f} differs from the reference")
+            files[f] = a
+        if not np.array_equal(r_ref, r_ora):
+            sys.exit(f"{name}: oracle kmer_to_occ differs from the reference")
+        st = m.stats()
+        out["cases"][name] = {
+            "k": k, "ci": ci, "cs": cs, "nh": nh, "nb": nb, "n_draws": n, "n_kmers": int(len(cnt)),
+            "sha256": files, "km_bin_bytes": os.path.getsize(f"{db}.ref/km.bin"),
+            "rest_bin_bytes": os.path.getsize(f"{db}.ref/rest.bin"),
+            "n_queries": int(len(q)), "occ_sha256": hashlib.sha256(r_ref.astype("<i4").tobytes()).hexdigest(),
+            "occ_sum": int(r_ref.astype(np.int64).sum()), "occ_nonzero": int((r_ref != 0).sum()),
+            "stats": {"n_km": st.n_km, "n_bf": list(st.n_bf), "attempts": st.attempts,
+                      "successes": st.successes, "rest_entries": st.rest_entries},
+        }
+        print(name, "ok", out["cases"][name]["stats"], flush=True)
+        if name == "tiny_k31":
+            d = os.path.join(HERE, "tiny")
+            shutil.rmtree(d, ignore_errors=True)
+            os.makedirs(d)
+            for ext in (".kmc_pre", ".kmc_suf"):
+                shutil.copy(db + ext, os.path.join(d, "db" + ext))
+            for f in ("header", "km.bin", "rest.bin"):
+                shutil.copy(f"{db}.ref/{f}", os.path.join(d, f))
+            with open(os.path.join(d, "queries.txt"), "w") as f:
+                f.write("\n".join(qs) + "\n")
+            np.savetxt(os.path.join(d, "occ.txt"), r_ref, fmt="%d")
+        m.close()
+    with open(os.path.join(HERE, "golden.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
