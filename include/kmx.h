@@ -1,0 +1,115 @@
+/* include/kmx.h -- C ABI of libkmx.so, the MI355X-native KModel insert/query hot path.
+ *
+ * The reference (lzhLab/kmcEx) has no FFI layer: its boundary is the header-only C++ class KModel plus
+ * two factory functions (kmodel.hpp).  This C ABI is what a binding for that class binds; every entry
+ * point cites the reference interface it replaces.  include/kmodel.hpp is the C++ facade with the
+ * reference's own names (get_model / init / init_KModel / kmer_to_occ / save / load) on top of it.
+ *
+ * Conventions
+ *   - plain C types, caller-owned buffers, no exceptions cross the boundary;
+ *   - every function returns 0 on success, a negative KMX_E_* code otherwise; kmx_last_error() gives
+ *     a thread-local message;
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with
+ *     KMX_E_NODEVICE;
+ *   - packed k-mers: W = ceil(k/32) uint64 words per k-mer, word 0 most significant, holding the
+ *     2k-bit integer right-aligned, A=0 C=1 G=2 T=3, first base most significant (tools.hpp:63-76);
+ *   - "_dev" variants take DEVICE pointers valid on the model's device and enqueue on the model's
+ *     stream (kmx_set_stream); they synchronise that stream only where a count has to reach the host.
+ */
+#ifndef KMX_H
+#define KMX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMX_OK            0
+#define KMX_E_ARG        -1   /* bad argument / parameter combination                         */
+#define KMX_E_NODEVICE   -2   /* no HIP device, or a HIP call failed                           */
+#define KMX_E_IO         -3   /* file missing / short / malformed                              */
+#define KMX_E_STATE      -4   /* call out of order (e.g. insert before begin, query before build) */
+#define KMX_E_RANGE      -5   /* a count outside [ci, cs] (reference: out-of-bounds index)      */
+#define KMX_E_NOMEM      -6
+
+typedef struct kmx_model kmx_model;
+
+typedef struct kmx_stats {
+	uint64_t n_total;         /* k-mers listed (CKMCFile::KmerCount, kmodel.hpp:429)            */
+	uint64_t n_km;            /* k-mers routed to the coupled arrays (kmodel.hpp:433)           */
+	uint64_t n_bf[3];         /* k-mers per Bloom-filter class (kmodel.hpp:425-428)             */
+	uint64_t attempts;        /* coupled-array insert attempts  (insert_to_array calls, :590)   */
+	uint64_t successes;       /* ... that succeeded                                             */
+	uint64_t rest_entries;    /* rows of rest.bin (rest.hpp:53 suffix_bin_count)                */
+	uint64_t km_byte_size;    /* bytes per tag / value array (kmodel.hpp:437)                   */
+	uint64_t byte_km_back;    /* kmodel.hpp:439                                                 */
+	uint64_t byte_bf[3], byte_bf_back[3];                          /* kmodel.hpp:411-416        */
+	uint64_t fast_commits;    /* successes decided by the uncontended fast path                 */
+	uint64_t contended;       /* attempts that went through the ordered slow path               */
+	uint64_t finisher_iters;  /* iterations of the single-workgroup ordered finisher            */
+	uint64_t blocks, rounds;  /* nb*2^18 blocks and rounds executed                             */
+	int32_t  k, ci, cs, nh, nb, bf_num;
+	int32_t  device, reserved;
+} kmx_stats;
+
+const char *kmx_last_error(void);
+int kmx_device_count(void);
+
+/* get_model(ci, cs, num_hash, num_bit)                                     kmodel.hpp:674-677 */
+int kmx_create(int ci, int cs, int nh, int nb, kmx_model **out);
+/* the reference never frees a model; the handle owns all device memory                        */
+int kmx_destroy(kmx_model *m);
+/* stream (hipStream_t) used by every later call on this model; NULL = the default stream       */
+int kmx_set_stream(kmx_model *m, void *hip_stream);
+
+/* KModel::init(db_file): two passes over the KMC listing + rest build      kmodel.hpp:57-86   */
+int kmx_build_from_kmc(kmx_model *m, const char *db_prefix);
+
+/* The same build, streamed.  begin = get_km_kmer_count's result + init_km_bit (kmodel.hpp:423-471):
+ * n_bf[i] = number of k-mers with count ci+i (i < bf_num), n_total = KmerCount().                */
+int kmx_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total);
+/* pass 2 (kmodel.hpp:68-74): batches in LISTING ORDER; host or device pointers                   */
+int kmx_insert_batch(kmx_model *m, const uint64_t *kmers, const uint32_t *counts, uint64_t n);
+int kmx_insert_batch_dev(kmx_model *m, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n);
+/* push_last_to_array / push_last_to_bloomfilter / kld->build()             kmodel.hpp:76-80   */
+int kmx_finish(kmx_model *m);
+/* one call = pass 1 (device histogram) + begin + insert + finish on a device-resident listing     */
+int kmx_build_dev(kmx_model *m, int k, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n);
+int kmx_build_host(kmx_model *m, int k, const uint64_t *kmers, const uint32_t *counts, uint64_t n);
+
+/* vector<int> KModel::kmer_to_occ(vector<string>, t_num)                   kmodel.hpp:90-98   */
+int kmx_query_packed(kmx_model *m, const uint64_t *kmers, uint64_t n, int32_t *out);
+int kmx_query_packed_dev(kmx_model *m, const uint64_t *d_kmers, uint64_t n, int32_t *d_out);
+/* n records of `stride` bytes holding `len` characters each (not NUL-terminated)                 */
+int kmx_query_ascii(kmx_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out);
+
+/* KModel::save(dir) -> header, km.bin, rest.bin (dir must exist)           kmodel.hpp:173-206 */
+int kmx_save(kmx_model *m, const char *dir);
+/* get_model(save_dir) = header parse + KModel::load                        kmodel.hpp:680-696, :209-235 */
+int kmx_load(const char *dir, kmx_model **out);
+
+int kmx_get_stats(kmx_model *m, kmx_stats *st);
+
+/* Raw on-disk-layout views for byte-level parity checks (kmodel.hpp:183-202).
+ * which: 0 bf[i], 1 bf_back[i], 2 km_back, 3 value array i (bit_array_1), 4 tag array i (bit_array_2),
+ *        5 claim bits of array i (must be all zero between rounds; internal invariant).             */
+int kmx_download(kmx_model *m, int which, int index, uint8_t *dst, uint64_t capacity, uint64_t *written);
+
+/* Primitive known-answer surface, evaluated ON THE DEVICE (tools.hpp:16-50, :160-167).
+ * hashes[n*n_seeds]: murmur_hash64 of the k-mer string (whole=1) or its (k-2)-mer (whole=0).       */
+int kmx_debug_hash(int k, const uint64_t *kmers, uint64_t n, const uint32_t *seeds, int n_seeds, int whole, uint64_t *hashes);
+int kmx_debug_min_kmer(int k, const uint64_t *kmers, uint64_t n, uint64_t *out);
+/* OccuBin tables (occu_bin.hpp:27-83): bin_of_occ[cs+1], mean_of_bin[2^nh]                         */
+int kmx_occubin(int cs, int nh, uint32_t *bin_of_occ, uint32_t *mean_of_bin);
+
+/* Random-access ceiling of the memory system for this access pattern: `touches` random
+ * 8-byte loads (mode 0) or 64-bit atomic ORs (mode 1) over `bytes` of device memory; seconds out.  */
+int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds);
+
+/* timing of the last build, seconds measured with HIP events on the model's stream */
+int kmx_last_build_seconds(kmx_model *m, double *insert_kernels_s, double *total_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,250 @@
+"""Python mirror of the reference's KModel interface (kmodel.hpp) over the C ABI of libkmx.so.
+
+Names follow the reference / its README: ``get_model``, ``init`` (``init_KModel``), ``kmer_to_occ``,
+``save`` (``save_model``), ``load`` (``load_model``).  All compute happens in the HIP library; this module
+only marshals pointers.  It raises ``KmxError`` (there is no CPU fallback) when the library or a GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+
+
+class KmxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"kmx error {code}: {msg}")
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_total", C.c_uint64), ("n_km", C.c_uint64), ("n_bf", C.c_uint64 * 3),
+                ("attempts", C.c_uint64), ("successes", C.c_uint64), ("rest_entries", C.c_uint64),
+                ("km_byte_size", C.c_uint64), ("byte_km_back", C.c_uint64),
+                ("byte_bf", C.c_uint64 * 3), ("byte_bf_back", C.c_uint64 * 3),
+                ("fast_commits", C.c_uint64), ("contended", C.c_uint64), ("finisher_iters", C.c_uint64),
+                ("blocks", C.c_uint64), ("rounds", C.c_uint64),
+                ("k", C.c_int32), ("ci", C.c_int32), ("cs", C.c_int32), ("nh", C.c_int32), ("nb", C.c_int32),
+                ("bf_num", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+# every symbol include/kmx.h declares (tests check that the library exports all of them)
+ABI_SYMBOLS = [
+    "kmx_last_error", "kmx_device_count", "kmx_create", "kmx_destroy", "kmx_set_stream", "kmx_build_from_kmc",
+    "kmx_begin", "kmx_insert_batch", "kmx_insert_batch_dev", "kmx_finish", "kmx_build_dev", "kmx_build_host",
+    "kmx_query_packed", "kmx_query_packed_dev", "kmx_query_ascii", "kmx_save", "kmx_load", "kmx_get_stats",
+    "kmx_download", "kmx_debug_hash", "kmx_debug_min_kmer", "kmx_occubin", "kmx_microbench", "kmx_last_build_seconds",
+]
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load_library():
+    """dlopen libkmx.so (building it first if hipcc is available and the sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path) or _build.stale():
+        try:
+            _build.build_lib()
+        except Exception as e:  # noqa: BLE001
+            if not os.path.exists(path):
+                raise KmxError(-2, f"libkmx.so is missing and could not be built ({e}); there is no CPU fallback")
+    L = C.CDLL(path)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    L.kmx_last_error.restype = C.c_char_p
+    L.kmx_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
+    L.kmx_destroy.argtypes = [vp]
+    L.kmx_set_stream.argtypes = [vp, vp]
+    L.kmx_build_from_kmc.argtypes = [vp, C.c_char_p]
+    L.kmx_begin.argtypes = [vp, i32, C.POINTER(u64), u64]
+    L.kmx_insert_batch.argtypes = [vp, vp, vp, u64]
+    L.kmx_insert_batch_dev.argtypes = [vp, vp, vp, u64]
+    L.kmx_finish.argtypes = [vp]
+    L.kmx_build_dev.argtypes = [vp, i32, vp, vp, u64]
+    L.kmx_build_host.argtypes = [vp, i32, vp, vp, u64]
+    L.kmx_query_packed.argtypes = [vp, vp, u64, vp]
+    L.kmx_query_packed_dev.argtypes = [vp, vp, u64, vp]
+    L.kmx_query_ascii.argtypes = [vp, C.c_char_p, i32, i32, u64, vp]
+    L.kmx_save.argtypes = [vp, C.c_char_p]
+    L.kmx_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.kmx_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.kmx_download.argtypes = [vp, i32, i32, vp, u64, C.POINTER(u64)]
+    L.kmx_debug_hash.argtypes = [i32, vp, u64, vp, i32, i32, vp]
+    L.kmx_debug_min_kmer.argtypes = [i32, vp, u64, vp]
+    L.kmx_occubin.argtypes = [i32, i32, vp, vp]
+    L.kmx_microbench.argtypes = [i32, u64, u64, i32, C.POINTER(C.c_double)]
+    L.kmx_last_build_seconds.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def _chk(rc: int):
+    if rc != 0:
+        raise KmxError(rc, load_library().kmx_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    return load_library().kmx_device_count()
+
+
+def occubin(cs: int, nh: int):
+    b = np.zeros(cs + 1, dtype=np.uint32)
+    m = np.zeros(1 << nh, dtype=np.uint32)
+    _chk(load_library().kmx_occubin(cs, nh, b.ctypes.data, m.ctypes.data))
+    return b, m
+
+
+def debug_hash(k: int, kmers: np.ndarray, seeds, whole: bool = True) -> np.ndarray:
+    kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+    n = kmers.size // ((k + 31) // 32)
+    out = np.zeros((n, len(seeds)), dtype=np.uint64)
+    _chk(load_library().kmx_debug_hash(k, kmers.ctypes.data, n, seeds.ctypes.data, len(seeds), int(whole), out.ctypes.data))
+    return out
+
+
+def debug_min_kmer(k: int, kmers: np.ndarray) -> np.ndarray:
+    kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+    n = kmers.size // ((k + 31) // 32)
+    out = np.zeros_like(kmers)
+    _chk(load_library().kmx_debug_min_kmer(k, kmers.ctypes.data, n, out.ctypes.data))
+    return out
+
+
+def microbench(mode: int, nbytes: int, touches: int, iters: int = 3) -> float:
+    s = C.c_double(0)
+    _chk(load_library().kmx_microbench(mode, nbytes, touches, iters, C.byref(s)))
+    return s.value
+
+
+class KModel:
+    """Handle on one model resident in HBM.  Mirrors reference class KModel (kmodel.hpp:39-672)."""
+
+    DL = {"bf": 0, "bf_back": 1, "km_back": 2, "value": 3, "tag": 4, "claims": 5}
+
+    def __init__(self, ci: int = 1, cs: int = 1023, num_hash: int = 7, num_bit: int = 5, _handle=None):
+        self.L = load_library()
+        if _handle is None:
+            h = C.c_void_p()
+            _chk(self.L.kmx_create(ci, cs, num_hash, num_bit, C.byref(h)))
+            _handle = h
+        self.h = _handle
+
+    # ---- build
+    def init(self, db_file: str) -> None:                      # kmodel.hpp:57
+        _chk(self.L.kmx_build_from_kmc(self.h, db_file.encode()))
+
+    init_KModel = init                                         # README.md:76
+
+    def build_packed(self, k: int, kmers: np.ndarray, counts: np.ndarray) -> None:
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        _chk(self.L.kmx_build_host(self.h, k, kmers.ctypes.data, counts.ctypes.data, len(counts)))
+
+    def build_dev(self, k: int, d_kmers_ptr: int, d_counts_ptr: int, n: int) -> None:
+        _chk(self.L.kmx_build_dev(self.h, k, d_kmers_ptr, d_counts_ptr, n))
+
+    def begin(self, k: int, n_bf, n_total: int) -> None:
+        arr = (C.c_uint64 * 3)(*[int(x) for x in list(n_bf) + [0, 0, 0]][:3])
+        _chk(self.L.kmx_begin(self.h, k, arr, n_total))
+
+    def insert_batch(self, kmers: np.ndarray, counts: np.ndarray) -> None:
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        _chk(self.L.kmx_insert_batch(self.h, kmers.ctypes.data, counts.ctypes.data, len(counts)))
+
+    def insert_batch_dev(self, d_kmers_ptr: int, d_counts_ptr: int, n: int) -> None:
+        _chk(self.L.kmx_insert_batch_dev(self.h, d_kmers_ptr, d_counts_ptr, n))
+
+    def finish(self) -> None:
+        _chk(self.L.kmx_finish(self.h))
+
+    def set_stream(self, stream_ptr: int) -> None:
+        _chk(self.L.kmx_set_stream(self.h, stream_ptr))
+
+    # ---- query
+    def kmer_to_occ(self, kmers, t_num: int = 4):             # kmodel.hpp:90,100 (t_num kept for signature parity)
+        single = isinstance(kmers, str)
+        strs = [kmers] if single else list(kmers)
+        if not strs:
+            return []
+        ln = len(strs[0])
+        if any(len(s) != ln for s in strs):
+            raise KmxError(-1, "all k-mers of a batch must have the model's k")
+        out = np.zeros(len(strs), dtype=np.int32)
+        _chk(self.L.kmx_query_ascii(self.h, "".join(strs).encode(), ln, ln, len(strs), out.ctypes.data))
+        return int(out[0]) if single else out.tolist()
+
+    def kmer_to_occ_packed(self, kmers: np.ndarray) -> np.ndarray:
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        W = (self.stats().k + 31) // 32
+        n = kmers.size // W
+        out = np.zeros(n, dtype=np.int32)
+        _chk(self.L.kmx_query_packed(self.h, kmers.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def kmer_to_occ_dev(self, d_kmers_ptr: int, n: int, d_out_ptr: int) -> None:
+        _chk(self.L.kmx_query_packed_dev(self.h, d_kmers_ptr, n, d_out_ptr))
+
+    # ---- persistence
+    def save(self, save_dir: str) -> None:                    # kmodel.hpp:173
+        _chk(self.L.kmx_save(self.h, save_dir.encode()))
+
+    save_model = save                                          # README.md:78
+
+    @classmethod
+    def load(cls, save_dir: str) -> "KModel":                  # kmodel.hpp:680-696 + :209
+        L = load_library()
+        h = C.c_void_p()
+        _chk(L.kmx_load(save_dir.encode(), C.byref(h)))
+        return cls(_handle=h)
+
+    load_model = load
+
+    # ---- introspection
+    def stats(self) -> Stats:
+        st = Stats()
+        _chk(self.L.kmx_get_stats(self.h, C.byref(st)))
+        return st
+
+    def download(self, which: str, index: int = 0) -> np.ndarray:
+        st = self.stats()
+        cap = max(int(st.km_byte_size), int(st.byte_km_back), max(st.byte_bf), max(st.byte_bf_back), 1)
+        buf = np.zeros(cap, dtype=np.uint8)
+        w = C.c_uint64(0)
+        _chk(self.L.kmx_download(self.h, self.DL[which], index, buf.ctypes.data, cap, C.byref(w)))
+        return buf[:w.value].copy()
+
+    def build_seconds(self) -> float:
+        a, b = C.c_double(0), C.c_double(0)
+        _chk(self.L.kmx_last_build_seconds(self.h, C.byref(a), C.byref(b)))
+        return b.value
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.L.kmx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def get_model(ci_or_dir=1, cs: int = 1023, num_hash: int = 7, num_bit: int = 5) -> KModel:
+    """Both reference factories (kmodel.hpp:674-677 and :680-696)."""
+    if isinstance(ci_or_dir, (str, os.PathLike)):
+        return KModel.load(os.fspath(ci_or_dir))
+    return KModel(int(ci_or_dir), cs, num_hash, num_bit)

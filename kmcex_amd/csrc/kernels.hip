@@ -1,0 +1,921 @@
+// kernels.hip -- hand-written gfx950 kernels of the KModel insert/query hot path.
+//
+// One lane = one k-mer.  Wave64; 256-thread workgroups; grids of >= 1024 workgroups on the hot kernels.
+// The path is HBM random-access bound (1-bit gathers/scatters addressed by MurmurHash64A), so there is
+// no MFMA anywhere: the levers are (i) one 8-byte cell per touched position (tag+value+claims
+// co-located), (ii) all nh touches of a k-mer in flight at once, (iii) no host round trips inside a
+// block: list lengths, contended sets and statistics stay in HBM and every kernel reads them there.
+//
+// Insert (reference: kmodel.hpp:543-622, sequential greedy) is reproduced bit for bit:
+//   round = nb independent (buffer i, array (i+t)%nb) pairs.  Per pair the reference walks the buffer
+//   in order; a k-mer fits iff no set tag carries a different value bit.  Here:
+//   A  check_claim   every k-mer checks the committed state; the ones that fit ("candidates") set a
+//                    claim bit (per wanted value) on every still-untagged position they touch;
+//   B  verify_commit a candidate that sees no OPPOSITE claim on its untagged positions cannot interact
+//                    with any other candidate of the list, so it commits (atomic OR) in parallel;
+//                    the others form the contended set U;
+//   S  slow path     U is resolved in list order by epoch-tagged min-index reservations: a k-mer that
+//                    holds the smallest index on all its slots has no earlier undecided k-mer touching
+//                    them, so its outcome is the sequential one.  Two grid-wide sub-rounds, then a
+//                    single-workgroup finisher that iterates until the set is empty.
+//   R  reorder       the reference's unstable compaction (kmodel.hpp:529-540) as count/scatter/fill.
+#include "kmx_types.h"
+
+__constant__ u32 c_seeds[128] = {   // tools.hpp:9 -- 128 consecutive primes (data)
+	46757, 46769, 46771, 46807, 46811, 46817, 46819, 46829, 46831, 46853, 46861, 46867, 46877, 46889, 46901, 46919,
+	46933, 46957, 46993, 46997, 47017, 47041, 47051, 47057, 47059, 47087, 47093, 47111, 47119, 47123, 47129, 47137,
+	47143, 47147, 47149, 47161, 47189, 47207, 47221, 47237, 47251, 47269, 47279, 47287, 47293, 47297, 47303, 47309,
+	47317, 47339, 47351, 47353, 47363, 47381, 47387, 47389, 47407, 47417, 47419, 47431, 47441, 47459, 47491, 47497,
+	47501, 47507, 47513, 47521, 47527, 47533, 47543, 47563, 47569, 47581, 47591, 47599, 47609, 47623, 47629, 47639,
+	47653, 47657, 47659, 47681, 47699, 47701, 47711, 47713, 47717, 47737, 47741, 47743, 47777, 47779, 47791, 47797,
+	47807, 47809, 47819, 47837, 47843, 47857, 47869, 47881, 47903, 47911, 47917, 47933, 47939, 47947, 47951, 47963,
+	47969, 47977, 47981, 48017, 48023, 48029, 48049, 48073, 48079, 48091, 48109, 48119, 48121, 48131, 48157, 48163};
+
+// ------------------------------------------------------------------------------------------ helpers
+template <int W> __device__ __forceinline__ void load_kmer(const u64 *base, u64 i, u64 *v)
+{
+#pragma unroll
+	for (int w = 0; w < W; w++) v[w] = base[i * W + w];
+}
+template <int W> __device__ __forceinline__ void store_kmer(u64 *base, u64 i, const u64 *v)
+{
+#pragma unroll
+	for (int w = 0; w < W; w++) base[i * W + w] = v[w];
+}
+
+// Bloom insert / probe of one pre-mixed string with HashSeeds[0..nhash-1] (kmodel.hpp:498-506, :373-383).
+// Empty filter: nothing to set, every probe misses (divergence D2).
+template <int W> __device__ __forceinline__ void bloom_insert_pm(const Premixed<W> &pm, const StrGeom g, u32 *bits, const ModU64 md, int nhash)
+{
+	if (!md.d) return;
+	for (int j = 0; j < nhash; j++) bloom_set(bits, mod_u64(murmur_seeded<W>(pm, g, c_seeds[j]), md));
+}
+template <int W> __device__ __forceinline__ bool bloom_check_pm(const Premixed<W> &pm, const StrGeom g, const u32 *bits, const ModU64 md, int nhash)
+{
+	if (!md.d) return false;
+	bool ok = true;
+	for (int j = 0; j < nhash && ok; j++) ok = bloom_get(bits, mod_u64(murmur_seeded<W>(pm, g, c_seeds[j]), md));
+	return ok;
+}
+
+__device__ __forceinline__ u64 cell_load_coherent(const u64 *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_load sc1: bypasses this CU's L1
+}
+
+// The nh touches of one k-mer on one coupled array.
+template <int NHM> struct Touches {
+	u64 pos[NHM];
+	u64 cell[NHM];
+};
+
+template <int W, int NHM, bool COHERENT>
+__device__ __forceinline__ void gather_touches(const ModelDev &md, const Premixed<W> &pm, int a, Touches<NHM> &t)
+{
+	const u64 *cells = md.cells[a];
+	const int sbase = a * md.nh;
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if (j < md.nh) {
+			t.pos[j] = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(sbase + j) & 127]), md.km_mod);
+			t.cell[j] = COHERENT ? cell_load_coherent(cells + (t.pos[j] >> 4)) : cells[t.pos[j] >> 4];
+		}
+}
+
+// insert_to_array's check (kmodel.hpp:604-610): fail iff a set tag carries the other value
+template <int NHM> __device__ __forceinline__ bool touches_conflict(const ModelDev &md, const Touches<NHM> &t, u32 bin)
+{
+	bool fail = false;
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if (j < md.nh) {
+			u32 b = bit_in_cell(t.pos[j]);
+			u32 tag = (u32)(t.cell[j] >> (16 + b)) & 1u, val = (u32)(t.cell[j] >> b) & 1u;
+			fail |= tag && (val != ((bin >> j) & 1u));
+		}
+	return fail;
+}
+
+// kmodel.hpp:611-618 + :548-550: set tag (and value) bits, then the (k-2)-mer goes into km_back
+template <int W, int NHM>
+__device__ __forceinline__ void commit_touches(const ModelDev &md, const Touches<NHM> &t, u32 bin, int a, const Aligned<W> &al)
+{
+	u64 *cells = md.cells[a];
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if (j < md.nh) {
+			u32 b = bit_in_cell(t.pos[j]);
+			if (!((t.cell[j] >> (16 + b)) & 1ULL))          // already tagged => already carries this value
+				atomicOr(cells + (t.pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
+		}
+	Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
+	bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+}
+
+// ------------------------------------------------------------------------------------------ pass 1
+// get_km_kmer_count (kmodel.hpp:423-428): histogram of the bf_num lowest counts.
+__global__ __launch_bounds__(256) void k_histogram(const u32 *counts, u64 n, int ci, int cs, int bf_num, u64 *n_bf, u64 *stats)
+{
+	u64 local[3] = {0, 0, 0}, bad = 0;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+		u32 c = counts[i];
+		if (c < (u32)ci || c > (u32)cs) bad++;
+		else if (c < (u32)(ci + bf_num)) local[c - ci]++;
+	}
+	for (int f = 0; f < 3; f++)
+		if (local[f]) atomicAdd(n_bf + f, local[f]);
+	if (bad) atomicAdd(stats + ST_BAD_COUNT, bad);
+}
+
+// ------------------------------------------------------------------------------------------ classification
+// Pass 2 front end (kmodel.hpp:70-73): Bloom-class k-mers are inserted right here (commutative ORs, any
+// order); coupled-array k-mers are compacted, in listing order, into the staging stream.
+#define CLS_TILE 2048
+template <int W> __global__ __launch_bounds__(256) void k_classify_count(ModelDev md, const u64 *kmers, const u32 *counts, u64 n, int *tile_cnt, u64 *stats)
+{
+	__shared__ int s_cnt;
+	if (threadIdx.x == 0) s_cnt = 0;
+	__syncthreads();
+	int mine = 0;
+	u64 base = (u64)blockIdx.x * CLS_TILE;
+	for (int q = 0; q < CLS_TILE / 256; q++) {
+		u64 i = base + (u64)q * 256 + threadIdx.x;
+		if (i >= n) break;
+		u32 c = counts[i];
+		if (c < (u32)md.ci || c > (u32)md.cs) { atomicAdd(stats + ST_BAD_COUNT, 1ULL); continue; }
+		if (c < (u32)(md.ci + md.bf_num)) {
+			int f = (int)(c - (u32)md.ci);
+			u64 v[W];
+			load_kmer<W>(kmers, i, v);
+			Aligned<W> al = left_align<W>(v, md.k);
+			Premixed<W> pf = premix_string<W>(al, md.gfull);
+			bloom_insert_pm<W>(pf, md.gfull, md.bf[f], md.bf_mod[f], md.nh - 1);                 // kmodel.hpp:474
+			Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
+			bloom_insert_pm<W>(pb, md.gback, md.bf_back[f], md.bf_back_mod[f], md.nh - 2);       // kmodel.hpp:475-476
+		} else mine++;
+	}
+	if (mine) atomicAdd(&s_cnt, mine);
+	__syncthreads();
+	if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_cnt;
+}
+
+// exclusive scan of up to 2^20 tile counts by one workgroup; total -> *total_out
+__global__ __launch_bounds__(1024) void k_scan_tiles(const int *cnt, int *off, int n_tiles, int *total_out)
+{
+	__shared__ int s[1024];
+	__shared__ int carry;
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	for (int base = 0; base < n_tiles; base += 1024) {
+		int i = base + threadIdx.x;
+		int v = i < n_tiles ? cnt[i] : 0;
+		s[threadIdx.x] = v;
+		__syncthreads();
+		for (int d = 1; d < 1024; d <<= 1) {
+			int t = threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+			__syncthreads();
+			s[threadIdx.x] += t;
+			__syncthreads();
+		}
+		if (i < n_tiles) off[i] = carry + s[threadIdx.x] - v;
+		__syncthreads();
+		if (threadIdx.x == 1023) carry += s[1023];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *total_out = carry;
+}
+
+// block-wide exclusive scan of one int per thread (256 threads)
+__device__ __forceinline__ int block_excl_scan_256(int v, int *s_tmp, int *total)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	int incl = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		int t = __shfl_up(incl, d, 64);
+		if (lane >= d) incl += t;
+	}
+	if (lane == 63) s_tmp[wave] = incl;
+	__syncthreads();
+	int wbase = 0, tot = 0;
+#pragma unroll
+	for (int w = 0; w < 4; w++) {
+		int c = s_tmp[w];
+		if (w < wave) wbase += c;
+		tot += c;
+	}
+	__syncthreads();
+	if (total) *total = tot;
+	return wbase + incl - v;
+}
+
+template <int W> __global__ __launch_bounds__(256) void k_classify_scatter(ModelDev md, const u64 *kmers, const u32 *counts, u64 n, const int *tile_off, u64 *stg_kmers, u32 *stg_counts, u64 stg_base)
+{
+	__shared__ int s_tmp[4];
+	constexpr int PER = CLS_TILE / 256;
+	u64 base = (u64)blockIdx.x * CLS_TILE + (u64)threadIdx.x * PER;
+	int flag[PER], cnt = 0;
+#pragma unroll
+	for (int q = 0; q < PER; q++) {
+		u64 i = base + q;
+		flag[q] = 0;
+		if (i < n) {
+			u32 c = counts[i];
+			flag[q] = (c >= (u32)(md.ci + md.bf_num) && c <= (u32)md.cs) ? 1 : 0;
+		}
+		cnt += flag[q];
+	}
+	int off = block_excl_scan_256(cnt, s_tmp, nullptr) + tile_off[blockIdx.x];
+#pragma unroll
+	for (int q = 0; q < PER; q++)
+		if (flag[q]) {
+			u64 v[W];
+			load_kmer<W>(kmers, base + q, v);
+			store_kmer<W>(stg_kmers, stg_base + (u64)off, v);
+			stg_counts[stg_base + (u64)off] = counts[base + q];
+			off++;
+		}
+}
+
+// lists of a fresh block: identity permutation (kmodel.hpp:509-513 fills row-major in listing order)
+__global__ __launch_bounds__(256) void k_block_init(BlockDev bd, int nb, int pp, int n_in_block)
+{
+	int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	bd.list[pp][(u64)i * KMX_BUCKET + x] = (u32)x;
+	if (x == 0) {
+		int lo = i * (int)KMX_BUCKET;
+		int ni = n_in_block - lo;
+		bd.n[i] = ni < 0 ? 0 : (ni > (int)KMX_BUCKET ? (int)KMX_BUCKET : ni);      // kmodel.hpp:521-525
+	}
+}
+
+// reset the per-round counters
+__global__ void k_round_reset(BlockDev bd, int nb)
+{
+	int t = threadIdx.x;
+	if (t < KMX_NSLOW * nb) bd.Un[t] = 0;
+	if (t < nb) { bd.m[t] = 0; bd.h[t] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------ A: check + claim
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_claim(ModelDev md, BlockDev bd, int t, int pp)
+{
+	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	const int n = bd.n[i];
+	if (x >= n) return;
+	if (x == 0) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
+	const u64 row = (u64)i * KMX_BUCKET;
+	const u32 idx = bd.list[pp][row + x];
+	u64 v[W];
+	load_kmer<W>(bd.kmers, row + idx, v);
+	const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+	const int a = (i + t) % md.nb;                                  // kmodel.hpp:563
+	Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
+	Touches<NHM> tc;
+	gather_touches<W, NHM, false>(md, pm, a, tc);
+	if (touches_conflict<NHM>(md, tc, bin)) { bd.status[row + x] = SLOT_FAILED; return; }
+	bd.status[row + x] = SLOT_UNDECIDED;
+	u64 *cells = md.cells[a];
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if (j < md.nh) {
+			u32 b = bit_in_cell(tc.pos[j]);
+			if (!((tc.cell[j] >> (16 + b)) & 1ULL)) atomicOr(cells + (tc.pos[j] >> 4), CELL_CLAIM((bin >> j) & 1u, b));
+		}
+}
+
+// ------------------------------------------------------------------------------------------ B: verify + commit
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_verify_commit(ModelDev md, BlockDev bd, int t, int pp)
+{
+	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	if (x >= bd.n[i]) return;
+	const u64 row = (u64)i * KMX_BUCKET;
+	if (bd.status[row + x] != SLOT_UNDECIDED) return;
+	const u32 idx = bd.list[pp][row + x];
+	u64 v[W];
+	load_kmer<W>(bd.kmers, row + idx, v);
+	const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+	const int a = (i + t) % md.nb;
+	Aligned<W> al = left_align<W>(v, md.k);
+	Premixed<W> pm = premix_string<W>(al, md.gfull);
+	Touches<NHM> tc;
+	gather_touches<W, NHM, false>(md, pm, a, tc);
+	bool contended = false;
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if (j < md.nh) {
+			u32 b = bit_in_cell(tc.pos[j]);
+			u32 want = (bin >> j) & 1u;
+			bool tagged = (tc.cell[j] >> (16 + b)) & 1ULL;
+			contended |= !tagged && ((tc.cell[j] >> (32 + 16 * (1 - want) + b)) & 1ULL);
+		}
+	if (!contended) {
+		commit_touches<W, NHM>(md, tc, bin, a, al);
+		bd.status[row + x] = SLOT_INSERTED;
+		atomicAdd(bd.stats + ST_SUCCESSES, 1ULL);
+		atomicAdd(bd.stats + ST_FAST, 1ULL);
+	} else {
+		int p = atomicAdd(bd.Un + i, 1);
+		bd.U[0][row + p] = (u32)x;
+		atomicAdd(bd.stats + ST_CONTENDED, 1ULL);
+	}
+}
+
+// ------------------------------------------------------------------------------------------ S: ordered slow path
+__device__ __forceinline__ u64 resv_key(u64 epoch, u32 x) { return (epoch << 20) | (u64)(0xFFFFFu - x); }
+__device__ __forceinline__ u64 *resv_slot(const BlockDev &bd, int i, u64 pos) { return bd.R + (u64)i * KMX_RSIZE + (pos & (KMX_RSIZE - 1)); }
+
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_reserve(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch)
+{
+	const int i = blockIdx.y, u = blockIdx.x * 256 + threadIdx.x;
+	if (u >= bd.Un[s * md.nb + i]) return;
+	const u64 row = (u64)i * KMX_BUCKET;
+	const u32 x = bd.U[s][row + u];
+	const u32 idx = bd.list[pp][row + x];
+	u64 v[W];
+	load_kmer<W>(bd.kmers, row + idx, v);
+	const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+	const int a = (i + t) % md.nb;
+	Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
+	Touches<NHM> tc;
+	gather_touches<W, NHM, false>(md, pm, a, tc);
+	if (touches_conflict<NHM>(md, tc, bin)) { bd.status[row + x] = SLOT_FAILED; return; }
+	const u64 key = resv_key(epoch, x);
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if (j < md.nh) {
+			u32 b = bit_in_cell(tc.pos[j]);
+			if (!((tc.cell[j] >> (16 + b)) & 1ULL)) atomicMax(resv_slot(bd, i, tc.pos[j]), key);
+		}
+}
+
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch)
+{
+	const int i = blockIdx.y, u = blockIdx.x * 256 + threadIdx.x;
+	if (u >= bd.Un[s * md.nb + i]) return;
+	const u64 row = (u64)i * KMX_BUCKET;
+	const u32 x = bd.U[s][row + u];
+	if (bd.status[row + x] != SLOT_UNDECIDED) return;
+	const u32 idx = bd.list[pp][row + x];
+	u64 v[W];
+	load_kmer<W>(bd.kmers, row + idx, v);
+	const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+	const int a = (i + t) % md.nb;
+	Aligned<W> al = left_align<W>(v, md.k);
+	Premixed<W> pm = premix_string<W>(al, md.gfull);
+	Touches<NHM> tc;
+	gather_touches<W, NHM, false>(md, pm, a, tc);
+	const u64 key = resv_key(epoch, x);
+	// A position that another k-mer of this sub-round has tagged since the reserve pass was won by a smaller
+	// index (it held our common slot), so it must be re-checked like committed state; if it now conflicts we
+	// stay undecided and the next reserve pass marks us failed.
+	bool mine = !touches_conflict<NHM>(md, tc, bin);
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if (j < md.nh) {
+			u32 b = bit_in_cell(tc.pos[j]);
+			if (!((tc.cell[j] >> (16 + b)) & 1ULL)) mine &= (*resv_slot(bd, i, tc.pos[j]) == key);
+		}
+	if (mine) {
+		commit_touches<W, NHM>(md, tc, bin, a, al);
+		bd.status[row + x] = SLOT_INSERTED;
+		atomicAdd(bd.stats + ST_SUCCESSES, 1ULL);
+	} else {
+		int p = atomicAdd(bd.Un + (s + 1) * md.nb + i, 1);
+		bd.U[s + 1][row + p] = (u32)x;
+	}
+}
+
+// Finisher: ONE workgroup per list iterates reserve/resolve until its set is empty.  Every iteration
+// decides at least the smallest undecided index, so the loop ends after at most |U| iterations.
+template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch0)
+{
+	__shared__ int s_pending;
+	const int i = blockIdx.x;
+	const int n = bd.Un[s * md.nb + i];
+	if (n == 0) return;
+	const u64 row = (u64)i * KMX_BUCKET;
+	const int a = (i + t) % md.nb;
+	u64 epoch = epoch0;
+	for (;; epoch++) {
+		if (threadIdx.x == 0) s_pending = 0;
+		__syncthreads();
+		for (int u = threadIdx.x; u < n; u += 1024) {
+			const u32 x = bd.U[s][row + u];
+			if (bd.status[row + x] != SLOT_UNDECIDED) continue;
+			const u32 idx = bd.list[pp][row + x];
+			u64 v[W];
+			load_kmer<W>(bd.kmers, row + idx, v);
+			const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
+			Touches<NHM> tc;
+			gather_touches<W, NHM, true>(md, pm, a, tc);
+			if (touches_conflict<NHM>(md, tc, bin)) { bd.status[row + x] = SLOT_FAILED; continue; }
+			const u64 key = resv_key(epoch, x);
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh) {
+					u32 b = bit_in_cell(tc.pos[j]);
+					if (!((tc.cell[j] >> (16 + b)) & 1ULL)) atomicMax(resv_slot(bd, i, tc.pos[j]), key);
+				}
+			s_pending = 1;
+		}
+		__threadfence();
+		__syncthreads();
+		const int pending = s_pending;
+		__syncthreads();
+		if (!pending) break;
+		if (threadIdx.x == 0) atomicAdd(bd.stats + ST_FIN_ITERS, 1ULL);
+		for (int u = threadIdx.x; u < n; u += 1024) {
+			const u32 x = bd.U[s][row + u];
+			if (bd.status[row + x] != SLOT_UNDECIDED) continue;
+			const u32 idx = bd.list[pp][row + x];
+			u64 v[W];
+			load_kmer<W>(bd.kmers, row + idx, v);
+			const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+			Aligned<W> al = left_align<W>(v, md.k);
+			Premixed<W> pm = premix_string<W>(al, md.gfull);
+			Touches<NHM> tc;
+			gather_touches<W, NHM, true>(md, pm, a, tc);
+			const u64 key = resv_key(epoch, x);
+			bool mine = !touches_conflict<NHM>(md, tc, bin);     // see k_slow_resolve
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh) {
+					u32 b = bit_in_cell(tc.pos[j]);
+					if (!((tc.cell[j] >> (16 + b)) & 1ULL)) mine &= (cell_load_coherent(resv_slot(bd, i, tc.pos[j])) == key);
+				}
+			if (mine) {
+				commit_touches<W, NHM>(md, tc, bin, a, al);
+				bd.status[row + x] = SLOT_INSERTED;
+				atomicAdd(bd.stats + ST_SUCCESSES, 1ULL);
+			}
+		}
+		__threadfence();
+		__syncthreads();
+	}
+}
+
+// Drop the claim bits of the contended k-mers once the round is decided (nobody reads claims any more);
+// fast-path claims need no cleaning: their positions are tagged now and claims only matter on untagged ones.
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_clear_claims(ModelDev md, BlockDev bd, int t, int pp)
+{
+	const int i = blockIdx.y, u = blockIdx.x * 256 + threadIdx.x;
+	if (u >= bd.Un[i]) return;
+	const u64 row = (u64)i * KMX_BUCKET;
+	const u32 x = bd.U[0][row + u];
+	const u32 idx = bd.list[pp][row + x];
+	u64 v[W];
+	load_kmer<W>(bd.kmers, row + idx, v);
+	const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+	const int a = (i + t) % md.nb;
+	Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
+	u64 *cells = md.cells[a];
+	for (int j = 0; j < md.nh; j++) {
+		u64 pos = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(a * md.nh + j) & 127]), md.km_mod);
+		atomicAnd(cells + (pos >> 4), ~CELL_CLAIM((bin >> j) & 1u, bit_in_cell(pos)));
+	}
+}
+
+// ------------------------------------------------------------------------------------------ R: reorder
+// reorder_buffer (kmodel.hpp:529-540): m survivors; survivors already below m stay; the i-th hole from
+// the left (below m) receives the i-th survivor from the right (at or above m).
+__global__ __launch_bounds__(256) void k_reorder_count(BlockDev bd)
+{
+	__shared__ int s_tmp[4];
+	const int i = blockIdx.y, tile = blockIdx.x;
+	const int n = bd.n[i];
+	const u64 row = (u64)i * KMX_BUCKET;
+	int c = 0;
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		int x = tile * KMX_TILE + threadIdx.x * 4 + q;
+		c += (x < n && bd.status[row + x] == SLOT_FAILED) ? 1 : 0;
+	}
+	int tot;
+	block_excl_scan_256(c, s_tmp, &tot);
+	if (threadIdx.x == 0) bd.tile_cnt[i * KMX_NTILES + tile] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_reorder_scatter(BlockDev bd, int pp)
+{
+	__shared__ int s_tmp[4];
+	__shared__ int s_m, s_off;
+	const int i = blockIdx.y, tile = blockIdx.x;
+	const int n = bd.n[i];
+	const u64 row = (u64)i * KMX_BUCKET;
+	{   // every workgroup scans the 256 tile counts of its list
+		int c = bd.tile_cnt[i * KMX_NTILES + threadIdx.x];
+		int tot;
+		int ex = block_excl_scan_256(c, s_tmp, &tot);
+		if ((int)threadIdx.x == tile) s_off = ex;
+		if (threadIdx.x == 0) s_m = tot;
+		__syncthreads();
+	}
+	const int m = s_m;
+	int f[4], c = 0;
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		int x = tile * KMX_TILE + threadIdx.x * 4 + q;
+		f[q] = (x < n && bd.status[row + x] == SLOT_FAILED) ? 1 : 0;
+		c += f[q];
+	}
+	int before = block_excl_scan_256(c, s_tmp, nullptr) + s_off;
+	const u32 *oldl = bd.list[pp] + row;
+	u32 *newl = bd.list[pp ^ 1] + row;
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		int x = tile * KMX_TILE + threadIdx.x * 4 + q;
+		if (x == m) bd.h[i] = m - before;                    // survivors at or above m == holes below m
+		if (x < n) {
+			if (x < m) {
+				if (f[q]) newl[x] = oldl[x];
+				else bd.hpos[row + (x - before)] = (u32)x;
+			} else if (f[q]) bd.sval[row + (m - before - 1)] = oldl[x];
+		}
+		before += f[q];
+	}
+	if (tile == 0 && threadIdx.x == 0) bd.m[i] = m;
+}
+
+__global__ __launch_bounds__(256) void k_reorder_fill(BlockDev bd, int pp)
+{
+	const int i = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
+	const u64 row = (u64)i * KMX_BUCKET;
+	if (r < bd.h[i]) bd.list[pp ^ 1][row + bd.hpos[row + r]] = bd.sval[row + r];
+	if (r == 0) bd.n[i] = bd.m[i];
+}
+
+// survivors of the block go to the rest table (kmodel.hpp:567-571); slot 0 is remembered for the
+// stale-slot duplicate of the final block (quirk Q1)
+template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev bd, int pp, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts)
+{
+	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	const int n = bd.n[i];
+	if (x == 0 && n == 0) stale_counts[i] = 0;
+	if (x >= n) return;
+	const u64 row = (u64)i * KMX_BUCKET;
+	const u32 idx = bd.list[pp][row + x];
+	u64 v[W];
+	load_kmer<W>(bd.kmers, row + idx, v);
+	const int c = (int)bd.counts[row + idx];
+	u64 p = atomicAdd(rest_n, 1ULL);
+	store_kmer<W>(rest_kmers, p, v);
+	rest_counts[p] = c;
+	if (x == 0) { store_kmer<W>(stale_kmers, (u64)i, v); stale_counts[i] = c; }
+}
+
+// ------------------------------------------------------------------------------------------ query
+template <int W> struct QKmer { u64 v[W]; };
+
+template <int W> __device__ __forceinline__ u64 shr128_lo(const u64 *v, int s)   // low 64 bits of (value >> s)
+{
+	if (W == 1) return s >= 64 ? 0 : v[0] >> s;
+	if (s >= 64) return s >= 128 ? 0 : v[0] >> (s - 64);
+	return s ? (v[0] << (64 - s)) | (v[1] >> s) : v[1];
+}
+
+// KRestData::check_kmer (rest.hpp:223-251) incl. its inclusive upper bound; rows are suffix integers
+template <int W> __device__ __forceinline__ int rest_check(const ModelDev &md, const u64 *v)
+{
+	if (!md.rest_entries) return 0;
+	const int sbits = 2 * (md.k - md.rest_pre_len);
+	const u32 pre = (u32)shr128_lo<W>(v, sbits);
+	const int g = md.rest_h2i[pre];
+	if (g < 0) return 0;
+	u64 key[W];
+	if (W == 1) key[0] = v[0] & ((1ULL << sbits) - 1);
+	else {
+		if (sbits >= 64) { key[0] = sbits >= 128 ? v[0] : v[0] & ((1ULL << (sbits - 64)) - 1); key[W - 1] = v[W - 1]; }
+		else { key[0] = 0; key[W - 1] = v[W - 1] & ((1ULL << sbits) - 1); }
+	}
+	int low = md.rest_pre[g], high = md.rest_pre[g + 1], mid = 0;
+	bool found = false;
+	while (low <= high) {
+		mid = (low + high) / 2;
+		if ((u64)mid >= md.rest_entries) break;             // divergence D3: the row past the table never matches
+		int c = 0;
+#pragma unroll
+		for (int w = 0; w < W; w++) {
+			u64 r = md.rest_suf[(u64)mid * W + w];
+			if (c == 0) c = key[w] < r ? -1 : (key[w] > r ? 1 : 0);
+		}
+		if (c < 0) high = mid - 1;
+		else if (c > 0) low = mid + 1;
+		else { found = true; break; }
+	}
+	return found ? md.rest_cnt[mid] : 0;
+}
+
+// check_all_bf (kmodel.hpp:361-371): filter order {0} for ci==1, {1,0,2} otherwise
+template <int W> __device__ __forceinline__ int check_all_bf(const ModelDev &md, const Premixed<W> &pf, const Premixed<W> &pb)
+{
+	for (int j = 0; j < md.bf_num; j++) {
+		int i = md.ci == 1 ? j : (j == 0 ? 1 : (j == 1 ? 0 : 2));
+		bool a = bloom_check_pm<W>(pf, md.gfull, md.bf[i], md.bf_mod[i], md.nh - 1);
+		bool b = a && bloom_check_pm<W>(pb, md.gback, md.bf_back[i], md.bf_back_mod[i], md.nh - 2);
+		if (a && b) return i + md.ci;
+	}
+	return 0;
+}
+
+// one coupled array: -1 if a tag is missing, else the value bits, hash j -> bit j (kmodel.hpp:630-642)
+template <int W> __device__ __forceinline__ int decode_array(const ModelDev &md, const Premixed<W> &pf, int a)
+{
+	if (!md.km_mod.d) return -1;
+	const u64 *cells = md.cells[a];
+	int v = 0;
+	bool ok = true;
+	for (int j = 0; j < md.nh && ok; j++) {
+		u64 pos = mod_u64(murmur_seeded<W>(pf, md.gfull, c_seeds[(a * md.nh + j) & 127]), md.km_mod);
+		u64 cell = cells[pos >> 4];
+		u32 b = bit_in_cell(pos);
+		ok = (cell >> (16 + b)) & 1ULL;
+		v |= (int)((cell >> b) & 1ULL) << j;
+	}
+	return ok ? v : -1;
+}
+
+// get_candidates (kmodel.hpp:326-342); returns -2 when the neighbour contributes nothing
+template <int W> __device__ __forceinline__ int neighbour_candidate(const ModelDev &md, u64 *nv)
+{
+	min_kmer<W>(nv, md.k);
+	int r = rest_check<W>(md, nv);
+	if (r > 0) return (int)md.bin_of_occ[r];
+	Aligned<W> al = left_align<W>(nv, md.k);
+	Premixed<W> pf = premix_string<W>(al, md.gfull);
+	Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
+	int occ = check_all_bf<W>(md, pf, pb);
+	if (occ != 0) return occ;
+	if (bloom_check_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2)) {
+		int result = -1;                                     // find_bitarray_one (kmodel.hpp:650-671, quirk Q3)
+		for (int a = 0; a < md.nb; a++) {
+			int d = decode_array<W>(md, pf, a);
+			if (d >= 0) { result = d; if (d != 0) break; }
+		}
+		if (result > -1) return result;
+	}
+	return -2;
+}
+
+// get_neighbor_kmer_bin (kmodel.hpp:344-359): 4 successors then 4 predecessors, bases in ACGT order
+template <int W> __device__ __forceinline__ int neighbour_bins(const ModelDev &md, const u64 *v, int *cand)
+{
+	int nc = 0;
+	const int k = md.k;
+	for (int x = 0; x < 8; x++) {
+		u64 nv[W];
+		if (x < 4) {              // drop the first base, append X
+			if (W == 1) nv[0] = ((v[0] << 2) | (u64)x) & (k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1));
+			else {
+				nv[0] = ((v[0] << 2) | (v[W - 1] >> 62)) & (k == 64 ? ~0ULL : ((1ULL << (2 * k - 64)) - 1));
+				nv[W - 1] = (v[W - 1] << 2) | (u64)x;
+			}
+		} else {                  // prepend X, drop the last base
+			u64 X = (u64)(x - 4);
+			if (W == 1) nv[0] = (v[0] >> 2) | (X << (2 * (k - 1)));
+			else {
+				nv[W - 1] = (v[W - 1] >> 2) | (v[0] << 62);
+				nv[0] = (v[0] >> 2) | (X << (2 * (k - 1) - 64));
+			}
+		}
+		int c = neighbour_candidate<W>(md, nv);
+		if (c != -2) cand[nc++] = c;
+	}
+	return nc;
+}
+
+// KModel::kmer_to_occ (kmodel.hpp:100-116) + kmer_to_bin (:286-323)
+template <int W> __global__ __launch_bounds__(256) void k_query(ModelDev md, const u64 *kmers, u64 n, int *out)
+{
+	const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (q >= n) return;
+	u64 v[W];
+	load_kmer<W>(kmers, q, v);
+	min_kmer<W>(v, md.k);
+	int occ = rest_check<W>(md, v);
+	if (occ != 0) { out[q] = occ; return; }
+	Aligned<W> al = left_align<W>(v, md.k);
+	Premixed<W> pf = premix_string<W>(al, md.gfull);
+	Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
+	const bool in_back = bloom_check_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+	occ = check_all_bf<W>(md, pf, pb);
+	if (!in_back) { out[q] = occ; return; }                  // :109-111
+	int nv = 0, first = 0;
+	for (int a = 0; a < md.nb; a++) {                        // find_bitarray (:625-646)
+		int d = decode_array<W>(md, pf, a);
+		if (d > 0) { if (nv == 0) first = d; nv++; }
+	}
+	int bin;
+	if (nv == 0) bin = occ;
+	else if (nv == 1) {
+		bin = first;
+		if (occ) {
+			int cand[8];
+			int nc = neighbour_bins<W>(md, v, cand), cnt = 0;
+			for (int c = 0; c < 8; c++) cnt += (c < nc && cand[c] < md.ci + md.bf_num) ? 1 : 0;
+			if (cnt >= nc / 2) bin = occ;
+		}
+	} else {
+		int cand[8];
+		int nc = neighbour_bins<W>(md, v, cand);
+		if (nc <= 0) bin = 0;
+		else {
+			int min_dist = 2 << 20;
+			bin = first;
+			for (int a = 0; a < md.nb; a++) {
+				int d = decode_array<W>(md, pf, a);
+				if (d <= 0) continue;
+				int cur = 2 << 20;
+				for (int c = 0; c < 8; c++)
+					if (c < nc) { int dd = d > cand[c] ? d - cand[c] : cand[c] - d; cur = dd < cur ? dd : cur; }
+				if (min_dist > cur) { min_dist = cur; bin = d; }
+			}
+		}
+	}
+	out[q] = (int)md.mean_of_bin[bin];
+}
+
+// ------------------------------------------------------------------------------------------ layout conversion
+// on-disk value/tag bytes <-> cells (kmodel.hpp:199-201, :227-229).  One thread per cell (2 bytes of each).
+__global__ __launch_bounds__(256) void k_cells_from_disk(const unsigned char *val, const unsigned char *tag, u64 nbytes, u64 *cells, u64 ncells)
+{
+	u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (c >= ncells) return;
+	u64 b0 = 2 * c, b1 = 2 * c + 1;
+	u64 v = (u64)val[b0] | (b1 < nbytes ? (u64)val[b1] << 8 : 0);
+	u64 t = (u64)tag[b0] | (b1 < nbytes ? (u64)tag[b1] << 8 : 0);
+	cells[c] = v | (t << 16);
+}
+// which: 0 value, 1 tag, 2 claims on untagged positions (must be zero between rounds)
+__global__ __launch_bounds__(256) void k_cells_to_disk(const u64 *cells, u64 ncells, u64 nbytes, int which, unsigned char *out)
+{
+	u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (c >= ncells) return;
+	u64 cell = cells[c];
+	u32 x = which == 0 ? (u32)(cell & 0xFFFF) : which == 1 ? (u32)((cell >> 16) & 0xFFFF)
+	                   : (u32)(((cell >> 32) | (cell >> 48)) & 0xFFFF & ~(cell >> 16));
+	out[2 * c] = (unsigned char)(x & 0xFF);
+	if (2 * c + 1 < nbytes) out[2 * c + 1] = (unsigned char)(x >> 8);
+}
+
+// ------------------------------------------------------------------------------------------ KAT surface
+template <int W> __global__ void k_debug_hash(int k, const u64 *kmers, u64 n, const u32 *seeds, int n_seeds, int whole, u64 *out)
+{
+	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	u64 v[W];
+	load_kmer<W>(kmers, i, v);
+	Aligned<W> al = left_align<W>(v, k);
+	StrGeom g;
+	int len = whole ? k : k - 2;
+	g.nblk = len / 8; g.rem = len & 7; g.lenm = (u64)len * MURMUR_M;
+	Premixed<W> pm = premix_string<W>(whole ? al : drop_first_base<W>(al), g);
+	for (int s = 0; s < n_seeds; s++) out[i * n_seeds + s] = murmur_seeded<W>(pm, g, seeds[s]);
+}
+template <int W> __global__ void k_debug_min_kmer(int k, const u64 *kmers, u64 n, u64 *out)
+{
+	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	u64 v[W];
+	load_kmer<W>(kmers, i, v);
+	min_kmer<W>(v, k);
+	store_kmer<W>(out, i, v);
+}
+
+// ------------------------------------------------------------------------------------------ microbenchmarks
+// The random-access ceiling the roofline fraction is quoted against: each lane issues 8
+// independent 8-byte touches at splitmix64 addresses, like one k-mer's touches on one array.
+__device__ __forceinline__ u64 splitmix(u64 z)
+{
+	z += 0x9E3779B97F4A7C15ULL;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void k_micro_gather(const u64 *buf, u64 ncell, u64 n_lanes, u64 salt, u64 *sink)
+{
+	u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_lanes) return;
+	u64 acc = 0;
+#pragma unroll
+	for (int j = 0; j < 8; j++) acc ^= buf[splitmix(i * 8 + j + salt) % ncell];
+	if (acc == 0x123456789ULL) *sink = acc;
+}
+__global__ __launch_bounds__(256) void k_micro_atomic_or(u64 *buf, u64 ncell, u64 n_lanes, u64 salt)
+{
+	u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_lanes) return;
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		u64 r = splitmix(i * 8 + j + salt);
+		atomicOr(buf + r % ncell, 1ULL << (r >> 58));
+	}
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+namespace kmxk {
+
+#define DISPATCH_W(W_, ...)                     \
+	do {                                        \
+		if ((W_) == 1) { constexpr int W = 1; __VA_ARGS__; } \
+		else { constexpr int W = 2; __VA_ARGS__; }           \
+	} while (0)
+#define DISPATCH_W_NH(W_, nh_, ...)             \
+	do {                                        \
+		if ((W_) == 1) { constexpr int W = 1; if ((nh_) <= 8) { constexpr int NHM = 8; __VA_ARGS__; } else { constexpr int NHM = 16; __VA_ARGS__; } } \
+		else { constexpr int W = 2; if ((nh_) <= 8) { constexpr int NHM = 8; __VA_ARGS__; } else { constexpr int NHM = 16; __VA_ARGS__; } } \
+	} while (0)
+
+static inline int words(const ModelDev &md) { return (md.k + 31) / 32; }
+
+void histogram(const u32 *counts, u64 n, int ci, int cs, int bf_num, u64 *n_bf, u64 *stats, hipStream_t st)
+{
+	if (!n) return;
+	u64 blocks = (n + 255) / 256;
+	if (blocks > 4096) blocks = 4096;
+	hipLaunchKernelGGL(k_histogram, dim3((unsigned)blocks), dim3(256), 0, st, counts, n, ci, cs, bf_num, n_bf, stats);
+}
+
+// returns the number of classification tiles
+int classify_tiles(u64 n) { return (int)((n + CLS_TILE - 1) / CLS_TILE); }
+
+void classify_count(const ModelDev &md, const u64 *kmers, const u32 *counts, u64 n, int *tile_cnt, int *tile_off, int *total, u64 *stats, hipStream_t st)
+{
+	int tiles = classify_tiles(n);
+	DISPATCH_W(words(md), hipLaunchKernelGGL(k_classify_count<W>, dim3(tiles), dim3(256), 0, st, md, kmers, counts, n, tile_cnt, stats));
+	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, (const int *)tile_cnt, tile_off, tiles, total);
+}
+
+void classify_scatter(const ModelDev &md, const u64 *kmers, const u32 *counts, u64 n, const int *tile_off, u64 *stg_kmers, u32 *stg_counts, u64 stg_base, hipStream_t st)
+{
+	int tiles = classify_tiles(n);
+	DISPATCH_W(words(md), hipLaunchKernelGGL(k_classify_scatter<W>, dim3(tiles), dim3(256), 0, st, md, kmers, counts, n, tile_off, stg_kmers, stg_counts, stg_base));
+}
+
+void block_init(const BlockDev &bd, int nb, int pp, int n_in_block, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_block_init, dim3(KMX_BUCKET / 256, nb), dim3(256), 0, st, bd, nb, pp, n_in_block);
+}
+
+// one round t of one block: A, B, slow sub-rounds, finisher, claim cleanup, reorder.  `epoch` advances.
+void round(const ModelDev &md, const BlockDev &bd, int t, int pp, u64 *epoch, hipStream_t st)
+{
+	const int nb = md.nb;
+	const dim3 grid(KMX_BUCKET / 256, nb), blk(256);
+	hipLaunchKernelGGL(k_round_reset, dim3(1), dim3(64), 0, st, bd, nb);
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_claim<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_verify_commit<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
+	for (int s = 0; s + 1 < KMX_NSLOW; s++) {
+		u64 e = (*epoch)++;
+		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_reserve<W, NHM>), grid, blk, 0, st, md, bd, t, pp, s, e));
+		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_resolve<W, NHM>), grid, blk, 0, st, md, bd, t, pp, s, e));
+	}
+	u64 e0 = *epoch;
+	*epoch += (1ULL << 19);                                    // the finisher may use up to |U| <= 2^18 epochs
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb), dim3(1024), 0, st, md, bd, t, pp, KMX_NSLOW - 1, e0));
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_clear_claims<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
+	hipLaunchKernelGGL(k_reorder_count, dim3(KMX_NTILES, nb), dim3(256), 0, st, bd);
+	hipLaunchKernelGGL(k_reorder_scatter, dim3(KMX_NTILES, nb), dim3(256), 0, st, bd, pp);
+	hipLaunchKernelGGL(k_reorder_fill, dim3(KMX_BUCKET / 2 / 256, nb), dim3(256), 0, st, bd, pp);
+}
+
+void rest_append(const ModelDev &md, const BlockDev &bd, int pp, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, hipStream_t st)
+{
+	DISPATCH_W(words(md), hipLaunchKernelGGL(k_rest_append<W>, dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, bd, pp, rest_kmers, rest_counts, rest_n, stale_kmers, stale_counts));
+}
+
+void query(const ModelDev &md, const u64 *kmers, u64 n, int *out, hipStream_t st)
+{
+	if (!n) return;
+	DISPATCH_W(words(md), hipLaunchKernelGGL(k_query<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, md, kmers, n, out));
+}
+
+void cells_from_disk(const unsigned char *val, const unsigned char *tag, u64 nbytes, u64 *cells, u64 ncells, hipStream_t st)
+{
+	if (!ncells) return;
+	hipLaunchKernelGGL(k_cells_from_disk, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st, val, tag, nbytes, cells, ncells);
+}
+void cells_to_disk(const u64 *cells, u64 ncells, u64 nbytes, int which, unsigned char *out, hipStream_t st)
+{
+	if (!ncells) return;
+	hipLaunchKernelGGL(k_cells_to_disk, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st, cells, ncells, nbytes, which, out);
+}
+
+void debug_hash(int k, const u64 *kmers, u64 n, const u32 *seeds, int n_seeds, int whole, u64 *out, hipStream_t st)
+{
+	DISPATCH_W((k + 31) / 32, hipLaunchKernelGGL(k_debug_hash<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, k, kmers, n, seeds, n_seeds, whole, out));
+}
+void debug_min_kmer(int k, const u64 *kmers, u64 n, u64 *out, hipStream_t st)
+{
+	DISPATCH_W((k + 31) / 32, hipLaunchKernelGGL(k_debug_min_kmer<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, k, kmers, n, out));
+}
+
+void micro(int mode, u64 *buf, u64 ncell, u64 n_lanes, u64 salt, u64 *sink, hipStream_t st)
+{
+	dim3 grid((unsigned)((n_lanes + 255) / 256));
+	if (mode == 0) hipLaunchKernelGGL(k_micro_gather, grid, dim3(256), 0, st, (const u64 *)buf, ncell, n_lanes, salt, sink);
+	else hipLaunchKernelGGL(k_micro_atomic_or, grid, dim3(256), 0, st, buf, ncell, n_lanes, salt);
+}
+
+}   // namespace kmxk

@@ -1,0 +1,46 @@
+// kmc_reader.h -- from-scratch listing reader for KMC databases (host C++).
+//
+// Replaces, for the KModel build path only, what the reference gets from its vendored KMC 3.1.0 API:
+//   CKMCFile::OpenForListing / ReadNextKmer / RestartListing / KmerCount / KmerLength
+//   (kmc_file.cpp:66-99, :428-515, :647-664, :763, :740) and CKmerAPI::to_string (kmer_api.h:433).
+// Written from the on-disk format; it decodes records straight into packed
+// 2-bit k-mers (W = ceil(k/32) u64 words, word 0 most significant) instead of strings, whole batches at
+// a time, so that the host feed is a memcpy-speed loop rather than the reference's per-k-mer string build.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace kmx {
+
+class KmcListing {
+public:
+	~KmcListing() { close(); }
+	// false + error() on failure.  Supports KMC1 (version 0) and KMC2 (0x200) prefix files, mode 0 counters.
+	bool open(const std::string &prefix);
+	void close();
+	void restart();                                  // RestartListing
+	uint32_t kmer_length() const { return k_; }
+	uint64_t kmer_count() const { return total_; }   // KmerCount() with untouched min/max
+	uint32_t min_count() const { return min_count_; }
+	uint64_t max_count() const { return max_count_; }
+	int words() const { return (int)((k_ + 31) / 32); }
+	// Next batch in listing order; counts outside [min_count, max_count] are skipped exactly like
+	// ReadNextKmer does (kmc_file.cpp:513).  Returns the number of k-mers produced (0 at the end).
+	size_t next_batch(uint64_t *kmers, uint32_t *counts, size_t max_n);
+	const std::string &error() const { return err_; }
+
+private:
+	bool fill();
+	FILE *suf_ = nullptr;
+	std::vector<uint64_t> lut_;      // concatenated LUT(s); lut_[size] sentinel = total
+	std::vector<unsigned char> buf_;
+	size_t buf_pos_ = 0, buf_len_ = 0;
+	uint64_t lut_idx_ = 0, rec_ = 0, total_ = 0, max_count_ = 0, prefix_mask_ = 0;
+	uint32_t k_ = 0, mode_ = 0, counter_size_ = 0, p_ = 0, min_count_ = 0, version_ = 0;
+	uint32_t suf_bytes_ = 0, rec_bytes_ = 0;
+	std::string err_;
+};
+
+}   // namespace kmx

@@ -1,0 +1,957 @@
+// kmx_api.hip -- host orchestration + the C ABI of include/kmx.h.
+//
+// Mirrors KModel's life cycle (kmodel.hpp:45-235, :674-696) with the bit arrays resident in HBM.
+// There is no CPU compute path in this file: every insert/query runs in the gfx950 kernels of
+// kernels.hip; the host only sizes, streams, sorts the (small) rest table and does file I/O.
+#include "../../include/kmx.h"
+#include "kmc_reader.h"
+#include "kmx_types.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace kmxk {
+void histogram(const u32 *, u64, int, int, int, u64 *, u64 *, hipStream_t);
+int classify_tiles(u64 n);
+void classify_count(const ModelDev &, const u64 *, const u32 *, u64, int *, int *, int *, u64 *, hipStream_t);
+void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int *, u64 *, u32 *, u64, hipStream_t);
+void block_init(const BlockDev &, int, int, int, hipStream_t);
+void round(const ModelDev &, const BlockDev &, int, int, u64 *, hipStream_t);
+void rest_append(const ModelDev &, const BlockDev &, int, u64 *, int *, unsigned long long *, u64 *, int *, hipStream_t);
+void query(const ModelDev &, const u64 *, u64, int *, hipStream_t);
+void cells_from_disk(const unsigned char *, const unsigned char *, u64, u64 *, u64, hipStream_t);
+void cells_to_disk(const u64 *, u64, u64, int, unsigned char *, hipStream_t);
+void debug_hash(int, const u64 *, u64, const u32 *, int, int, u64 *, hipStream_t);
+void debug_min_kmer(int, const u64 *, u64, u64 *, hipStream_t);
+void micro(int, u64 *, u64, u64, u64, u64 *, hipStream_t);
+}   // namespace kmxk
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return code;
+}
+#define HIPCHK(call)                                                                             \
+	do {                                                                                         \
+		hipError_t e_ = (call);                                                                  \
+		if (e_ != hipSuccess) return fail(KMX_E_NODEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
+	} while (0)
+
+extern "C" const char *kmx_last_error(void) { return g_err; }
+
+extern "C" int kmx_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+// ------------------------------------------------------------------------------------------ OccuBin
+// occu_bin.hpp:27-83: three zones -- identity below e1 = 2^nh/4, 2^nh/2 bins 3 wide, 2^nh/4 bins `cap` wide.
+static int occubin_tables(int cs, int nh, std::vector<u32> &bin_of_occ, std::vector<u32> &mean_of_bin)
+{
+	const int mc = cs + 1, e3 = 1 << nh, e1 = e3 / 4, e2 = e1 + e3 / 2;
+	bin_of_occ.assign(mc, 0xFFFFFFFFu);
+	std::vector<u32> mean_of_occ(mc, 0xFFFFFFFFu);
+	int start = e1;
+	for (int i = 0; i < e3 / 2; i++, start += 3)
+		for (int j = 0; j < 3; j++) {
+			if (start + j >= mc) return -1;                    // cs too small for nh (reference overruns, Q11)
+			mean_of_occ[start + j] = start + 1;
+			bin_of_occ[start + j] = e1 + i;
+		}
+	const int nz3 = e3 / 4, cap = (mc - start) / nz3;
+	for (int i = 0; i < nz3; i++, start += cap)
+		for (int j = 0; j < cap; j++) {
+			mean_of_occ[start + j] = (2 * start + cap) / 2;
+			bin_of_occ[start + j] = e2 + i;
+		}
+	for (int i = start; i < mc; i++) {
+		mean_of_occ[i] = (2 * start - cap) / 2;
+		bin_of_occ[i] = e3 - 1;
+	}
+	for (int i = 0; i < e1 && i < mc; i++) bin_of_occ[i] = i;
+	mean_of_bin.assign(e3, 0);                                 // unordered_map::operator[] on a missing bin yields 0
+	for (int b = 0; b < e1; b++) mean_of_bin[b] = b;
+	std::vector<char> seen(e3, 0);
+	for (int i = e1; i < mc; i++) {                            // map::insert keeps the first mean per bin
+		u32 b = bin_of_occ[i];
+		if (b < (u32)e3 && !seen[b]) { seen[b] = 1; if ((int)b >= e1) mean_of_bin[b] = mean_of_occ[i]; }
+	}
+	return 0;
+}
+
+extern "C" int kmx_occubin(int cs, int nh, uint32_t *bin_of_occ, uint32_t *mean_of_bin)
+{
+	if (nh < 3 || nh > KMX_MAX_NH || cs < 1) return fail(KMX_E_ARG, "bad cs/nh");
+	std::vector<u32> b, m;
+	if (occubin_tables(cs, nh, b, m)) return fail(KMX_E_ARG, "cs=%d too small for nh=%d", cs, nh);
+	memcpy(bin_of_occ, b.data(), b.size() * 4);
+	memcpy(mean_of_bin, m.data(), m.size() * 4);
+	return KMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ rest table (host side)
+// rest.hpp:46-65 arrays in their on-disk form (Appendix B.2) + the device form used by k_query.
+struct RestTable {
+	int k = 0, pre_len = 0, map_size = 0, pre_buffer_size = 0, suff_group = 0;
+	u64 suff_bin_size = 0, entries = 0;
+	std::vector<int> hash2index, pre_buffer, count_bin;
+	std::vector<unsigned char> suffix_bin;
+	// device
+	int *d_h2i = nullptr, *d_pre = nullptr, *d_cnt = nullptr;
+	u64 *d_suf = nullptr;
+};
+static int rest_prefix_len(int k) { for (int i = 7; i >= 3; i--) if ((k - i) % 4 == 0) return i; return 3; }   // rest.hpp:78-83
+
+struct RestEnt { u64 w[2]; int c; };
+
+// ------------------------------------------------------------------------------------------ the model
+enum { ST_EMPTY = 0, ST_BUILDING = 1, ST_READY = 2 };
+
+struct kmx_model {
+	int ci = 1, cs = 1023, nh = 7, nb = 5, k = 0, bf_num = 1, W = 1;
+	int device = 0, state = ST_EMPTY;
+	hipStream_t stream = nullptr;
+	std::vector<u32> h_bin_of_occ, h_mean_of_bin;
+	u32 *d_bin_of_occ = nullptr, *d_mean_of_bin = nullptr;
+	u64 n_total = 0, n_km = 0, n_bf[3] = {0, 0, 0};
+	u64 byte_bf[3] = {0, 0, 0}, byte_bf_back[3] = {0, 0, 0}, km_byte_size = 0, byte_km_back = 0, ncells = 0;
+	u32 *d_bf[3] = {nullptr, nullptr, nullptr}, *d_bf_back[3] = {nullptr, nullptr, nullptr}, *d_km_back = nullptr;
+	u64 *d_cells[KMX_MAX_NB] = {nullptr};
+	RestTable rest;
+	ModelDev md;
+	// ---- build-time state
+	u64 *d_stg_kmers = nullptr;
+	u32 *d_stg_counts = nullptr;
+	u64 stg_n = 0, stg_cap = 0;
+	BlockDev bd;
+	void *d_block_scratch = nullptr;
+	u64 *d_rest_kmers = nullptr;
+	int *d_rest_counts = nullptr;
+	unsigned long long *d_rest_n = nullptr;
+	u64 rest_cap = 0, rest_upper = 0;
+	u64 *d_stale_kmers = nullptr;
+	int *d_stale_counts = nullptr;
+	u64 *d_stats = nullptr, *d_nbf = nullptr;
+	int *d_tile_cnt = nullptr, *d_tile_off = nullptr, *d_total = nullptr;
+	int *h_total = nullptr;                                    // pinned
+	u64 epoch = 1, blocks = 0, rounds = 0;
+	u64 h_stats[ST_N] = {0};
+	double t_insert_kernels = 0, t_total = 0;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static const u64 kChunk = u64(1) << 23;                       // k-mers classified per pass of the front end
+
+template <typename T> static int dalloc(T **p, u64 n_elems, bool zero, hipStream_t st)
+{
+	*p = nullptr;
+	u64 bytes = n_elems * sizeof(T);
+	if (!bytes) bytes = 16;
+	HIPCHK(hipMalloc((void **)p, bytes));
+	if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes, st));
+	return KMX_OK;
+}
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+static void free_build_state(kmx_model *m)
+{
+	hipFree(m->d_stg_kmers); m->d_stg_kmers = nullptr;
+	hipFree(m->d_stg_counts); m->d_stg_counts = nullptr;
+	hipFree(m->d_block_scratch); m->d_block_scratch = nullptr;
+	hipFree(m->d_rest_kmers); m->d_rest_kmers = nullptr;
+	hipFree(m->d_rest_counts); m->d_rest_counts = nullptr;
+	hipFree(m->d_rest_n); m->d_rest_n = nullptr;
+	hipFree(m->d_stale_kmers); m->d_stale_kmers = nullptr;
+	hipFree(m->d_stale_counts); m->d_stale_counts = nullptr;
+	hipFree(m->d_tile_cnt); m->d_tile_cnt = nullptr;
+	hipFree(m->d_tile_off); m->d_tile_off = nullptr;
+	hipFree(m->d_total); m->d_total = nullptr;
+	m->stg_n = m->stg_cap = 0;
+}
+
+static void free_rest_dev(RestTable &r)
+{
+	hipFree(r.d_h2i); hipFree(r.d_pre); hipFree(r.d_cnt); hipFree(r.d_suf);
+	r.d_h2i = r.d_pre = r.d_cnt = nullptr;
+	r.d_suf = nullptr;
+}
+
+static void free_arrays(kmx_model *m)
+{
+	for (int i = 0; i < 3; i++) {
+		hipFree(m->d_bf[i]); hipFree(m->d_bf_back[i]);
+		m->d_bf[i] = m->d_bf_back[i] = nullptr;
+	}
+	hipFree(m->d_km_back); m->d_km_back = nullptr;
+	for (int a = 0; a < KMX_MAX_NB; a++) { hipFree(m->d_cells[a]); m->d_cells[a] = nullptr; }
+	free_rest_dev(m->rest);
+}
+
+extern "C" int kmx_create(int ci, int cs, int nh, int nb, kmx_model **out)
+{
+	if (!out) return fail(KMX_E_ARG, "null out");
+	*out = nullptr;
+	if (nh < 3 || nh > KMX_MAX_NH || nb < 1 || nb > KMX_MAX_NB || ci < 1 || cs < ci)
+		return fail(KMX_E_ARG, "bad parameters ci=%d cs=%d nh=%d nb=%d", ci, cs, nh, nb);
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+		return fail(KMX_E_NODEVICE, "no HIP device: libkmx has no CPU fallback");
+	kmx_model *m = new kmx_model();
+	m->ci = ci; m->cs = cs; m->nh = nh; m->nb = nb;
+	m->bf_num = ci == 1 ? 1 : 3;                               // kmodel.hpp:50
+	if (occubin_tables(cs, nh, m->h_bin_of_occ, m->h_mean_of_bin)) { delete m; return fail(KMX_E_ARG, "cs=%d too small for nh=%d", cs, nh); }
+	HIPCHK(hipGetDevice(&m->device));
+	HIPCHK(hipMalloc((void **)&m->d_bin_of_occ, m->h_bin_of_occ.size() * 4));
+	HIPCHK(hipMalloc((void **)&m->d_mean_of_bin, m->h_mean_of_bin.size() * 4));
+	HIPCHK(hipMemcpy(m->d_bin_of_occ, m->h_bin_of_occ.data(), m->h_bin_of_occ.size() * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(m->d_mean_of_bin, m->h_mean_of_bin.data(), m->h_mean_of_bin.size() * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMalloc((void **)&m->d_stats, ST_N * 8));
+	HIPCHK(hipMalloc((void **)&m->d_nbf, 3 * 8));
+	HIPCHK(hipMemset(m->d_stats, 0, ST_N * 8));
+	HIPCHK(hipHostMalloc((void **)&m->h_total, 64));
+	HIPCHK(hipEventCreate(&m->ev0));
+	HIPCHK(hipEventCreate(&m->ev1));
+	*out = m;
+	return KMX_OK;
+}
+
+extern "C" int kmx_destroy(kmx_model *m)
+{
+	if (!m) return KMX_OK;
+	hipSetDevice(m->device);
+	hipStreamSynchronize(m->stream);
+	free_build_state(m);
+	free_arrays(m);
+	hipFree(m->d_bin_of_occ); hipFree(m->d_mean_of_bin); hipFree(m->d_stats); hipFree(m->d_nbf);
+	if (m->h_total) hipHostFree(m->h_total);
+	if (m->ev0) hipEventDestroy(m->ev0);
+	if (m->ev1) hipEventDestroy(m->ev1);
+	delete m;
+	return KMX_OK;
+}
+
+extern "C" int kmx_set_stream(kmx_model *m, void *s)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	m->stream = (hipStream_t)s;
+	return KMX_OK;
+}
+
+// sizes (kmodel.hpp:402-420, :436-456) and the by-value kernel argument block
+static void compute_sizes(kmx_model *m)
+{
+	u64 nbf = 0;
+	for (int i = 0; i < m->bf_num; i++) {
+		m->byte_bf[i] = (u64)((double)m->n_bf[i] / 5.5 * (double)(m->nh - 1));          // f64 then truncation (Q5)
+		m->byte_bf_back[i] = (m->n_bf[i] >> 3) * (u64)(m->nh - 2);
+		nbf += m->n_bf[i];
+	}
+	m->n_km = m->n_total - nbf;                                                        // kmodel.hpp:433
+	m->km_byte_size = (m->n_km >> 4) * (u64)m->nh;
+	m->byte_km_back = (m->n_km >> 4) * (u64)(m->nh - 2);
+	m->ncells = (m->km_byte_size + 1) / 2;
+}
+
+static void fill_model_dev(kmx_model *m)
+{
+	ModelDev &md = m->md;
+	memset(&md, 0, sizeof md);
+	md.k = m->k; md.nh = m->nh; md.nb = m->nb; md.ci = m->ci; md.cs = m->cs; md.bf_num = m->bf_num;
+	md.gfull = make_geom(m->k);
+	md.gback = make_geom(m->k - 2);
+	for (int i = 0; i < 3; i++) {
+		md.bf[i] = m->d_bf[i]; md.bf_mod[i] = make_mod(i < m->bf_num ? m->byte_bf[i] * 8 : 0);
+		md.bf_back[i] = m->d_bf_back[i]; md.bf_back_mod[i] = make_mod(i < m->bf_num ? m->byte_bf_back[i] * 8 : 0);
+	}
+	md.km_back = m->d_km_back; md.km_back_mod = make_mod(m->byte_km_back * 8);
+	for (int a = 0; a < m->nb; a++) md.cells[a] = m->d_cells[a];
+	md.km_mod = make_mod(m->km_byte_size * 8);
+	md.bin_of_occ = m->d_bin_of_occ; md.mean_of_bin = m->d_mean_of_bin;
+	md.rest_pre_len = m->rest.pre_len; md.rest_W = m->W; md.rest_entries = m->rest.entries;
+	md.rest_h2i = m->rest.d_h2i; md.rest_pre = m->rest.d_pre; md.rest_suf = m->rest.d_suf; md.rest_cnt = m->rest.d_cnt;
+}
+
+static int alloc_arrays(kmx_model *m)
+{
+	free_arrays(m);
+	for (int i = 0; i < m->bf_num; i++) {
+		TRY(dalloc(&m->d_bf[i], (m->byte_bf[i] + 3) / 4 + 1, true, m->stream));
+		TRY(dalloc(&m->d_bf_back[i], (m->byte_bf_back[i] + 3) / 4 + 1, true, m->stream));
+	}
+	TRY(dalloc(&m->d_km_back, (m->byte_km_back + 3) / 4 + 1, true, m->stream));
+	for (int a = 0; a < m->nb; a++) TRY(dalloc(&m->d_cells[a], m->ncells + 1, true, m->stream));
+	return KMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ streamed build
+extern "C" int kmx_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	if (k < 3 || k > 64) return fail(KMX_E_ARG, "k=%d out of range [3,64]", k);
+	HIPCHK(hipSetDevice(m->device));
+	u64 s = 0;
+	for (int i = 0; i < m->bf_num; i++) s += n_bf[i];
+	if (s > n_total) return fail(KMX_E_ARG, "n_bf exceeds n_total");
+	free_build_state(m);
+	m->k = k; m->W = (k + 31) / 32;
+	m->n_total = n_total;
+	for (int i = 0; i < 3; i++) m->n_bf[i] = i < m->bf_num ? n_bf[i] : 0;
+	compute_sizes(m);
+	TRY(alloc_arrays(m));
+	m->rest = RestTable();
+	fill_model_dev(m);
+	const int nb = m->nb;
+	const u64 B = KMX_BUCKET, blk = (u64)nb * B;
+	// staging stream for coupled-array k-mers: one front-end chunk plus one block of carry-over
+	m->stg_cap = kChunk + blk;
+	TRY(dalloc(&m->d_stg_kmers, m->stg_cap * m->W, false, m->stream));
+	TRY(dalloc(&m->d_stg_counts, m->stg_cap, false, m->stream));
+	m->stg_n = 0;
+	// one slab for the block working set
+	u64 off = 0;
+	auto carve = [&](u64 bytes) { u64 o = off; off += (bytes + 255) & ~u64(255); return o; };
+	u64 o_list0 = carve(blk * 4), o_list1 = carve(blk * 4), o_n = carve(nb * 4), o_status = carve(blk);
+	u64 o_U[KMX_NSLOW];
+	for (int s2 = 0; s2 < KMX_NSLOW; s2++) o_U[s2] = carve(blk * 4);
+	u64 o_Un = carve(KMX_NSLOW * nb * 4), o_R = carve((u64)nb * KMX_RSIZE * 8), o_tc = carve((u64)nb * KMX_NTILES * 4);
+	u64 o_m = carve(nb * 4), o_h = carve(nb * 4), o_hpos = carve(blk * 4), o_sval = carve(blk * 4);
+	HIPCHK(hipMalloc(&m->d_block_scratch, off));
+	HIPCHK(hipMemsetAsync(m->d_block_scratch, 0, off, m->stream));
+	char *base = (char *)m->d_block_scratch;
+	BlockDev &bd = m->bd;
+	bd.kmers = nullptr; bd.counts = nullptr;
+	bd.list[0] = (u32 *)(base + o_list0); bd.list[1] = (u32 *)(base + o_list1);
+	bd.n = (int *)(base + o_n); bd.status = (unsigned char *)(base + o_status);
+	for (int s2 = 0; s2 < KMX_NSLOW; s2++) bd.U[s2] = (u32 *)(base + o_U[s2]);
+	bd.Un = (int *)(base + o_Un); bd.R = (u64 *)(base + o_R); bd.tile_cnt = (int *)(base + o_tc);
+	bd.m = (int *)(base + o_m); bd.h = (int *)(base + o_h); bd.hpos = (u32 *)(base + o_hpos); bd.sval = (u32 *)(base + o_sval);
+	bd.stats = m->d_stats;
+	// rest accumulators: grown on demand (see ensure_rest_capacity)
+	m->rest_cap = std::max<u64>(m->n_km / 8, 2 * blk) + blk;
+	TRY(dalloc(&m->d_rest_kmers, m->rest_cap * m->W, false, m->stream));
+	TRY(dalloc(&m->d_rest_counts, m->rest_cap, false, m->stream));
+	TRY(dalloc(&m->d_rest_n, 1, true, m->stream));
+	m->rest_upper = 0;
+	TRY(dalloc(&m->d_stale_kmers, (u64)nb * 2, true, m->stream));
+	TRY(dalloc(&m->d_stale_counts, (u64)nb, true, m->stream));
+	const int tiles = kmxk::classify_tiles(kChunk);
+	TRY(dalloc(&m->d_tile_cnt, (u64)tiles, false, m->stream));
+	TRY(dalloc(&m->d_tile_off, (u64)tiles, false, m->stream));
+	TRY(dalloc(&m->d_total, 4, true, m->stream));
+	HIPCHK(hipMemsetAsync(m->d_stats, 0, ST_N * 8, m->stream));
+	m->epoch = 1; m->blocks = 0; m->rounds = 0;
+	m->t_insert_kernels = 0; m->t_total = 0;
+	memset(m->h_stats, 0, sizeof m->h_stats);
+	m->state = ST_BUILDING;
+	return KMX_OK;
+}
+
+static int ensure_rest_capacity(kmx_model *m, u64 add)
+{
+	if (m->rest_upper + add <= m->rest_cap) { m->rest_upper += add; return KMX_OK; }
+	unsigned long long actual = 0;
+	HIPCHK(hipMemcpyAsync(&actual, m->d_rest_n, 8, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipStreamSynchronize(m->stream));
+	m->rest_upper = actual;
+	if (m->rest_upper + add > m->rest_cap) {
+		u64 ncap = std::max<u64>(m->rest_cap * 2, m->rest_upper + add);
+		u64 *nk = nullptr;
+		int *nc = nullptr;
+		HIPCHK(hipMalloc((void **)&nk, ncap * m->W * 8));
+		HIPCHK(hipMalloc((void **)&nc, ncap * 4));
+		HIPCHK(hipMemcpyAsync(nk, m->d_rest_kmers, actual * m->W * 8, hipMemcpyDeviceToDevice, m->stream));
+		HIPCHK(hipMemcpyAsync(nc, m->d_rest_counts, actual * 4, hipMemcpyDeviceToDevice, m->stream));
+		HIPCHK(hipStreamSynchronize(m->stream));
+		hipFree(m->d_rest_kmers); hipFree(m->d_rest_counts);
+		m->d_rest_kmers = nk; m->d_rest_counts = nc; m->rest_cap = ncap;
+	}
+	m->rest_upper += add;
+	return KMX_OK;
+}
+
+// Stale-slot duplicate (quirk Q1, kmodel.hpp:520-527 + :539): in the final partial block every unused
+// buffer row whose slot 0 still holds a survivor of the previous block re-offers it to nb-1 arrays (it
+// fails on all of them: bits are never cleared) and pushes it to the rest table a second time.
+__global__ void k_stale_dup(int first_unused_row, int nb, int W, const u64 *stale_kmers, const int *stale_counts, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stats)
+{
+	int i = first_unused_row + threadIdx.x;
+	if (i >= nb || stale_counts[i] == 0) return;
+	u64 p = atomicAdd(rest_n, 1ULL);
+	for (int w = 0; w < W; w++) rest_kmers[p * W + w] = stale_kmers[(u64)i * W + w];
+	rest_counts[p] = stale_counts[i];
+	atomicAdd(stats + ST_ATTEMPTS, (u64)(nb - 1));
+}
+
+// insert_with_thread (kmodel.hpp:557-573) for the block at staging offset `head`
+static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_partial)
+{
+	const int nb = m->nb;
+	m->bd.kmers = m->d_stg_kmers + head * m->W;
+	m->bd.counts = m->d_stg_counts + head;
+	int pp = 0;
+	kmxk::block_init(m->bd, nb, pp, (int)n_in_block, m->stream);
+	for (int t = 0; t < nb; t++) {
+		kmxk::round(m->md, m->bd, t, pp, &m->epoch, m->stream);
+		pp ^= 1;
+		m->rounds++;
+	}
+	TRY(ensure_rest_capacity(m, n_in_block + (u64)nb));
+	if (final_partial) {
+		int row = (int)((n_in_block - 1) / KMX_BUCKET);
+		if (row + 1 < nb && m->blocks > 0)
+			hipLaunchKernelGGL(k_stale_dup, dim3(1), dim3(64), 0, m->stream, row + 1, nb, m->W, (const u64 *)m->d_stale_kmers,
+			                   (const int *)m->d_stale_counts, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stats);
+	}
+	kmxk::rest_append(m->md, m->bd, pp, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->stream);
+	m->blocks++;
+	HIPCHK(hipGetLastError());
+	return KMX_OK;
+}
+
+extern "C" int kmx_insert_batch_dev(kmx_model *m, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	if (m->state != ST_BUILDING) return fail(KMX_E_STATE, "insert_batch before begin");
+	HIPCHK(hipSetDevice(m->device));
+	const u64 blk = (u64)m->nb * KMX_BUCKET;
+	for (u64 done = 0; done < n;) {
+		const u64 c = std::min<u64>(kChunk, n - done);
+		const u64 *km = (const u64 *)d_kmers + done * m->W;
+		const u32 *ct = (const u32 *)d_counts + done;
+		kmxk::classify_count(m->md, km, ct, c, m->d_tile_cnt, m->d_tile_off, m->d_total, m->d_stats, m->stream);
+		HIPCHK(hipMemcpyAsync(m->h_total, m->d_total, 4, hipMemcpyDeviceToHost, m->stream));
+		HIPCHK(hipStreamSynchronize(m->stream));
+		const u64 add = (u64)*m->h_total;
+		if (m->km_byte_size == 0 && add) { done += c; continue; }             // divergence D2: no arrays to insert into
+		if (m->stg_n + add > m->stg_cap) return fail(KMX_E_STATE, "staging overflow");
+		kmxk::classify_scatter(m->md, km, ct, c, m->d_tile_off, m->d_stg_kmers, m->d_stg_counts, m->stg_n, m->stream);
+		m->stg_n += add;
+		u64 head = 0;
+		while (m->stg_n - head >= blk) {
+			TRY(process_block(m, head, blk, false));
+			head += blk;
+		}
+		if (head) {                                                           // carry the remainder (< one block) to the front
+			const u64 rem = m->stg_n - head;
+			if (rem) {
+				HIPCHK(hipMemcpyAsync(m->d_stg_kmers, m->d_stg_kmers + head * m->W, rem * m->W * 8, hipMemcpyDeviceToDevice, m->stream));
+				HIPCHK(hipMemcpyAsync(m->d_stg_counts, m->d_stg_counts + head, rem * 4, hipMemcpyDeviceToDevice, m->stream));
+			}
+			m->stg_n = rem;
+		}
+		done += c;
+	}
+	HIPCHK(hipGetLastError());
+	return KMX_OK;
+}
+
+extern "C" int kmx_insert_batch(kmx_model *m, const uint64_t *kmers, const uint32_t *counts, uint64_t n)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	if (m->state != ST_BUILDING) return fail(KMX_E_STATE, "insert_batch before begin");
+	HIPCHK(hipSetDevice(m->device));
+	u64 *dk = nullptr;
+	u32 *dc = nullptr;
+	const u64 step = std::min<u64>(kChunk, n ? n : 1);
+	HIPCHK(hipMalloc((void **)&dk, step * m->W * 8));
+	HIPCHK(hipMalloc((void **)&dc, step * 4));
+	int rc = KMX_OK;
+	for (u64 done = 0; done < n && !rc; done += step) {
+		const u64 c = std::min<u64>(step, n - done);
+		if (hipMemcpyAsync(dk, kmers + done * m->W, c * m->W * 8, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
+		    hipMemcpyAsync(dc, counts + done, c * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess) { rc = fail(KMX_E_NODEVICE, "H2D copy failed"); break; }
+		rc = kmx_insert_batch_dev(m, (const uint64_t *)dk, dc, c);
+	}
+	hipStreamSynchronize(m->stream);
+	hipFree(dk); hipFree(dc);
+	return rc;
+}
+
+// KRestData::build (rest.hpp:95-135,157-161) from the survivors accumulated on the device; uploads the
+// device form for queries.  Host side: the table is small (a few % of the k-mers).
+static int rest_to_device(kmx_model *m, const std::vector<RestEnt> *sorted);
+
+static int build_rest(kmx_model *m)
+{
+	RestTable &r = m->rest;
+	free_rest_dev(r);
+	unsigned long long n = 0;
+	HIPCHK(hipMemcpyAsync(&n, m->d_rest_n, 8, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipStreamSynchronize(m->stream));
+	const int W = m->W, k = m->k;
+	std::vector<u64> hk(n * W);
+	std::vector<int> hc(n);
+	if (n) {
+		HIPCHK(hipMemcpy(hk.data(), m->d_rest_kmers, n * W * 8, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(hc.data(), m->d_rest_counts, n * 4, hipMemcpyDeviceToHost));
+	}
+	std::vector<RestEnt> v(n);
+	for (u64 i = 0; i < n; i++) {
+		v[i].w[0] = W == 2 ? hk[2 * i] : 0;
+		v[i].w[1] = W == 2 ? hk[2 * i + 1] : hk[i];
+		v[i].c = hc[i];
+	}
+	std::sort(v.begin(), v.end(), [](const RestEnt &a, const RestEnt &b) { return a.w[0] != b.w[0] ? a.w[0] < b.w[0] : a.w[1] < b.w[1]; });
+	r.k = k;
+	r.pre_len = rest_prefix_len(k);
+	r.map_size = 1 << (2 * r.pre_len);
+	r.suff_group = (k - r.pre_len) / 4;
+	r.entries = n;
+	r.suff_bin_size = n * (u64)r.suff_group;
+	r.hash2index.assign(r.map_size, -1);
+	r.pre_buffer.assign(1, 0);
+	r.suffix_bin.assign(r.suff_bin_size, 0);
+	r.count_bin.resize(n);
+	const int sbits = 2 * (k - r.pre_len);
+	long long prev = -1;
+	for (u64 e = 0; e < n; e++) {
+		unsigned __int128 val = ((unsigned __int128)v[e].w[0] << 64) | v[e].w[1];
+		long long pre = (long long)(u64)(val >> sbits);
+		if (pre != prev) { r.hash2index[pre] = (int)r.pre_buffer.size() - 1; r.pre_buffer.push_back(0); prev = pre; }
+		r.pre_buffer.back() = (int)(e + 1);
+		for (int g = 0; g < r.suff_group; g++)
+			r.suffix_bin[e * (u64)r.suff_group + g] = (unsigned char)(val >> (8 * (r.suff_group - 1 - g)));
+		r.count_bin[e] = v[e].c;
+	}
+	r.pre_buffer_size = (int)r.pre_buffer.size();
+	return rest_to_device(m, &v);
+}
+
+// device form: suffix integers (W words per row) instead of byte rows
+static int rest_to_device(kmx_model *m, const std::vector<RestEnt> *sorted)
+{
+	RestTable &r = m->rest;
+	const int W = m->W;
+	const u64 n = r.entries;
+	std::vector<u64> suf(n * W + 1, 0);
+	const int sbits = 8 * r.suff_group;
+	for (u64 e = 0; e < n; e++) {
+		unsigned __int128 val = 0;
+		if (sorted) val = ((unsigned __int128)(*sorted)[e].w[0] << 64) | (*sorted)[e].w[1];
+		else for (int g = 0; g < r.suff_group; g++) val = (val << 8) | r.suffix_bin[e * (u64)r.suff_group + g];
+		if (sbits < 128) val &= (((unsigned __int128)1) << sbits) - 1;
+		if (W == 1) suf[e] = (u64)val;
+		else { suf[2 * e] = (u64)(val >> 64); suf[2 * e + 1] = (u64)val; }
+	}
+	HIPCHK(hipMalloc((void **)&r.d_h2i, (u64)r.map_size * 4));
+	HIPCHK(hipMalloc((void **)&r.d_pre, (u64)r.pre_buffer_size * 4 + 4));
+	HIPCHK(hipMalloc((void **)&r.d_cnt, n * 4 + 4));
+	HIPCHK(hipMalloc((void **)&r.d_suf, suf.size() * 8));
+	HIPCHK(hipMemcpy(r.d_h2i, r.hash2index.data(), (u64)r.map_size * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(r.d_pre, r.pre_buffer.data(), (u64)r.pre_buffer_size * 4, hipMemcpyHostToDevice));
+	if (n) HIPCHK(hipMemcpy(r.d_cnt, r.count_bin.data(), n * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(r.d_suf, suf.data(), suf.size() * 8, hipMemcpyHostToDevice));
+	return KMX_OK;
+}
+
+extern "C" int kmx_finish(kmx_model *m)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	if (m->state != ST_BUILDING) return fail(KMX_E_STATE, "finish before begin");
+	HIPCHK(hipSetDevice(m->device));
+	if (m->stg_n) TRY(process_block(m, 0, m->stg_n, true));   // push_last_to_array; an empty tail is skipped (divergence D1)
+	m->stg_n = 0;
+	HIPCHK(hipMemcpyAsync(m->h_stats, m->d_stats, ST_N * 8, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipStreamSynchronize(m->stream));
+	if (m->h_stats[ST_BAD_COUNT]) {
+		m->state = ST_EMPTY;
+		return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)m->h_stats[ST_BAD_COUNT], m->ci, m->cs);
+	}
+	TRY(build_rest(m));
+	free_build_state(m);
+	fill_model_dev(m);
+	m->state = ST_READY;
+	return KMX_OK;
+}
+
+static int build_common(kmx_model *m, int k, const u64 *d_kmers, const u32 *d_counts, u64 n, u64 n_total)
+{
+	HIPCHK(hipSetDevice(m->device));
+	HIPCHK(hipEventRecord(m->ev0, m->stream));
+	HIPCHK(hipMemsetAsync(m->d_nbf, 0, 24, m->stream));
+	HIPCHK(hipMemsetAsync(m->d_stats, 0, ST_N * 8, m->stream));
+	kmxk::histogram(d_counts, n, m->ci, m->cs, m->bf_num, m->d_nbf, m->d_stats, m->stream);    // pass 1
+	u64 nbf[3], bad = 0;
+	HIPCHK(hipMemcpyAsync(nbf, m->d_nbf, 24, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipMemcpyAsync(&bad, m->d_stats + ST_BAD_COUNT, 8, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipStreamSynchronize(m->stream));
+	if (bad) return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)bad, m->ci, m->cs);
+	TRY(kmx_begin(m, k, (const uint64_t *)nbf, n_total));
+	TRY(kmx_insert_batch_dev(m, (const uint64_t *)d_kmers, d_counts, n));
+	TRY(kmx_finish(m));
+	HIPCHK(hipEventRecord(m->ev1, m->stream));
+	HIPCHK(hipEventSynchronize(m->ev1));
+	float ms = 0;
+	HIPCHK(hipEventElapsedTime(&ms, m->ev0, m->ev1));
+	m->t_total = ms * 1e-3;
+	return KMX_OK;
+}
+
+extern "C" int kmx_build_dev(kmx_model *m, int k, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	if (k < 3 || k > 64) return fail(KMX_E_ARG, "k=%d out of range [3,64]", k);
+	return build_common(m, k, (const u64 *)d_kmers, (const u32 *)d_counts, n, n);
+}
+
+extern "C" int kmx_build_host(kmx_model *m, int k, const uint64_t *kmers, const uint32_t *counts, uint64_t n)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	if (k < 3 || k > 64) return fail(KMX_E_ARG, "k=%d out of range [3,64]", k);
+	HIPCHK(hipSetDevice(m->device));
+	const int W = (k + 31) / 32;
+	u64 *dk = nullptr;
+	u32 *dc = nullptr;
+	HIPCHK(hipMalloc((void **)&dk, (n ? n : 1) * W * 8));
+	HIPCHK(hipMalloc((void **)&dc, (n ? n : 1) * 4));
+	HIPCHK(hipMemcpy(dk, kmers, n * W * 8, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(dc, counts, n * 4, hipMemcpyHostToDevice));
+	int rc = build_common(m, k, dk, dc, n, n);
+	hipFree(dk); hipFree(dc);
+	return rc;
+}
+
+// KModel::init(db_file) (kmodel.hpp:57-86): pass 1 counts on the host while listing, pass 2 streams batches
+extern "C" int kmx_build_from_kmc(kmx_model *m, const char *db_prefix)
+{
+	if (!m || !db_prefix) return fail(KMX_E_ARG, "null argument");
+	kmx::KmcListing db;
+	if (!db.open(db_prefix)) return fail(KMX_E_IO, "can't open the kmer_data_base %s: %s", db_prefix, db.error().c_str());
+	const int k = (int)db.kmer_length(), W = db.words();
+	const size_t B = size_t(1) << 22;
+	u64 *hk = nullptr;
+	u32 *hc = nullptr;
+	HIPCHK(hipSetDevice(m->device));
+	HIPCHK(hipHostMalloc((void **)&hk, B * W * 8));
+	HIPCHK(hipHostMalloc((void **)&hc, B * 4));
+	uint64_t nbf[3] = {0, 0, 0};
+	int rc = KMX_OK;
+	for (size_t got; (got = db.next_batch((uint64_t *)hk, hc, B)) > 0;)      // pass 1 (kmodel.hpp:423-428)
+		for (size_t i = 0; i < got; i++) {
+			if (hc[i] < (u32)m->ci || hc[i] > (u32)m->cs) { rc = fail(KMX_E_RANGE, "count %u outside [ci=%d, cs=%d]", hc[i], m->ci, m->cs); break; }
+			if (hc[i] < (u32)(m->ci + m->bf_num)) nbf[hc[i] - (u32)m->ci]++;
+		}
+	if (!rc) rc = kmx_begin(m, k, nbf, db.kmer_count());
+	if (!rc) {
+		hipEventRecord(m->ev0, m->stream);
+		db.restart();                                                          // kmodel.hpp:430
+		for (size_t got; !rc && (got = db.next_batch((uint64_t *)hk, hc, B)) > 0;) rc = kmx_insert_batch(m, (const uint64_t *)hk, hc, got);   // pass 2
+	}
+	if (!rc) rc = kmx_finish(m);
+	if (!rc) {
+		hipEventRecord(m->ev1, m->stream);
+		hipEventSynchronize(m->ev1);
+		float ms = 0;
+		hipEventElapsedTime(&ms, m->ev0, m->ev1);
+		m->t_total = ms * 1e-3;
+	}
+	hipHostFree(hk); hipHostFree(hc);
+	return rc;
+}
+
+// ------------------------------------------------------------------------------------------ query
+extern "C" int kmx_query_packed_dev(kmx_model *m, const uint64_t *d_kmers, uint64_t n, int32_t *d_out)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	if (m->state != ST_READY) return fail(KMX_E_STATE, "query before the model is built or loaded");
+	HIPCHK(hipSetDevice(m->device));
+	kmxk::query(m->md, (const u64 *)d_kmers, n, d_out, m->stream);
+	HIPCHK(hipGetLastError());
+	return KMX_OK;
+}
+
+extern "C" int kmx_query_packed(kmx_model *m, const uint64_t *kmers, uint64_t n, int32_t *out)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	if (m->state != ST_READY) return fail(KMX_E_STATE, "query before the model is built or loaded");
+	if (!n) return KMX_OK;
+	HIPCHK(hipSetDevice(m->device));
+	u64 *dk = nullptr;
+	int *dout = nullptr;
+	HIPCHK(hipMalloc((void **)&dk, n * m->W * 8));
+	HIPCHK(hipMalloc((void **)&dout, n * 4));
+	HIPCHK(hipMemcpyAsync(dk, kmers, n * m->W * 8, hipMemcpyHostToDevice, m->stream));
+	int rc = kmx_query_packed_dev(m, (const uint64_t *)dk, n, dout);
+	if (!rc && hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "D2H copy failed");
+	hipStreamSynchronize(m->stream);
+	hipFree(dk); hipFree(dout);
+	return rc;
+}
+
+// vector<string> front door: strings are packed on the host (2 bits/base), the lookup runs on the device.
+// Strings that the packed form cannot represent (length != k, characters outside ACGT) are rejected.
+extern "C" int kmx_query_ascii(kmx_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	if (m->state != ST_READY) return fail(KMX_E_STATE, "query before the model is built or loaded");
+	if (len != m->k) return fail(KMX_E_ARG, "k-mer length %d does not match the model's k=%d", len, m->k);
+	std::vector<u64> pk(n * m->W);
+	for (u64 i = 0; i < n; i++) {
+		unsigned __int128 v = 0;
+		const char *s = strs + i * (u64)stride;
+		for (int j = 0; j < len; j++) {
+			unsigned c;
+			switch (s[j]) {
+			case 'A': c = 0; break;
+			case 'C': c = 1; break;
+			case 'G': c = 2; break;
+			case 'T': c = 3; break;
+			default: return fail(KMX_E_ARG, "k-mer %llu holds a character outside ACGT", (unsigned long long)i);
+			}
+			v = (v << 2) | c;
+		}
+		if (m->W == 1) pk[i] = (u64)v;
+		else { pk[2 * i] = (u64)(v >> 64); pk[2 * i + 1] = (u64)v; }
+	}
+	return kmx_query_packed(m, (const uint64_t *)pk.data(), n, out);
+}
+
+// ------------------------------------------------------------------------------------------ persistence
+static int download_array(kmx_model *m, int which, int index, std::vector<unsigned char> &out)
+{
+	out.clear();
+	if (which == 0 || which == 1 || which == 2) {
+		if (which != 2 && (index < 0 || index >= m->bf_num)) return fail(KMX_E_ARG, "bad filter index");
+		const u64 nbytes = which == 0 ? m->byte_bf[index] : which == 1 ? m->byte_bf_back[index] : m->byte_km_back;
+		const u32 *src = which == 0 ? m->d_bf[index] : which == 1 ? m->d_bf_back[index] : m->d_km_back;
+		out.resize(nbytes);
+		if (nbytes) HIPCHK(hipMemcpy(out.data(), src, nbytes, hipMemcpyDeviceToHost));
+		return KMX_OK;
+	}
+	if (which < 3 || which > 5 || index < 0 || index >= m->nb) return fail(KMX_E_ARG, "bad array selector");
+	const u64 nbytes = m->km_byte_size;
+	out.resize(nbytes);
+	if (!nbytes) return KMX_OK;
+	unsigned char *tmp = nullptr;
+	HIPCHK(hipMalloc((void **)&tmp, m->ncells * 2));
+	kmxk::cells_to_disk(m->d_cells[index], m->ncells, nbytes, which - 3, tmp, m->stream);
+	hipError_t e = hipMemcpyAsync(out.data(), tmp, nbytes, hipMemcpyDeviceToHost, m->stream);
+	hipStreamSynchronize(m->stream);
+	hipFree(tmp);
+	if (e != hipSuccess) return fail(KMX_E_NODEVICE, "D2H copy failed");
+	return KMX_OK;
+}
+
+extern "C" int kmx_download(kmx_model *m, int which, int index, uint8_t *dst, uint64_t capacity, uint64_t *written)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	if (m->state == ST_EMPTY) return fail(KMX_E_STATE, "no arrays yet");
+	HIPCHK(hipSetDevice(m->device));
+	HIPCHK(hipStreamSynchronize(m->stream));
+	std::vector<unsigned char> v;
+	TRY(download_array(m, which, index, v));
+	if (written) *written = v.size();
+	if (v.size() > capacity) return fail(KMX_E_ARG, "buffer too small: need %llu bytes", (unsigned long long)v.size());
+	if (!v.empty()) memcpy(dst, v.data(), v.size());
+	return KMX_OK;
+}
+
+// KModel::save (kmodel.hpp:173-206) + KRestData::save_file (rest.hpp:197-221); layouts: Appendix B.1/B.2
+extern "C" int kmx_save(kmx_model *m, const char *dir)
+{
+	if (!m || !dir) return fail(KMX_E_ARG, "null argument");
+	if (m->state != ST_READY) return fail(KMX_E_STATE, "save before the model is built or loaded");
+	HIPCHK(hipSetDevice(m->device));
+	HIPCHK(hipStreamSynchronize(m->stream));
+	std::string d(dir);
+	FILE *f = fopen((d + "/header").c_str(), "w");
+	if (!f) return fail(KMX_E_IO, "cannot write %s/header", dir);
+	fprintf(f, "number_hash %d\nnumber_bit %d\nci %d\ncs %d\n", m->nh, m->nb, m->ci, m->cs);
+	fclose(f);
+	if (!(f = fopen((d + "/km.bin").c_str(), "wb"))) return fail(KMX_E_IO, "cannot write %s/km.bin", dir);
+	fwrite(&m->n_km, 8, 1, f);
+	for (int i = 0; i < m->bf_num; i++) fwrite(&m->n_bf[i], 8, 1, f);
+	std::vector<unsigned char> v;
+	int rc = KMX_OK;
+	for (int i = 0; i < m->bf_num && !rc; i++) {
+		if (!(rc = download_array(m, 0, i, v))) fwrite(v.data(), 1, v.size(), f);
+		if (!rc && !(rc = download_array(m, 1, i, v))) fwrite(v.data(), 1, v.size(), f);
+	}
+	if (!rc && !(rc = download_array(m, 2, 0, v))) fwrite(v.data(), 1, v.size(), f);
+	for (int a = 0; a < m->nb && !rc; a++) {
+		if (!(rc = download_array(m, 3, a, v))) fwrite(v.data(), 1, v.size(), f);             // bit_array_1 (value)
+		if (!rc && !(rc = download_array(m, 4, a, v))) fwrite(v.data(), 1, v.size(), f);      // bit_array_2 (tag)
+	}
+	fclose(f);
+	if (rc) return rc;
+	const RestTable &r = m->rest;
+	if (!(f = fopen((d + "/rest.bin").c_str(), "wb"))) return fail(KMX_E_IO, "cannot write %s/rest.bin", dir);
+	int h[4] = {r.k, r.pre_len, r.map_size, r.pre_buffer_size};
+	fwrite(h, 4, 4, f);
+	fwrite(&r.suff_bin_size, 8, 1, f);
+	fwrite(&r.entries, 8, 1, f);
+	fwrite(r.hash2index.data(), 4, r.hash2index.size(), f);
+	fwrite(r.pre_buffer.data(), 4, r.pre_buffer.size(), f);
+	fwrite(r.suffix_bin.data(), 1, r.suffix_bin.size(), f);
+	fwrite(r.count_bin.data(), 4, r.count_bin.size(), f);
+	fclose(f);
+	return KMX_OK;
+}
+
+// get_model(save_dir) (kmodel.hpp:680-696) + KModel::load (:209-235) + KRestData::from_file (rest.hpp:163-195)
+extern "C" int kmx_load(const char *dir, kmx_model **out)
+{
+	if (!dir || !out) return fail(KMX_E_ARG, "null argument");
+	*out = nullptr;
+	std::string d(dir);
+	FILE *f = fopen((d + "/header").c_str(), "r");
+	if (!f) return fail(KMX_E_IO, "load_model: cant't open the header of the model ! (%s/header)", dir);
+	char key[64];
+	int nh, nb, ci, cs;
+	int got = fscanf(f, "%63s %d %63s %d %63s %d %63s %d", key, &nh, key, &nb, key, &ci, key, &cs);
+	fclose(f);
+	if (got != 8) return fail(KMX_E_IO, "malformed header in %s", dir);
+	kmx_model *m = nullptr;
+	TRY(kmx_create(ci, cs, nh, nb, &m));
+	auto bail = [&](int code) { kmx_destroy(m); return code; };
+	// rest.bin first: it carries k
+	if (!(f = fopen((d + "/rest.bin").c_str(), "rb"))) return bail(fail(KMX_E_IO, "cannot open %s/rest.bin", dir));
+	RestTable &r = m->rest;
+	int h[4];
+	bool ok = fread(h, 4, 4, f) == 4 && fread(&r.suff_bin_size, 8, 1, f) == 1 && fread(&r.entries, 8, 1, f) == 1;
+	if (ok) {
+		r.k = h[0]; r.pre_len = h[1]; r.map_size = h[2]; r.pre_buffer_size = h[3];
+		ok = r.k >= 3 && r.k <= 64 && r.pre_len >= 1 && r.pre_len <= 12 && r.map_size == (1 << (2 * r.pre_len)) && r.pre_buffer_size >= 1;
+	}
+	if (ok) {
+		r.suff_group = (r.k - r.pre_len) / 4;
+		ok = r.suff_bin_size == r.entries * (u64)r.suff_group;
+	}
+	if (ok) {
+		r.hash2index.resize(r.map_size); r.pre_buffer.resize(r.pre_buffer_size);
+		r.suffix_bin.resize(r.suff_bin_size); r.count_bin.resize(r.entries);
+		ok = fread(r.hash2index.data(), 4, r.map_size, f) == (size_t)r.map_size &&
+		     fread(r.pre_buffer.data(), 4, r.pre_buffer_size, f) == (size_t)r.pre_buffer_size &&
+		     fread(r.suffix_bin.data(), 1, r.suff_bin_size, f) == r.suff_bin_size &&
+		     fread(r.count_bin.data(), 4, r.entries, f) == r.entries;
+	}
+	fclose(f);
+	if (!ok) return bail(fail(KMX_E_IO, "malformed %s/rest.bin", dir));
+	m->k = r.k; m->W = (r.k + 31) / 32;
+	if (!(f = fopen((d + "/km.bin").c_str(), "rb"))) return bail(fail(KMX_E_IO, "cannot open %s/km.bin", dir));
+	ok = fread(&m->n_km, 8, 1, f) == 1;
+	u64 nbf = 0;
+	for (int i = 0; i < m->bf_num && ok; i++) { ok = fread(&m->n_bf[i], 8, 1, f) == 1; nbf += m->n_bf[i]; }
+	if (!ok) { fclose(f); return bail(fail(KMX_E_IO, "malformed %s/km.bin", dir)); }
+	m->n_total = m->n_km + nbf;
+	compute_sizes(m);
+	int rc = alloc_arrays(m);
+	if (rc) { fclose(f); return bail(rc); }
+	std::vector<unsigned char> buf, buf2;
+	auto upload = [&](u32 *dst, u64 nbytes) -> bool {
+		buf.resize(nbytes);
+		if (nbytes && fread(buf.data(), 1, nbytes, f) != nbytes) return false;
+		return !nbytes || hipMemcpy(dst, buf.data(), nbytes, hipMemcpyHostToDevice) == hipSuccess;
+	};
+	for (int i = 0; i < m->bf_num && ok; i++) ok = upload(m->d_bf[i], m->byte_bf[i]) && upload(m->d_bf_back[i], m->byte_bf_back[i]);
+	ok = ok && upload(m->d_km_back, m->byte_km_back);
+	unsigned char *dv = nullptr, *dt = nullptr;
+	if (ok && m->km_byte_size) {
+		ok = hipMalloc((void **)&dv, m->ncells * 2) == hipSuccess && hipMalloc((void **)&dt, m->ncells * 2) == hipSuccess;
+		for (int a = 0; a < m->nb && ok; a++) {
+			buf.resize(m->km_byte_size); buf2.resize(m->km_byte_size);
+			ok = fread(buf.data(), 1, m->km_byte_size, f) == m->km_byte_size && fread(buf2.data(), 1, m->km_byte_size, f) == m->km_byte_size;
+			ok = ok && hipMemcpy(dv, buf.data(), m->km_byte_size, hipMemcpyHostToDevice) == hipSuccess &&
+			     hipMemcpy(dt, buf2.data(), m->km_byte_size, hipMemcpyHostToDevice) == hipSuccess;
+			if (ok) { kmxk::cells_from_disk(dv, dt, m->km_byte_size, m->d_cells[a], m->ncells, m->stream); ok = hipStreamSynchronize(m->stream) == hipSuccess; }
+		}
+		hipFree(dv); hipFree(dt);
+	}
+	fclose(f);
+	if (!ok) return bail(fail(KMX_E_IO, "short or unreadable %s/km.bin", dir));
+	rc = rest_to_device(m, nullptr);
+	if (rc) return bail(rc);
+	fill_model_dev(m);
+	m->state = ST_READY;
+	*out = m;
+	return KMX_OK;
+}
+
+extern "C" int kmx_get_stats(kmx_model *m, kmx_stats *st)
+{
+	if (!m || !st) return fail(KMX_E_ARG, "null argument");
+	memset(st, 0, sizeof *st);
+	st->n_total = m->n_total; st->n_km = m->n_km;
+	for (int i = 0; i < 3; i++) { st->n_bf[i] = m->n_bf[i]; st->byte_bf[i] = m->byte_bf[i]; st->byte_bf_back[i] = m->byte_bf_back[i]; }
+	st->attempts = m->h_stats[ST_ATTEMPTS]; st->successes = m->h_stats[ST_SUCCESSES];
+	st->fast_commits = m->h_stats[ST_FAST]; st->contended = m->h_stats[ST_CONTENDED]; st->finisher_iters = m->h_stats[ST_FIN_ITERS];
+	st->rest_entries = m->rest.entries; st->km_byte_size = m->km_byte_size; st->byte_km_back = m->byte_km_back;
+	st->blocks = m->blocks; st->rounds = m->rounds;
+	st->k = m->k; st->ci = m->ci; st->cs = m->cs; st->nh = m->nh; st->nb = m->nb; st->bf_num = m->bf_num; st->device = m->device;
+	return KMX_OK;
+}
+
+extern "C" int kmx_last_build_seconds(kmx_model *m, double *insert_kernels_s, double *total_s)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	if (insert_kernels_s) *insert_kernels_s = m->t_insert_kernels;
+	if (total_s) *total_s = m->t_total;
+	return KMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ KAT surface / microbench
+extern "C" int kmx_debug_hash(int k, const uint64_t *kmers, uint64_t n, const uint32_t *seeds, int n_seeds, int whole, uint64_t *hashes)
+{
+	if (k < 3 || k > 64 || n_seeds < 1) return fail(KMX_E_ARG, "bad arguments");
+	const int W = (k + 31) / 32;
+	u64 *dk = nullptr, *dh = nullptr;
+	u32 *ds = nullptr;
+	HIPCHK(hipMalloc((void **)&dk, n * W * 8 + 8));
+	HIPCHK(hipMalloc((void **)&dh, n * n_seeds * 8 + 8));
+	HIPCHK(hipMalloc((void **)&ds, n_seeds * 4));
+	HIPCHK(hipMemcpy(dk, kmers, n * W * 8, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(ds, seeds, n_seeds * 4, hipMemcpyHostToDevice));
+	kmxk::debug_hash(k, dk, n, ds, n_seeds, whole, dh, nullptr);
+	HIPCHK(hipMemcpy(hashes, dh, n * n_seeds * 8, hipMemcpyDeviceToHost));
+	hipFree(dk); hipFree(dh); hipFree(ds);
+	return KMX_OK;
+}
+
+extern "C" int kmx_debug_min_kmer(int k, const uint64_t *kmers, uint64_t n, uint64_t *out)
+{
+	if (k < 3 || k > 64) return fail(KMX_E_ARG, "bad arguments");
+	const int W = (k + 31) / 32;
+	u64 *dk = nullptr, *dout = nullptr;
+	HIPCHK(hipMalloc((void **)&dk, n * W * 8 + 8));
+	HIPCHK(hipMalloc((void **)&dout, n * W * 8 + 8));
+	HIPCHK(hipMemcpy(dk, kmers, n * W * 8, hipMemcpyHostToDevice));
+	kmxk::debug_min_kmer(k, dk, n, dout, nullptr);
+	HIPCHK(hipMemcpy(out, dout, n * W * 8, hipMemcpyDeviceToHost));
+	hipFree(dk); hipFree(dout);
+	return KMX_OK;
+}
+
+extern "C" int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds)
+{
+	if (bytes < 4096 || touches < 8 || iters < 1 || !seconds) return fail(KMX_E_ARG, "bad arguments");
+	u64 *buf = nullptr, *sink = nullptr;
+	const u64 ncell = bytes / 8, lanes = touches / 8;
+	HIPCHK(hipMalloc((void **)&buf, ncell * 8));
+	HIPCHK(hipMalloc((void **)&sink, 8));
+	HIPCHK(hipMemset(buf, 0, ncell * 8));
+	hipEvent_t e0, e1;
+	HIPCHK(hipEventCreate(&e0));
+	HIPCHK(hipEventCreate(&e1));
+	kmxk::micro(mode, buf, ncell, lanes, 12345, sink, nullptr);            // warm-up
+	HIPCHK(hipEventRecord(e0, nullptr));
+	for (int it = 0; it < iters; it++) kmxk::micro(mode, buf, ncell, lanes, 1000003ULL * (it + 1), sink, nullptr);
+	HIPCHK(hipEventRecord(e1, nullptr));
+	HIPCHK(hipEventSynchronize(e1));
+	float ms = 0;
+	HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+	*seconds = ms * 1e-3 / iters;
+	hipEventDestroy(e0); hipEventDestroy(e1);
+	hipFree(buf); hipFree(sink);
+	return KMX_OK;
+}

@@ -1,0 +1,52 @@
+// kmx_types.h -- plain structs passed by value from the host orchestration to the gfx950 kernels.
+#pragma once
+#include "device_common.h"
+
+// Everything a kernel needs to address the model in HBM (A.1-A.3 of SURVEY.md).
+struct ModelDev {
+	int k, nh, nb, ci, cs, bf_num;
+	StrGeom gfull, gback;                      // geometry of the k-mer and (k-2)-mer strings
+	u32 *bf[3];      ModU64 bf_mod[3];         // Bloom filters, on-disk byte layout (kmodel.hpp:250,253)
+	u32 *bf_back[3]; ModU64 bf_back_mod[3];    // their (k-2)-mer back filters       (kmodel.hpp:251,255)
+	u32 *km_back;    ModU64 km_back_mod;       // back filter of the coupled arrays  (kmodel.hpp:267-269)
+	u64 *cells[KMX_MAX_NB];                    // coupled arrays, cell layout (device_common.h)
+	ModU64 km_mod;                             // bit_array_length                   (kmodel.hpp:33,445)
+	const u32 *bin_of_occ;                     // occ -> bin  (occu_bin.hpp:67-77)
+	const u32 *mean_of_bin;                    // bin -> mean (occu_bin.hpp:79-83)
+	// exact rest table (rest.hpp), device form: suffixes as integers instead of byte rows
+	int rest_pre_len, rest_W;
+	u64 rest_entries;
+	const int *rest_h2i;                       // hash2index[4^pre_len]
+	const int *rest_pre;                       // pre_buffer[groups+1]
+	const u64 *rest_suf;                       // [entries][W] suffix value (low 2*(k-pre_len) bits)
+	const int *rest_cnt;                       // count_bin[entries]
+};
+
+// device-side statistics (one u64 each)
+enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_FAST, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_N };
+
+#define KMX_RSIZE_LOG2 20
+#define KMX_RSIZE (1u << KMX_RSIZE_LOG2)      // reservation slots per list (ordered slow path)
+#define KMX_NSLOW 3                            // U lists: after the fast path, after slow sub-round 1, 2
+#define KMX_TILE 1024                          // slots per reorder tile
+#define KMX_NTILES (KMX_BUCKET / KMX_TILE)
+
+// Working set of one nb*2^18 block (kmodel.hpp:508-573): lists are index permutations into the block.
+struct BlockDev {
+	const u64 *kmers;        // [nb*BUCKET][W] this block's k-mers in listing order (buffer i = slice i)
+	const u32 *counts;       // [nb*BUCKET]
+	u32 *list[2];            // ping-pong: list[pp][i*BUCKET + x] = index into buffer i of slot x
+	int *n;                  // [nb] current list lengths (buff_real_n, kmodel.hpp:277)
+	unsigned char *status;   // [nb*BUCKET] per slot: 0 undecided, 1 failed (survivor), 2 inserted
+	u32 *U[KMX_NSLOW];       // contended slot lists
+	int *Un;                 // [KMX_NSLOW*nb]
+	u64 *R;                  // [nb*KMX_RSIZE] epoch-tagged reservations
+	int *tile_cnt;           // [nb*NTILES]
+	int *m;                  // [nb] survivors of the round
+	int *h;                  // [nb] holes below m
+	u32 *hpos;               // [nb*BUCKET] hole positions, left to right
+	u32 *sval;               // [nb*BUCKET] movers, right to left
+	u64 *stats;              // [ST_N]
+};
+
+enum { SLOT_UNDECIDED = 0, SLOT_FAILED = 1, SLOT_INSERTED = 2 };

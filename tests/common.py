@@ -1,0 +1,47 @@
+"""Shared by the golden generator and the tests: the case table and the query-set recipe."""
+import hashlib
+
+import numpy as np
+
+from kmcex_amd import synth
+
+# name, k, ci, cs, nh, nb, n_draws
+CASES = [
+    ("tiny_k31", 31, 1, 1023, 7, 5, 20000),
+    ("k31_ci2_200k", 31, 2, 1023, 7, 5, 200000),
+    ("k55_nh9_nb6", 55, 1, 4095, 9, 6, 30000),
+    ("k21_nh6_nb3", 21, 2, 255, 6, 3, 5000),
+    ("k31_multiblock_ci1", 31, 1, 1023, 7, 5, 3200000),      # 2 full blocks + partial with unused rows (Q1)
+    ("k31_multiblock_ci2", 31, 2, 1023, 7, 5, 4000000),      # RS-scale plumbing stand-in (BASELINE configs[0])
+    ("k55_multiblock", 55, 1, 4095, 9, 6, 2000000),          # 1 full block (6*2^18) + partial, two-word k-mers
+    ("k32_nb4", 32, 1, 1023, 7, 4, 50000),                   # k == 32 boundary, pre_len 4
+]
+CASE = {c[0]: c for c in CASES}
+SMALL = ["tiny_k31", "k31_ci2_200k", "k55_nh9_nb6", "k21_nh6_nb3", "k32_nb4"]
+LARGE = ["k31_multiblock_ci1", "k31_multiblock_ci2", "k55_multiblock"]
+MAX_PRESENT = 400000
+
+
+def query_set(km, k, seed=7, max_present=MAX_PRESENT):
+    """Inserted k-mers in a seeded shuffle, first half reverse-complemented, + 10 % absent draws."""
+    rng = np.random.default_rng(seed)
+    idx = rng.permutation(len(km))
+    if max_present is not None:
+        idx = idx[:max_present]
+    q = km[idx].copy()
+    h = len(q) // 2
+    q[:h] = synth.revcomp(q[:h], k)
+    absent = synth.random_kmers(max(len(q) // 10, 10), k, seed_k=999)
+    return np.concatenate([q, absent])
+
+
+def sha_file(p):
+    h = hashlib.sha256()
+    with open(p, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def sha_occ(occ):
+    return hashlib.sha256(np.asarray(occ).astype("<i4").tobytes()).hexdigest()

@@ -29,38 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402
 from kmcex_amd import kmcdb, synth  # noqa: E402
 
-# name, k, ci, cs, nh, nb, n_draws
-CASES = [
-    ("tiny_k31", 31, 1, 1023, 7, 5, 20000),
-    ("k31_ci2_200k", 31, 2, 1023, 7, 5, 200000),
-    ("k55_nh9_nb6", 55, 1, 4095, 9, 6, 30000),
-    ("k21_nh6_nb3", 21, 2, 255, 6, 3, 5000),
-    ("k31_multiblock_ci1", 31, 1, 1023, 7, 5, 3200000),      # 2 full blocks + partial with unused rows (Q1)
-    ("k31_multiblock_ci2", 31, 2, 1023, 7, 5, 4000000),      # RS-scale plumbing stand-in (BASELINE configs[0])
-    ("k55_multiblock", 55, 1, 4095, 9, 6, 2000000),          # 1 full block (6*2^18) + partial, two-word k-mers
-    ("k32_nb4", 32, 1, 1023, 7, 4, 50000),                   # k == 32 boundary, pre_len 4
-]
-
-
-def query_set(km, k, seed=7, max_present=None):
-    """Inserted k-mers in a seeded shuffle, first half reverse-complemented, + 10 % absent draws."""
-    rng = np.random.default_rng(seed)
-    idx = rng.permutation(len(km))
-    if max_present is not None:
-        idx = idx[:max_present]
-    q = km[idx].copy()
-    h = len(q) // 2
-    q[:h] = synth.revcomp(q[:h], k)
-    absent = synth.random_kmers(max(len(q) // 10, 10), k, seed_k=999)
-    return np.concatenate([q, absent])
-
-
-def sha_file(p):
-    h = hashlib.sha256()
-    with open(p, "rb") as f:
-        for blk in iter(lambda: f.read(1 << 24), b""):
-            h.update(blk)
-    return h.hexdigest()
+from common import CASES, query_set, sha_file  # noqa: E402
 
 
 def main():
@@ -76,7 +45,7 @@ def main():
         m = O.OracleModel(ci, cs, nh, nb)
         m.build(k, km, cnt)
         m.save(db + ".ora")
-        q = query_set(km, k, max_present=400000)
+        q = query_set(km, k)
         qs = synth.to_strings(q, k)
         r_ref = O.ref_query(db + ".ref", qs, db)
         r_ora = m.query_packed(k, q)

@@ -1,0 +1,171 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the committed goldens.
+
+Everything here needs a real MI355X (`-m gpu`).  Bar: bit-exact (integer / byte / index work).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from common import CASE, LARGE, SMALL, query_set, sha_file, sha_occ
+from kmcex_amd import KModel, api, kmcdb, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("k", [31, 55, 21, 32, 33, 64, 16])
+def test_device_hash_matches_oracle(k):
+    """MurmurHash64A over the rebuilt ASCII string, k-mer and (k-2)-mer (tools.hpp:16-50)."""
+    km = synth.random_kmers(2000, k, seed_k=5)
+    strs = synth.to_strings(km, k)
+    seeds_idx = [0, 1, 6, 7, 34, 127]
+    seeds = [O.lib().kmo_hash_seed(i) for i in seeds_idx]
+    for whole in (True, False):
+        dev = api.debug_hash(k, km, seeds, whole)
+        for i in range(0, len(strs), 37):
+            s = strs[i] if whole else strs[i][1:-1]
+            for j, si in enumerate(seeds_idx):
+                assert int(dev[i, j]) == O.murmur64(s.encode(), si), (k, whole, strs[i], si)
+
+
+def test_device_hash_known_answers():
+    """Appendix C of SURVEY.md: vectors printed by the compiled reference."""
+    kat = {"ACGTACGTTGCAAGCTTAGGCTAACGTTAGC": (0x40918180070a81da, 0x9a229d41863aebb3),
+           "T" * 31: (0x378cba69158c32d6, 0x5536311a42c7bdc7),
+           "GATTACAGATTACAGATTACAGATTACAGAT": (0x26bf0b90f7af10fb, 0xf0abc7124c776870)}
+    seed0 = [O.lib().kmo_hash_seed(0)]
+    for s, (h_full, h_back) in kat.items():
+        km = synth.from_strings([s], 31)
+        assert int(api.debug_hash(31, km, seed0, True)[0, 0]) == h_full
+        assert int(api.debug_hash(31, km, seed0, False)[0, 0]) == h_back
+
+
+@pytest.mark.parametrize("k", [31, 55, 21, 32, 40, 64])
+def test_device_min_kmer_matches_oracle(k):
+    """get_min_kmer incl. the k>32 overflow (tools.hpp:160-167, quirk Q4)."""
+    km = synth.random_kmers(3000, k, seed_k=11)
+    dev = api.debug_min_kmer(k, km)
+    strs = synth.to_strings(km, k)
+    exp = synth.from_strings([O.min_kmer(s) for s in strs], k)
+    assert np.array_equal(dev.reshape(exp.shape), exp)
+
+
+def _build_both(name):
+    _, k, ci, cs, nh, nb, n = CASE[name]
+    km, cnt = synth.make_stream(n, k, ci, cs)
+    m = KModel(ci, cs, nh, nb)
+    m.build_packed(k, km, cnt)
+    o = O.OracleModel(ci, cs, nh, nb)
+    o.build(k, km, cnt)
+    return k, nb, km, cnt, m, o
+
+
+def _check_arrays(m, o, nb, bf_num):
+    for a in range(nb):
+        assert np.array_equal(m.download("tag", a), o.array_bytes("tag", a)), f"tag array {a}"
+        assert np.array_equal(m.download("value", a), o.array_bytes("value", a)), f"value array {a}"
+        assert not m.download("claims", a).any(), f"claim bits left on untagged positions of array {a}"
+    assert np.array_equal(m.download("km_back"), o.array_bytes("km_back"))
+    for i in range(bf_num):
+        assert np.array_equal(m.download("bf", i), o.array_bytes("bf", i)), f"bloom filter {i}"
+        assert np.array_equal(m.download("bf_back", i), o.array_bytes("bf_back", i)), f"back filter {i}"
+
+
+@pytest.mark.parametrize("name", SMALL + LARGE)
+def test_build_save_query_bit_exact(name, golden, tmp_path):
+    """insert -> identical arrays, stats, km.bin/rest.bin (sha256 of the REFERENCE's files) and kmer_to_occ."""
+    g = golden["cases"][name]
+    k, nb, km, cnt, m, o = _build_both(name)
+    st, so = m.stats(), o.stats()
+    assert (st.n_km, list(st.n_bf), st.km_byte_size, st.byte_km_back) == (so.n_km, list(so.n_bf), so.km_byte_size, so.byte_km_back)
+    _check_arrays(m, o, nb, st.bf_num)
+    assert (st.attempts, st.successes, st.rest_entries) == (so.attempts, so.successes, so.rest_entries)
+    assert st.attempts == g["stats"]["attempts"] and st.successes == g["stats"]["successes"]
+    d = str(tmp_path / "model")
+    os.makedirs(d)
+    m.save(d)
+    for f in ("header", "km.bin", "rest.bin"):
+        assert sha_file(os.path.join(d, f)) == g["sha256"][f], f
+    q = query_set(km, k)
+    occ = m.kmer_to_occ_packed(q)
+    assert np.array_equal(occ, o.query_packed(k, q))
+    assert sha_occ(occ) == g["occ_sha256"]
+    # reload what we saved and query again (load path)
+    m2 = KModel.load(d)
+    assert np.array_equal(m2.kmer_to_occ_packed(q), occ)
+    m.close(); m2.close(); o.close()
+
+
+def test_load_reference_files_and_query_strings():
+    """get_model(dir) on files written by the reference itself + the vector<string> front door."""
+    d = os.path.join(ROOT, "tests", "golden", "tiny")
+    m = KModel.load(d)
+    qs = open(os.path.join(d, "queries.txt")).read().split()
+    exp = np.loadtxt(os.path.join(d, "occ.txt"), dtype=np.int32)
+    assert np.array_equal(np.array(m.kmer_to_occ(qs), dtype=np.int32), exp)
+    assert m.kmer_to_occ(qs[0]) == int(exp[0])
+
+
+def test_init_from_kmc_database(golden, tmp_path):
+    """KModel::init(db_file): our KMC listing reader + streamed host batches -> the reference's files."""
+    d = os.path.join(ROOT, "tests", "golden", "tiny")
+    m = KModel(1, 1023, 7, 5)
+    m.init(os.path.join(d, "db"))
+    out = str(tmp_path / "m")
+    os.makedirs(out)
+    m.save_model(out)
+    for f in ("header", "km.bin", "rest.bin"):
+        assert sha_file(os.path.join(out, f)) == sha_file(os.path.join(d, f)), f
+
+
+def test_streamed_ragged_batches_equal_one_shot():
+    """kmx_begin / insert_batch / finish with ragged (incl. empty) batches == one-shot build."""
+    name = "k31_ci2_200k"
+    _, k, ci, cs, nh, nb, n = CASE[name]
+    km, cnt = synth.make_stream(n, k, ci, cs)
+    o = O.OracleModel(ci, cs, nh, nb)
+    o.build(k, km, cnt)
+    m = KModel(ci, cs, nh, nb)
+    n_bf = [int((cnt == ci + i).sum()) for i in range(3)]
+    m.begin(k, n_bf, len(cnt))
+    cuts = [0, 1, 1, 7777, 7777 + 65536, 150000, len(cnt)]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        m.insert_batch(km[a:b], cnt[a:b])
+    m.finish()
+    _check_arrays(m, o, nb, 3)
+    assert m.stats().rest_entries == o.stats().rest_entries
+
+
+def test_heavy_collision_tiny_arrays():
+    """Tiny coupled arrays (L = 8*(N_km>>4)*nh bits): almost every k-mer is contended, so the ordered slow
+    path and the single-workgroup finisher decide the round.  Still bit-exact."""
+    k, ci, cs, nh, nb = 31, 1, 1023, 7, 5
+    for n in (40, 300, 3000):
+        km, cnt = synth.make_stream(n, k, ci, cs, seed_k=77)
+        cnt = np.maximum(cnt, 2).astype(np.uint32)          # everything into the coupled arrays
+        m = KModel(ci, cs, nh, nb)
+        m.build_packed(k, km, cnt)
+        o = O.OracleModel(ci, cs, nh, nb)
+        o.build(k, km, cnt)
+        _check_arrays(m, o, nb, 0)
+        st, so = m.stats(), o.stats()
+        assert (st.attempts, st.successes, st.rest_entries) == (so.attempts, so.successes, so.rest_entries)
+        q = np.concatenate([km, synth.revcomp(km, k)])
+        assert np.array_equal(m.kmer_to_occ_packed(q), o.query_packed(k, q))
+
+
+def test_error_behaviour():
+    m = KModel(1, 1023, 7, 5)
+    with pytest.raises(api.KmxError):
+        m.kmer_to_occ_packed(np.zeros(4, dtype=np.uint64))   # query before build
+    km, cnt = synth.make_stream(1000, 31, 1, 1023)
+    bad = cnt.copy()
+    bad[5] = 5000                                            # count > cs: the reference indexes out of bounds
+    with pytest.raises(api.KmxError):
+        m.build_packed(31, km, bad)
+    with pytest.raises(api.KmxError):
+        m.init("/nonexistent/db")                            # reference: message + exit(1)
+    with pytest.raises(api.KmxError):
+        KModel.load("/nonexistent/dir")
