@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- KModel insert + query throughput on MI355X (BASELINE.json metric), one JSON line on stdout.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one batch of synthetic input: one full KModel build
+(kmx_build_dev = pass-1 histogram + classification/Bloom insert + ordered coupled-array insert + rest build)
+of the configured stream, already resident in HBM.  Query steps (one batched kmer_to_occ over the query set)
+are timed in a second, separately bracketed region.  `value` is the insert rate (k-mers encoded per second,
+whole job); the query rate is reported beside it.
+
+Workload at N=1: BASELINE.json configs[1] -- synthetic 100 M distinct canonical 31-mers, nh=7 nb=5 ci=1
+cs=1023, D1 counts.  N>1: one independent stream + model per rank (weak scaling, no
+data-path collective).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+G = 32  # bytes per touched position (HBM access granule)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=100_000_000, help="k-mer draws per rank")
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--ci", type=int, default=1)
+    ap.add_argument("--cs", type=int, default=1023)
+    ap.add_argument("--nh", type=int, default=7)
+    ap.add_argument("--nb", type=int, default=5)
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="k-mers of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def sync_all(distributed):
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def cpu_baseline(a):
+    """The real reference (oracle/_ref, kind=reference) or the CPU oracle (kind=port) on a bounded sample of the
+    same workload, timed on this host's cores.  Never on the product path; reported, not a target."""
+    import oracle_lib as O
+    from common import query_set
+    from kmcex_amd import kmcdb, synth
+    n = a.cpu_sample
+    km, cnt = synth.make_stream(n, a.k, a.ci, a.cs)
+    q = query_set(km, a.k, max_present=min(len(km), 1_000_000))
+    ncpu = os.cpu_count() or 1
+    out = {"unit": "k-mers/s", "sample": f"{len(cnt)} synthetic {a.k}-mers (same generator, D1 counts), "
+           f"insert = KModel::init incl. both passes and rest build; query = {len(q)} k-mers"}
+    with tempfile.TemporaryDirectory(prefix="kmx_cpu_") as tmp:
+        if O.have_ref():
+            db = os.path.join(tmp, "db")
+            kmcdb.write_kmc1(db, km, cnt, a.k, a.ci, a.cs)
+            t_ins = O.ref_build(db, db + ".m", a.ci, a.cs, a.nh, a.nb)
+            O.ref_query(db + ".m", synth.to_strings(q, a.k), db, t_num=ncpu)
+            t_q = O.last_ref_query_seconds
+            out.update(kind="reference", cores=a.nb, query_cores=ncpu)
+        else:
+            m = O.OracleModel(a.ci, a.cs, a.nh, a.nb)
+            t0 = time.time()
+            m.build(a.k, km, cnt)
+            t_ins = time.time() - t0
+            t0 = time.time()
+            m.query_packed(a.k, q, threads=ncpu)
+            t_q = time.time() - t0
+            out.update(kind="port", cores=a.nb, query_cores=ncpu)
+    out["value"] = len(cnt) / t_ins
+    out["query_value"] = len(q) / t_q
+    out["host_cpus"] = ncpu
+    return out
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the KModel hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if distributed:
+        dist.init_process_group("nccl", device_id=dev)
+    from kmcex_amd import KModel, api, synth_torch
+
+    # ---- synthetic listing of this rank, resident in HBM
+    km, cnt = synth_torch.make_stream(a.n, a.k, a.ci, a.cs, dev, seed_k=1 + 1000003 * rank, seed_c=2 + 1000003 * rank)
+    n = km.numel()
+    g = torch.Generator(device=dev)
+    g.manual_seed(7 + rank)
+    nq = n
+    perm = torch.randperm(n, device=dev, generator=g)[:nq]
+    q = km[perm].clone()
+    q[: nq // 2] = synth_torch.revcomp(q[: nq // 2], a.k)
+    q = torch.cat([q, synth_torch.random_kmers(max(nq // 10, 10), a.k, 999 + rank, dev)])
+    out = torch.empty(q.numel(), dtype=torch.int32, device=dev)
+    del perm
+
+    m = KModel(a.ci, a.cs, a.nh, a.nb)
+    stream = torch.cuda.current_stream().cuda_stream
+    m.set_stream(stream)
+
+    def insert_step():
+        m.build_dev(a.k, km.data_ptr(), cnt.data_ptr(), n)
+
+    def query_step():
+        m.kmer_to_occ_dev(q.data_ptr(), q.numel(), out.data_ptr())
+
+    for _ in range(a.warmup):
+        insert_step()
+        query_step()
+    sync_all(distributed)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        insert_step()
+    sync_all(distributed)
+    t_ins = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        query_step()
+    sync_all(distributed)
+    t_q = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([t_ins, t_q], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_ins, t_q = tt.tolist()
+        nn = torch.tensor([n, q.numel()], dtype=torch.int64, device=dev)
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        n_all, nq_all = nn.tolist()
+    else:
+        n_all, nq_all = n, q.numel()
+    st = m.stats()
+
+    # ---- roofline leg: same steps again with HIP events around every launch of each kernel class
+    roof = None
+    extra = {}
+    if rank == 0 and not a.no_roofline:
+        m.set_profile(True)
+        m.kernel_times(reset=True)
+        for _ in range(a.steps):
+            insert_step()
+        for _ in range(a.steps):
+            query_step()
+        kt = m.kernel_times(reset=True)
+        m.set_profile(False)
+        A, S, nbf = st.attempts, st.successes, sum(st.n_bf)
+        W8 = 8 * ((a.k + 31) // 32) + 4
+        alg = {  # algorithmic bytes of ONE step per kernel class (SURVEY.md §8d formula, split by kernel)
+            "check_claim": G * A * a.nh + A * W8,
+            "verify_commit": G * (S * a.nh + 2 * S * (a.nh - 2)),
+            "classify": G * 2 * nbf * ((a.nh - 1) + (a.nh - 2)) + n * W8,
+        }
+        per_q = G * (a.nb * a.nh + (a.nh - 2) + 2 + 6) + W8      # §8d: ~48 touches per query
+        alg["query"] = q.numel() * per_q
+        total_insert_alg = alg["check_claim"] + alg["verify_commit"] + alg["classify"]
+        classes = {}
+        for name, v in kt.items():
+            if v["launches"]:
+                classes[name] = {"launches_per_step": v["launches"] / a.steps, "seconds_per_step": v["seconds"] / a.steps,
+                                 "avg_launch_us": v["seconds"] / v["launches"] * 1e6}
+                if name in alg:
+                    classes[name]["alg_GBps"] = alg[name] / (v["seconds"] / a.steps) / 1e9
+        dom = max((c for c in classes if c != "query"), key=lambda c: classes[c]["seconds_per_step"])
+        dv = kt[dom]
+        per_launch = alg.get(dom, 0) * a.steps / max(dv["launches"], 1)
+        ach = per_launch / (dv["seconds"] / max(dv["launches"], 1)) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                "traffic": None, "alg_bytes_per_launch": per_launch, "avg_launch_us": classes[dom]["avg_launch_us"],
+                "launches": dv["launches"]}
+        # the random-access ceiling of this chip for 8-byte touches over a footprint like the coupled arrays'
+        foot = max(int(st.km_byte_size) * 4 * a.nb, 1 << 26)
+        tg = api.microbench(0, foot, 1 << 27, 3)
+        ta = api.microbench(1, foot, 1 << 27, 3)
+        extra = {"kernel_classes": classes,
+                 "insert_alg_bytes_per_kmer": total_insert_alg / n,
+                 "insert_alg_GBps_whole_step": total_insert_alg / (t_ins / a.steps) / 1e9,
+                 "insert_frac_of_8TBps": total_insert_alg / (t_ins / a.steps) / 8e12,
+                 "query_alg_GBps": alg["query"] / (t_q / a.steps) / 1e9,
+                 "query_frac_of_8TBps": alg["query"] / (t_q / a.steps) / 8e12,
+                 "random_access_ceiling": {"footprint_bytes": foot, "gather_Gtouch_s": (1 << 27) / tg / 1e9,
+                                           "atomic_or_Gtouch_s": (1 << 27) / ta / 1e9,
+                                           "gather_GBps_at_32B": (1 << 27) * G / tg / 1e9,
+                                           "atomic_GBps_at_32B": (1 << 27) * G / ta / 1e9}}
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_sample > 0:
+        try:
+            cpu = cpu_baseline(a)
+        except Exception as e:  # noqa: BLE001
+            cpu = {"error": repr(e)}
+    if rank == 0:
+        line = {
+            "metric": "k-mers/s encoded (insert), k=31 nh=7; query rate and % of HBM roofline alongside",
+            "value": n_all * a.steps / t_ins, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": t_ins / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"synthetic {n} distinct canonical {a.k}-mers per GPU, D1 counts, insert then query "
+                                   f"({q.numel()} queries: all inserted k-mers shuffled, half reverse-complemented, +10% absent)",
+                       "k": a.k, "nh": a.nh, "nb": a.nb, "ci": a.ci, "cs": a.cs, "kmers_per_gpu": n,
+                       "parallelism": f"{world} independent model(s), one per GPU"},
+            "query_value": nq_all * a.steps / t_q, "query_ms_per_step": t_q / a.steps * 1e3,
+            "stats": {"n_km": st.n_km, "n_bf": list(st.n_bf)[: st.bf_num], "attempts": st.attempts, "successes": st.successes,
+                      "rest_entries": st.rest_entries, "fast_commits": st.fast_commits, "contended": st.contended,
+                      "finisher_iters": st.finisher_iters, "blocks": st.blocks, "rounds": st.rounds},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,6 +39,7 @@ ABI_SYMBOLS = [
     "kmx_begin", "kmx_insert_batch", "kmx_insert_batch_dev", "kmx_finish", "kmx_build_dev", "kmx_build_host",
     "kmx_query_packed", "kmx_query_packed_dev", "kmx_query_ascii", "kmx_save", "kmx_load", "kmx_get_stats",
     "kmx_download", "kmx_debug_hash", "kmx_debug_min_kmer", "kmx_occubin", "kmx_microbench", "kmx_last_build_seconds",
+    "kmx_set_profile", "kmx_get_kernel_times",
 ]
 
 _lib = None
@@ -85,6 +86,8 @@ def load_library():
     L.kmx_occubin.argtypes = [i32, i32, vp, vp]
     L.kmx_microbench.argtypes = [i32, u64, u64, i32, C.POINTER(C.c_double)]
     L.kmx_last_build_seconds.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.kmx_set_profile.argtypes = [vp, i32]
+    L.kmx_get_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), i32]
     _lib = L
     return L
 
@@ -188,8 +191,10 @@ class KModel:
 
     def kmer_to_occ_packed(self, kmers: np.ndarray) -> np.ndarray:
         kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
-        W = (self.stats().k + 31) // 32
-        n = kmers.size // W
+        k = self.stats().k
+        if k == 0:
+            raise KmxError(-4, "query before the model is built or loaded")
+        n = kmers.size // ((k + 31) // 32)
         out = np.zeros(n, dtype=np.int32)
         _chk(self.L.kmx_query_packed(self.h, kmers.ctypes.data, n, out.ctypes.data))
         return out
@@ -225,6 +230,17 @@ class KModel:
         w = C.c_uint64(0)
         _chk(self.L.kmx_download(self.h, self.DL[which], index, buf.ctypes.data, cap, C.byref(w)))
         return buf[:w.value].copy()
+
+    KERNEL_CLASSES = ["classify", "check_claim", "verify_commit", "slow_path", "reorder", "rest_append", "query"]
+
+    def set_profile(self, on: bool) -> None:
+        _chk(self.L.kmx_set_profile(self.h, int(on)))
+
+    def kernel_times(self, reset: bool = True) -> dict:
+        sec = (C.c_double * 7)()
+        cnt = (C.c_uint64 * 7)()
+        _chk(self.L.kmx_get_kernel_times(self.h, sec, cnt, int(reset)))
+        return {n: {"seconds": sec[i], "launches": int(cnt[i])} for i, n in enumerate(self.KERNEL_CLASSES)}
 
     def build_seconds(self) -> float:
         a, b = C.c_double(0), C.c_double(0)

@@ -58,6 +58,26 @@ template <int W> __device__ __forceinline__ bool bloom_check_pm(const Premixed<W
 	return ok;
 }
 
+// Wave-aggregated counters: one atomic per wave instead of one per lane (same-address atomics serialise).
+// Call from converged code; lanes that already returned simply do not take part in the ballot.
+__device__ __forceinline__ void wave_count_add(u64 *ctr, bool pred)
+{
+	const u64 mask = __ballot(pred);
+	if (!mask) return;
+	const int lane = threadIdx.x & 63;
+	if (lane == __ffsll((long long)mask) - 1) atomicAdd(ctr, (u64)__popcll(mask));
+}
+template <typename T> __device__ __forceinline__ T wave_append_slot(T *ctr, bool pred)
+{
+	const u64 mask = __ballot(pred);
+	if (!mask) return 0;
+	const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+	T base = 0;
+	if (lane == leader) base = atomicAdd(ctr, (T)__popcll(mask));
+	base = __shfl(base, leader, 64);
+	return base + (T)__popcll(mask & ((1ULL << lane) - 1));
+}
+
 __device__ __forceinline__ u64 cell_load_coherent(const u64 *p)
 {
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_load sc1: bypasses this CU's L1
@@ -98,16 +118,17 @@ template <int NHM> __device__ __forceinline__ bool touches_conflict(const ModelD
 
 // kmodel.hpp:611-618 + :548-550: set tag (and value) bits, then the (k-2)-mer goes into km_back
 template <int W, int NHM>
-__device__ __forceinline__ void commit_touches(const ModelDev &md, const Touches<NHM> &t, u32 bin, int a, const Aligned<W> &al)
+__device__ __forceinline__ void commit_touches(const ModelDev &md, const Touches<NHM> &t, u32 bin, int a, const Aligned<W> &al, int dbg = 0)
 {
 	u64 *cells = md.cells[a];
 #pragma unroll
 	for (int j = 0; j < NHM; j++)
-		if (j < md.nh) {
+		if (j < md.nh && !(dbg & 1)) {
 			u32 b = bit_in_cell(t.pos[j]);
 			if (!((t.cell[j] >> (16 + b)) & 1ULL))          // already tagged => already carries this value
 				atomicOr(cells + (t.pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
 		}
+	if (dbg & 2) return;
 	Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
 	bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
 }
@@ -237,6 +258,29 @@ template <int W> __global__ __launch_bounds__(256) void k_classify_scatter(Model
 		}
 }
 
+// Block-aggregated append: ONE global atomic per workgroup (same-address atomics serialise at ~11 ns each on
+// gfx950, so per-lane or even per-wave counters on a hot word dominate a kernel).  Every thread of the
+// workgroup must call it; s_cnt must have been zeroed and barriered.  Returns the global slot for pred lanes.
+__device__ __forceinline__ int block_append_slot(int *gctr, bool pred, int *s_cnt, int *s_base)
+{
+	const u64 mask = __ballot(pred);
+	const int lane = threadIdx.x & 63;
+	int wbase = 0;
+	if (lane == 0 && mask) wbase = atomicAdd(s_cnt, (int)__popcll(mask));
+	wbase = __shfl(wbase, 0, 64);
+	__syncthreads();
+	if (threadIdx.x == 0) *s_base = *s_cnt ? atomicAdd(gctr, *s_cnt) : 0;
+	__syncthreads();
+	return *s_base + wbase + (int)__popcll(mask & ((1ULL << lane) - 1));
+}
+__device__ __forceinline__ void block_count_add(u64 *gctr, bool pred, int *s_cnt)
+{
+	const u64 mask = __ballot(pred);
+	if ((threadIdx.x & 63) == 0 && mask) atomicAdd(s_cnt, (int)__popcll(mask));
+	__syncthreads();
+	if (threadIdx.x == 0 && *s_cnt) atomicAdd(gctr, (u64)*s_cnt);
+}
+
 // lists of a fresh block: identity permutation (kmodel.hpp:509-513 fills row-major in listing order)
 __global__ __launch_bounds__(256) void k_block_init(BlockDev bd, int nb, int pp, int n_in_block)
 {
@@ -246,15 +290,8 @@ __global__ __launch_bounds__(256) void k_block_init(BlockDev bd, int nb, int pp,
 		int lo = i * (int)KMX_BUCKET;
 		int ni = n_in_block - lo;
 		bd.n[i] = ni < 0 ? 0 : (ni > (int)KMX_BUCKET ? (int)KMX_BUCKET : ni);      // kmodel.hpp:521-525
+		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, nb)] = 0;
 	}
-}
-
-// reset the per-round counters
-__global__ void k_round_reset(BlockDev bd, int nb)
-{
-	int t = threadIdx.x;
-	if (t < KMX_NSLOW * nb) bd.Un[t] = 0;
-	if (t < nb) { bd.m[t] = 0; bd.h[t] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------ A: check + claim
@@ -287,48 +324,50 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_c
 // ------------------------------------------------------------------------------------------ B: verify + commit
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_verify_commit(ModelDev md, BlockDev bd, int t, int pp)
 {
+	__shared__ int s_cnt, s_base;
+	if (threadIdx.x == 0) s_cnt = 0;
+	__syncthreads();
 	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-	if (x >= bd.n[i]) return;
 	const u64 row = (u64)i * KMX_BUCKET;
-	if (bd.status[row + x] != SLOT_UNDECIDED) return;
-	const u32 idx = bd.list[pp][row + x];
-	u64 v[W];
-	load_kmer<W>(bd.kmers, row + idx, v);
-	const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
-	const int a = (i + t) % md.nb;
-	Aligned<W> al = left_align<W>(v, md.k);
-	Premixed<W> pm = premix_string<W>(al, md.gfull);
-	Touches<NHM> tc;
-	gather_touches<W, NHM, false>(md, pm, a, tc);
+	const bool active = x < bd.n[i] && bd.status[row + x] == SLOT_UNDECIDED;
 	bool contended = false;
+	if (active) {
+		const u32 idx = bd.list[pp][row + x];
+		u64 v[W];
+		load_kmer<W>(bd.kmers, row + idx, v);
+		const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+		const int a = (i + t) % md.nb;
+		Aligned<W> al = left_align<W>(v, md.k);
+		Premixed<W> pm = premix_string<W>(al, md.gfull);
+		Touches<NHM> tc;
+		gather_touches<W, NHM, false>(md, pm, a, tc);
 #pragma unroll
-	for (int j = 0; j < NHM; j++)
-		if (j < md.nh) {
-			u32 b = bit_in_cell(tc.pos[j]);
-			u32 want = (bin >> j) & 1u;
-			bool tagged = (tc.cell[j] >> (16 + b)) & 1ULL;
-			contended |= !tagged && ((tc.cell[j] >> (32 + 16 * (1 - want) + b)) & 1ULL);
+		for (int j = 0; j < NHM; j++)
+			if (j < md.nh) {
+				u32 b = bit_in_cell(tc.pos[j]);
+				u32 want = (bin >> j) & 1u;
+				bool tagged = (tc.cell[j] >> (16 + b)) & 1ULL;
+				contended |= !tagged && ((tc.cell[j] >> (32 + 16 * (1 - want) + b)) & 1ULL);
+			}
+		if (!contended) {
+			commit_touches<W, NHM>(md, tc, bin, a, al, bd.debug_flags);
+			bd.status[row + x] = SLOT_INSERTED;
 		}
-	if (!contended) {
-		commit_touches<W, NHM>(md, tc, bin, a, al);
-		bd.status[row + x] = SLOT_INSERTED;
-		atomicAdd(bd.stats + ST_SUCCESSES, 1ULL);
-		atomicAdd(bd.stats + ST_FAST, 1ULL);
-	} else {
-		int p = atomicAdd(bd.Un + i, 1);
-		bd.U[0][row + p] = (u32)x;
-		atomicAdd(bd.stats + ST_CONTENDED, 1ULL);
 	}
+	const int p = block_append_slot(bd.Un + UN_IDX(0, i, md.nb), contended, &s_cnt, &s_base);
+	if (contended) bd.U[0][row + p] = (u32)x;
 }
 
 // ------------------------------------------------------------------------------------------ S: ordered slow path
 __device__ __forceinline__ u64 resv_key(u64 epoch, u32 x) { return (epoch << 20) | (u64)(0xFFFFFu - x); }
 __device__ __forceinline__ u64 *resv_slot(const BlockDev &bd, int i, u64 pos) { return bd.R + (u64)i * KMX_RSIZE + (pos & (KMX_RSIZE - 1)); }
 
+// s == 0 also drops the claim bits of the contended k-mers: claims are read by verify_commit only, and fast-path
+// claims need no cleaning (their positions are tagged now; claims matter on untagged positions only).
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_reserve(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch)
 {
 	const int i = blockIdx.y, u = blockIdx.x * 256 + threadIdx.x;
-	if (u >= bd.Un[s * md.nb + i]) return;
+	if (u >= bd.Un[UN_IDX(s, i, md.nb)]) return;
 	const u64 row = (u64)i * KMX_BUCKET;
 	const u32 x = bd.U[s][row + u];
 	const u32 idx = bd.list[pp][row + x];
@@ -339,6 +378,15 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_reserve(
 	Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
 	Touches<NHM> tc;
 	gather_touches<W, NHM, false>(md, pm, a, tc);
+	if (s == 0) {
+		u64 *cells = md.cells[a];
+#pragma unroll
+		for (int j = 0; j < NHM; j++)
+			if (j < md.nh) {
+				const u64 cb = CELL_CLAIM((bin >> j) & 1u, bit_in_cell(tc.pos[j]));
+				if (tc.cell[j] & cb) atomicAnd(cells + (tc.pos[j] >> 4), ~cb);
+			}
+	}
 	if (touches_conflict<NHM>(md, tc, bin)) { bd.status[row + x] = SLOT_FAILED; return; }
 	const u64 key = resv_key(epoch, x);
 #pragma unroll
@@ -351,51 +399,59 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_reserve(
 
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch)
 {
+	__shared__ int s_cnt, s_base, s_succ;
+	if (threadIdx.x == 0) { s_cnt = 0; s_succ = 0; }
+	__syncthreads();
 	const int i = blockIdx.y, u = blockIdx.x * 256 + threadIdx.x;
-	if (u >= bd.Un[s * md.nb + i]) return;
 	const u64 row = (u64)i * KMX_BUCKET;
-	const u32 x = bd.U[s][row + u];
-	if (bd.status[row + x] != SLOT_UNDECIDED) return;
-	const u32 idx = bd.list[pp][row + x];
-	u64 v[W];
-	load_kmer<W>(bd.kmers, row + idx, v);
-	const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
-	const int a = (i + t) % md.nb;
-	Aligned<W> al = left_align<W>(v, md.k);
-	Premixed<W> pm = premix_string<W>(al, md.gfull);
-	Touches<NHM> tc;
-	gather_touches<W, NHM, false>(md, pm, a, tc);
-	const u64 key = resv_key(epoch, x);
-	// A position that another k-mer of this sub-round has tagged since the reserve pass was won by a smaller
-	// index (it held our common slot), so it must be re-checked like committed state; if it now conflicts we
-	// stay undecided and the next reserve pass marks us failed.
-	bool mine = !touches_conflict<NHM>(md, tc, bin);
+	bool mine = false, defer = false;
+	u32 x = 0;
+	if (u < bd.Un[UN_IDX(s, i, md.nb)]) {
+		x = bd.U[s][row + u];
+		if (bd.status[row + x] == SLOT_UNDECIDED) {
+			const u32 idx = bd.list[pp][row + x];
+			u64 v[W];
+			load_kmer<W>(bd.kmers, row + idx, v);
+			const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+			const int a = (i + t) % md.nb;
+			Aligned<W> al = left_align<W>(v, md.k);
+			Premixed<W> pm = premix_string<W>(al, md.gfull);
+			Touches<NHM> tc;
+			gather_touches<W, NHM, false>(md, pm, a, tc);
+			const u64 key = resv_key(epoch, x);
+			// A position that another k-mer of this sub-round has tagged since the reserve pass was won by a smaller
+			// index (it held our common slot), so it is re-checked like committed state; if it now conflicts we stay
+			// undecided and the next reserve pass marks us failed.
+			mine = !touches_conflict<NHM>(md, tc, bin);
 #pragma unroll
-	for (int j = 0; j < NHM; j++)
-		if (j < md.nh) {
-			u32 b = bit_in_cell(tc.pos[j]);
-			if (!((tc.cell[j] >> (16 + b)) & 1ULL)) mine &= (*resv_slot(bd, i, tc.pos[j]) == key);
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh) {
+					u32 b = bit_in_cell(tc.pos[j]);
+					if (!((tc.cell[j] >> (16 + b)) & 1ULL)) mine &= (*resv_slot(bd, i, tc.pos[j]) == key);
+				}
+			if (mine) {
+				commit_touches<W, NHM>(md, tc, bin, a, al);
+				bd.status[row + x] = SLOT_INSERTED;
+			}
+			defer = !mine;
 		}
-	if (mine) {
-		commit_touches<W, NHM>(md, tc, bin, a, al);
-		bd.status[row + x] = SLOT_INSERTED;
-		atomicAdd(bd.stats + ST_SUCCESSES, 1ULL);
-	} else {
-		int p = atomicAdd(bd.Un + (s + 1) * md.nb + i, 1);
-		bd.U[s + 1][row + p] = (u32)x;
 	}
+	const int p = block_append_slot(bd.Un + UN_IDX(s + 1, i, md.nb), defer, &s_cnt, &s_base);
+	if (defer) bd.U[s + 1][row + p] = x;
+	block_count_add(bd.stats + ST_SLOW_SUCC, mine, &s_succ);
 }
 
 // Finisher: ONE workgroup per list iterates reserve/resolve until its set is empty.  Every iteration
 // decides at least the smallest undecided index, so the loop ends after at most |U| iterations.
 template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch0)
 {
-	__shared__ int s_pending;
+	__shared__ int s_pending, s_succ;
 	const int i = blockIdx.x;
-	const int n = bd.Un[s * md.nb + i];
+	const int n = bd.Un[UN_IDX(s, i, md.nb)];
 	if (n == 0) return;
 	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;
+	if (threadIdx.x == 0) s_succ = 0;
 	u64 epoch = epoch0;
 	for (;; epoch++) {
 		if (threadIdx.x == 0) s_pending = 0;
@@ -425,7 +481,7 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 		const int pending = s_pending;
 		__syncthreads();
 		if (!pending) break;
-		if (threadIdx.x == 0) atomicAdd(bd.stats + ST_FIN_ITERS, 1ULL);
+		int succ = 0;
 		for (int u = threadIdx.x; u < n; u += 1024) {
 			const u32 x = bd.U[s][row + u];
 			if (bd.status[row + x] != SLOT_UNDECIDED) continue;
@@ -448,32 +504,16 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 			if (mine) {
 				commit_touches<W, NHM>(md, tc, bin, a, al);
 				bd.status[row + x] = SLOT_INSERTED;
-				atomicAdd(bd.stats + ST_SUCCESSES, 1ULL);
+				succ++;
 			}
 		}
+		if (succ) atomicAdd(&s_succ, succ);
 		__threadfence();
 		__syncthreads();
 	}
-}
-
-// Drop the claim bits of the contended k-mers once the round is decided (nobody reads claims any more);
-// fast-path claims need no cleaning: their positions are tagged now and claims only matter on untagged ones.
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_clear_claims(ModelDev md, BlockDev bd, int t, int pp)
-{
-	const int i = blockIdx.y, u = blockIdx.x * 256 + threadIdx.x;
-	if (u >= bd.Un[i]) return;
-	const u64 row = (u64)i * KMX_BUCKET;
-	const u32 x = bd.U[0][row + u];
-	const u32 idx = bd.list[pp][row + x];
-	u64 v[W];
-	load_kmer<W>(bd.kmers, row + idx, v);
-	const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
-	const int a = (i + t) % md.nb;
-	Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
-	u64 *cells = md.cells[a];
-	for (int j = 0; j < md.nh; j++) {
-		u64 pos = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(a * md.nh + j) & 127]), md.km_mod);
-		atomicAnd(cells + (pos >> 4), ~CELL_CLAIM((bin >> j) & 1u, bit_in_cell(pos)));
+	if (threadIdx.x == 0) {
+		atomicAdd(bd.stats + ST_FIN_ITERS, (u64)(epoch - epoch0));
+		if (s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)s_succ);
 	}
 }
 
@@ -494,7 +534,10 @@ __global__ __launch_bounds__(256) void k_reorder_count(BlockDev bd)
 	}
 	int tot;
 	block_excl_scan_256(c, s_tmp, &tot);
-	if (threadIdx.x == 0) bd.tile_cnt[i * KMX_NTILES + tile] = tot;
+	if (threadIdx.x == 0) {
+		bd.tile_cnt[i * KMX_NTILES + tile] = tot;
+		if (tile == 0) bd.h[i] = 0;
+	}
 }
 
 __global__ __launch_bounds__(256) void k_reorder_scatter(BlockDev bd, int pp)
@@ -538,36 +581,55 @@ __global__ __launch_bounds__(256) void k_reorder_scatter(BlockDev bd, int pp)
 	if (tile == 0 && threadIdx.x == 0) bd.m[i] = m;
 }
 
-__global__ __launch_bounds__(256) void k_reorder_fill(BlockDev bd, int pp)
+// also closes the round's books: successes = n - m, contended = |U0|; resets the U counters for the next round
+__global__ __launch_bounds__(256) void k_reorder_fill(BlockDev bd, int pp, int nb)
 {
 	const int i = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
 	const u64 row = (u64)i * KMX_BUCKET;
 	if (r < bd.h[i]) bd.list[pp ^ 1][row + bd.hpos[row + r]] = bd.sval[row + r];
-	if (r == 0) bd.n[i] = bd.m[i];
+	if (r == 0) {
+		const int n = bd.n[i], m = bd.m[i];
+		if (n > m) atomicAdd(bd.stats + ST_SUCCESSES, (u64)(n - m));
+		const int c = bd.Un[UN_IDX(0, i, nb)];
+		if (c) atomicAdd(bd.stats + ST_CONTENDED, (u64)c);
+		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, nb)] = 0;
+		bd.n[i] = m;
+	}
 }
 
 // survivors of the block go to the rest table (kmodel.hpp:567-571); slot 0 is remembered for the
 // stale-slot duplicate of the final block (quirk Q1)
 template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev bd, int pp, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts)
 {
+	__shared__ int s_cnt;
+	__shared__ unsigned long long s_base;
+	if (threadIdx.x == 0) s_cnt = 0;
+	__syncthreads();
 	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
 	const int n = bd.n[i];
 	if (x == 0 && n == 0) stale_counts[i] = 0;
-	if (x >= n) return;
+	const bool act = x < n;
+	const u64 mask = __ballot(act);
+	const int lane = threadIdx.x & 63;
+	int wbase = 0;
+	if (lane == 0 && mask) wbase = atomicAdd(&s_cnt, (int)__popcll(mask));
+	wbase = __shfl(wbase, 0, 64);
+	__syncthreads();
+	if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(rest_n, (unsigned long long)s_cnt) : 0ULL;
+	__syncthreads();
+	if (!act) return;
+	const u64 p = s_base + (u64)wbase + (u64)__popcll(mask & ((1ULL << lane) - 1));
 	const u64 row = (u64)i * KMX_BUCKET;
 	const u32 idx = bd.list[pp][row + x];
 	u64 v[W];
 	load_kmer<W>(bd.kmers, row + idx, v);
 	const int c = (int)bd.counts[row + idx];
-	u64 p = atomicAdd(rest_n, 1ULL);
 	store_kmer<W>(rest_kmers, p, v);
 	rest_counts[p] = c;
 	if (x == 0) { store_kmer<W>(stale_kmers, (u64)i, v); stale_counts[i] = c; }
 }
 
 // ------------------------------------------------------------------------------------------ query
-template <int W> struct QKmer { u64 v[W]; };
-
 template <int W> __device__ __forceinline__ u64 shr128_lo(const u64 *v, int s)   // low 64 bits of (value >> s)
 {
 	if (W == 1) return s >= 64 ? 0 : v[0] >> s;
@@ -813,6 +875,40 @@ __global__ __launch_bounds__(256) void k_micro_atomic_or(u64 *buf, u64 ncell, u6
 	}
 }
 
+__global__ __launch_bounds__(256) void k_micro_byte_store(unsigned char *buf, u64 nbytes, u64 n_lanes, u64 salt)
+{
+	u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_lanes) return;
+#pragma unroll
+	for (int j = 0; j < 8; j++) buf[splitmix(i * 8 + j + salt) % nbytes] = (unsigned char)(salt | 1);
+}
+__global__ __launch_bounds__(256) void k_micro_byte_gather(const unsigned char *buf, u64 nbytes, u64 n_lanes, u64 salt, u64 *sink)
+{
+	u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_lanes) return;
+	u32 acc = 0;
+#pragma unroll
+	for (int j = 0; j < 8; j++) acc += buf[splitmix(i * 8 + j + salt) % nbytes];
+	if (acc == 0x12345678u) *sink = acc;
+}
+__global__ __launch_bounds__(256) void k_micro_store8(u64 *buf, u64 ncell, u64 n_lanes, u64 salt)
+{
+	u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_lanes) return;
+#pragma unroll
+	for (int j = 0; j < 8; j++) buf[splitmix(i * 8 + j + salt) % ncell] = salt;
+}
+__global__ __launch_bounds__(256) void k_micro_atomic_or32(u32 *buf, u64 nword, u64 n_lanes, u64 salt)
+{
+	u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_lanes) return;
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		u64 r = splitmix(i * 8 + j + salt);
+		atomicOr(buf + r % nword, 1u << (r >> 59));
+	}
+}
+
 // ------------------------------------------------------------------------------------------ launchers
 namespace kmxk {
 
@@ -840,10 +936,12 @@ void histogram(const u32 *counts, u64 n, int ci, int cs, int bf_num, u64 *n_bf, 
 // returns the number of classification tiles
 int classify_tiles(u64 n) { return (int)((n + CLS_TILE - 1) / CLS_TILE); }
 
-void classify_count(const ModelDev &md, const u64 *kmers, const u32 *counts, u64 n, int *tile_cnt, int *tile_off, int *total, u64 *stats, hipStream_t st)
+void classify_count(const ModelDev &md, const u64 *kmers, const u32 *counts, u64 n, int *tile_cnt, int *tile_off, int *total, u64 *stats, hipStream_t st, KernelProf *prof)
 {
 	int tiles = classify_tiles(n);
+	KPROF_BEGIN(prof, KC_CLASSIFY, st);
 	DISPATCH_W(words(md), hipLaunchKernelGGL(k_classify_count<W>, dim3(tiles), dim3(256), 0, st, md, kmers, counts, n, tile_cnt, stats));
+	KPROF_END(prof, st);
 	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, (const int *)tile_cnt, tile_off, tiles, total);
 }
 
@@ -858,14 +956,18 @@ void block_init(const BlockDev &bd, int nb, int pp, int n_in_block, hipStream_t 
 	hipLaunchKernelGGL(k_block_init, dim3(KMX_BUCKET / 256, nb), dim3(256), 0, st, bd, nb, pp, n_in_block);
 }
 
-// one round t of one block: A, B, slow sub-rounds, finisher, claim cleanup, reorder.  `epoch` advances.
-void round(const ModelDev &md, const BlockDev &bd, int t, int pp, u64 *epoch, hipStream_t st)
+// one round t of one block: A, B, ordered slow sub-rounds, finisher, reorder.  `epoch` advances.
+void round(const ModelDev &md, const BlockDev &bd, int t, int pp, u64 *epoch, hipStream_t st, KernelProf *prof)
 {
 	const int nb = md.nb;
 	const dim3 grid(KMX_BUCKET / 256, nb), blk(256);
-	hipLaunchKernelGGL(k_round_reset, dim3(1), dim3(64), 0, st, bd, nb);
+	KPROF_BEGIN(prof, KC_CHECK_CLAIM, st);
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_claim<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
+	KPROF_END(prof, st);
+	KPROF_BEGIN(prof, KC_VERIFY_COMMIT, st);
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_verify_commit<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
+	KPROF_END(prof, st);
+	KPROF_BEGIN(prof, KC_SLOW, st);
 	for (int s = 0; s + 1 < KMX_NSLOW; s++) {
 		u64 e = (*epoch)++;
 		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_reserve<W, NHM>), grid, blk, 0, st, md, bd, t, pp, s, e));
@@ -874,10 +976,12 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, u64 *epoch, hi
 	u64 e0 = *epoch;
 	*epoch += (1ULL << 19);                                    // the finisher may use up to |U| <= 2^18 epochs
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb), dim3(1024), 0, st, md, bd, t, pp, KMX_NSLOW - 1, e0));
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_clear_claims<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
+	KPROF_END(prof, st);
+	KPROF_BEGIN(prof, KC_REORDER, st);
 	hipLaunchKernelGGL(k_reorder_count, dim3(KMX_NTILES, nb), dim3(256), 0, st, bd);
 	hipLaunchKernelGGL(k_reorder_scatter, dim3(KMX_NTILES, nb), dim3(256), 0, st, bd, pp);
-	hipLaunchKernelGGL(k_reorder_fill, dim3(KMX_BUCKET / 2 / 256, nb), dim3(256), 0, st, bd, pp);
+	hipLaunchKernelGGL(k_reorder_fill, dim3(KMX_BUCKET / 2 / 256, nb), dim3(256), 0, st, bd, pp, nb);
+	KPROF_END(prof, st);
 }
 
 void rest_append(const ModelDev &md, const BlockDev &bd, int pp, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, hipStream_t st)
@@ -885,10 +989,12 @@ void rest_append(const ModelDev &md, const BlockDev &bd, int pp, u64 *rest_kmers
 	DISPATCH_W(words(md), hipLaunchKernelGGL(k_rest_append<W>, dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, bd, pp, rest_kmers, rest_counts, rest_n, stale_kmers, stale_counts));
 }
 
-void query(const ModelDev &md, const u64 *kmers, u64 n, int *out, hipStream_t st)
+void query(const ModelDev &md, const u64 *kmers, u64 n, int *out, hipStream_t st, KernelProf *prof)
 {
 	if (!n) return;
+	KPROF_BEGIN(prof, KC_QUERY, st);
 	DISPATCH_W(words(md), hipLaunchKernelGGL(k_query<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, md, kmers, n, out));
+	KPROF_END(prof, st);
 }
 
 void cells_from_disk(const unsigned char *val, const unsigned char *tag, u64 nbytes, u64 *cells, u64 ncells, hipStream_t st)
@@ -915,7 +1021,11 @@ void micro(int mode, u64 *buf, u64 ncell, u64 n_lanes, u64 salt, u64 *sink, hipS
 {
 	dim3 grid((unsigned)((n_lanes + 255) / 256));
 	if (mode == 0) hipLaunchKernelGGL(k_micro_gather, grid, dim3(256), 0, st, (const u64 *)buf, ncell, n_lanes, salt, sink);
-	else hipLaunchKernelGGL(k_micro_atomic_or, grid, dim3(256), 0, st, buf, ncell, n_lanes, salt);
+	else if (mode == 1) hipLaunchKernelGGL(k_micro_atomic_or, grid, dim3(256), 0, st, buf, ncell, n_lanes, salt);
+	else if (mode == 2) hipLaunchKernelGGL(k_micro_byte_store, grid, dim3(256), 0, st, (unsigned char *)buf, ncell * 8, n_lanes, salt);
+	else if (mode == 3) hipLaunchKernelGGL(k_micro_byte_gather, grid, dim3(256), 0, st, (const unsigned char *)buf, ncell * 8, n_lanes, salt, sink);
+	else if (mode == 4) hipLaunchKernelGGL(k_micro_store8, grid, dim3(256), 0, st, buf, ncell, n_lanes, salt);
+	else hipLaunchKernelGGL(k_micro_atomic_or32, grid, dim3(256), 0, st, (u32 *)buf, ncell * 2, n_lanes, salt);
 }
 
 }   // namespace kmxk

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -17,17 +18,19 @@
 namespace kmxk {
 void histogram(const u32 *, u64, int, int, int, u64 *, u64 *, hipStream_t);
 int classify_tiles(u64 n);
-void classify_count(const ModelDev &, const u64 *, const u32 *, u64, int *, int *, int *, u64 *, hipStream_t);
+void classify_count(const ModelDev &, const u64 *, const u32 *, u64, int *, int *, int *, u64 *, hipStream_t, KernelProf *);
 void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int *, u64 *, u32 *, u64, hipStream_t);
 void block_init(const BlockDev &, int, int, int, hipStream_t);
-void round(const ModelDev &, const BlockDev &, int, int, u64 *, hipStream_t);
+void round(const ModelDev &, const BlockDev &, int, int, u64 *, hipStream_t, KernelProf *);
 void rest_append(const ModelDev &, const BlockDev &, int, u64 *, int *, unsigned long long *, u64 *, int *, hipStream_t);
-void query(const ModelDev &, const u64 *, u64, int *, hipStream_t);
+void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *);
 void cells_from_disk(const unsigned char *, const unsigned char *, u64, u64 *, u64, hipStream_t);
 void cells_to_disk(const u64 *, u64, u64, int, unsigned char *, hipStream_t);
 void debug_hash(int, const u64 *, u64, const u32 *, int, int, u64 *, hipStream_t);
 void debug_min_kmer(int, const u64 *, u64, u64 *, hipStream_t);
 void micro(int, u64 *, u64, u64, u64, u64 *, hipStream_t);
+hipError_t rest_sort(const u64 *, const int *, u64, int, int, u64 *, int *, hipStream_t);
+hipError_t rest_index(const u64 *, u64, int, int, int, int *, int *, u64 *, int *, hipStream_t);
 }   // namespace kmxk
 
 // ------------------------------------------------------------------------------------------ errors
@@ -107,9 +110,11 @@ struct RestTable {
 	u64 suff_bin_size = 0, entries = 0;
 	std::vector<int> hash2index, pre_buffer, count_bin;
 	std::vector<unsigned char> suffix_bin;
+	bool host_valid = false;       // the four on-disk arrays above are materialised (load, or lazily at save)
 	// device
-	int *d_h2i = nullptr, *d_pre = nullptr, *d_cnt = nullptr;
+	int *d_h2i = nullptr, *d_pre = nullptr, *d_cnt = nullptr;     // d_cnt: counts in sorted order
 	u64 *d_suf = nullptr;
+	u64 *d_sorted = nullptr;       // sorted k-mers [entries][W] (kept for save after a device build)
 };
 static int rest_prefix_len(int k) { for (int i = 7; i >= 3; i--) if ((k - i) % 4 == 0) return i; return 3; }   // rest.hpp:78-83
 
@@ -128,6 +133,7 @@ struct kmx_model {
 	u64 byte_bf[3] = {0, 0, 0}, byte_bf_back[3] = {0, 0, 0}, km_byte_size = 0, byte_km_back = 0, ncells = 0;
 	u32 *d_bf[3] = {nullptr, nullptr, nullptr}, *d_bf_back[3] = {nullptr, nullptr, nullptr}, *d_km_back = nullptr;
 	u64 *d_cells[KMX_MAX_NB] = {nullptr};
+	u64 cap_bf[3] = {0, 0, 0}, cap_bf_back[3] = {0, 0, 0}, cap_km_back = 0, cap_cells[KMX_MAX_NB] = {0};   // bytes allocated
 	RestTable rest;
 	ModelDev md;
 	// ---- build-time state
@@ -136,6 +142,9 @@ struct kmx_model {
 	u64 stg_n = 0, stg_cap = 0;
 	BlockDev bd;
 	void *d_block_scratch = nullptr;
+	u64 scratch_bytes = 0;
+	int scratch_nb = 0, scratch_W = 0;
+	int *h_groups = nullptr;                                   // pinned
 	u64 *d_rest_kmers = nullptr;
 	int *d_rest_counts = nullptr;
 	unsigned long long *d_rest_n = nullptr;
@@ -149,7 +158,43 @@ struct kmx_model {
 	u64 h_stats[ST_N] = {0};
 	double t_insert_kernels = 0, t_total = 0;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	// per-kernel-class timing (kmx_set_profile)
+	KernelProf prof;
+	std::vector<hipEvent_t> prof_events;
+	std::vector<int> prof_spans;
+	size_t prof_used = 0;
+	double kc_seconds[KC_N] = {0};
+	uint64_t kc_launches[KC_N] = {0};
 };
+
+static void prof_begin(KernelProf *p, int cls, hipStream_t st)
+{
+	auto *ev = (std::vector<hipEvent_t> *)p->events;
+	auto *sp = (std::vector<int> *)p->spans;
+	const size_t need = 2 * sp->size() + 2;
+	while (ev->size() < need) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ev->push_back(e); }
+	sp->push_back(cls);
+	hipEventRecord((*ev)[2 * sp->size() - 2], st);
+}
+static void prof_end(KernelProf *p, hipStream_t st)
+{
+	auto *ev = (std::vector<hipEvent_t> *)p->events;
+	auto *sp = (std::vector<int> *)p->spans;
+	if (sp->empty() || ev->size() < 2 * sp->size()) return;
+	hipEventRecord((*ev)[2 * sp->size() - 1], st);
+}
+// fold the recorded spans into kc_seconds / kc_launches (stream must be idle)
+static void prof_collect(kmx_model *m)
+{
+	for (size_t i = 0; i < m->prof_spans.size(); i++) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, m->prof_events[2 * i], m->prof_events[2 * i + 1]) == hipSuccess) {
+			m->kc_seconds[m->prof_spans[i]] += ms * 1e-3;
+			m->kc_launches[m->prof_spans[i]]++;
+		}
+	}
+	m->prof_spans.clear();
+}
 
 static const u64 kChunk = u64(1) << 23;                       // k-mers classified per pass of the front end
 
@@ -163,6 +208,19 @@ template <typename T> static int dalloc(T **p, u64 n_elems, bool zero, hipStream
 	return KMX_OK;
 }
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+// grow-only device buffer: reallocated only when `need` exceeds what is there (bench loops rebuild the same sizes)
+template <typename T> static int ensure(T **p, u64 *cap_bytes, u64 need_bytes, bool zero, hipStream_t st)
+{
+	if (!need_bytes) need_bytes = 16;
+	if (!*p || *cap_bytes < need_bytes) {
+		if (*p) { HIPCHK(hipStreamSynchronize(st)); hipFree(*p); *p = nullptr; }
+		HIPCHK(hipMalloc((void **)p, need_bytes));
+		*cap_bytes = need_bytes;
+	}
+	if (zero) HIPCHK(hipMemsetAsync(*p, 0, need_bytes, st));
+	return KMX_OK;
+}
 
 static void free_build_state(kmx_model *m)
 {
@@ -182,9 +240,9 @@ static void free_build_state(kmx_model *m)
 
 static void free_rest_dev(RestTable &r)
 {
-	hipFree(r.d_h2i); hipFree(r.d_pre); hipFree(r.d_cnt); hipFree(r.d_suf);
+	hipFree(r.d_h2i); hipFree(r.d_pre); hipFree(r.d_cnt); hipFree(r.d_suf); hipFree(r.d_sorted);
 	r.d_h2i = r.d_pre = r.d_cnt = nullptr;
-	r.d_suf = nullptr;
+	r.d_suf = r.d_sorted = nullptr;
 }
 
 static void free_arrays(kmx_model *m)
@@ -194,7 +252,9 @@ static void free_arrays(kmx_model *m)
 		m->d_bf[i] = m->d_bf_back[i] = nullptr;
 	}
 	hipFree(m->d_km_back); m->d_km_back = nullptr;
-	for (int a = 0; a < KMX_MAX_NB; a++) { hipFree(m->d_cells[a]); m->d_cells[a] = nullptr; }
+	for (int a = 0; a < KMX_MAX_NB; a++) { hipFree(m->d_cells[a]); m->d_cells[a] = nullptr; m->cap_cells[a] = 0; }
+	for (int i = 0; i < 3; i++) m->cap_bf[i] = m->cap_bf_back[i] = 0;
+	m->cap_km_back = 0;
 	free_rest_dev(m->rest);
 }
 
@@ -222,6 +282,7 @@ extern "C" int kmx_create(int ci, int cs, int nh, int nb, kmx_model **out)
 	HIPCHK(hipHostMalloc((void **)&m->h_total, 64));
 	HIPCHK(hipEventCreate(&m->ev0));
 	HIPCHK(hipEventCreate(&m->ev1));
+	m->prof.events = &m->prof_events; m->prof.spans = &m->prof_spans; m->prof.begin = prof_begin; m->prof.end = prof_end;
 	*out = m;
 	return KMX_OK;
 }
@@ -237,6 +298,7 @@ extern "C" int kmx_destroy(kmx_model *m)
 	if (m->h_total) hipHostFree(m->h_total);
 	if (m->ev0) hipEventDestroy(m->ev0);
 	if (m->ev1) hipEventDestroy(m->ev1);
+	for (hipEvent_t e : m->prof_events) hipEventDestroy(e);
 	delete m;
 	return KMX_OK;
 }
@@ -284,13 +346,13 @@ static void fill_model_dev(kmx_model *m)
 
 static int alloc_arrays(kmx_model *m)
 {
-	free_arrays(m);
+	free_rest_dev(m->rest);
 	for (int i = 0; i < m->bf_num; i++) {
-		TRY(dalloc(&m->d_bf[i], (m->byte_bf[i] + 3) / 4 + 1, true, m->stream));
-		TRY(dalloc(&m->d_bf_back[i], (m->byte_bf_back[i] + 3) / 4 + 1, true, m->stream));
+		TRY(ensure(&m->d_bf[i], &m->cap_bf[i], ((m->byte_bf[i] + 3) / 4 + 1) * 4, true, m->stream));
+		TRY(ensure(&m->d_bf_back[i], &m->cap_bf_back[i], ((m->byte_bf_back[i] + 3) / 4 + 1) * 4, true, m->stream));
 	}
-	TRY(dalloc(&m->d_km_back, (m->byte_km_back + 3) / 4 + 1, true, m->stream));
-	for (int a = 0; a < m->nb; a++) TRY(dalloc(&m->d_cells[a], m->ncells + 1, true, m->stream));
+	TRY(ensure(&m->d_km_back, &m->cap_km_back, ((m->byte_km_back + 3) / 4 + 1) * 4, true, m->stream));
+	for (int a = 0; a < m->nb; a++) TRY(ensure(&m->d_cells[a], &m->cap_cells[a], (m->ncells + 1) * 8, true, m->stream));
 	return KMX_OK;
 }
 
@@ -303,7 +365,6 @@ extern "C" int kmx_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n
 	u64 s = 0;
 	for (int i = 0; i < m->bf_num; i++) s += n_bf[i];
 	if (s > n_total) return fail(KMX_E_ARG, "n_bf exceeds n_total");
-	free_build_state(m);
 	m->k = k; m->W = (k + 31) / 32;
 	m->n_total = n_total;
 	for (int i = 0; i < 3; i++) m->n_bf[i] = i < m->bf_num ? n_bf[i] : 0;
@@ -313,44 +374,59 @@ extern "C" int kmx_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n
 	fill_model_dev(m);
 	const int nb = m->nb;
 	const u64 B = KMX_BUCKET, blk = (u64)nb * B;
-	// staging stream for coupled-array k-mers: one front-end chunk plus one block of carry-over
-	m->stg_cap = kChunk + blk;
-	TRY(dalloc(&m->d_stg_kmers, m->stg_cap * m->W, false, m->stream));
-	TRY(dalloc(&m->d_stg_counts, m->stg_cap, false, m->stream));
+	// Build-time buffers are kept across builds of the same shape (nb, W): only the counters are re-zeroed.
+	if (m->d_block_scratch && (m->scratch_nb != nb || m->scratch_W != m->W)) free_build_state(m);
+	if (!m->d_block_scratch) {
+		// staging stream for coupled-array k-mers: one front-end chunk plus one block of carry-over
+		m->stg_cap = kChunk + blk;
+		TRY(dalloc(&m->d_stg_kmers, m->stg_cap * m->W, false, m->stream));
+		TRY(dalloc(&m->d_stg_counts, m->stg_cap, false, m->stream));
+		// one slab for the block working set
+		u64 off = 0;
+		auto carve = [&](u64 bytes) { u64 o = off; off += (bytes + 255) & ~u64(255); return o; };
+		u64 o_list0 = carve(blk * 4), o_list1 = carve(blk * 4), o_n = carve(nb * 4), o_status = carve(blk);
+		u64 o_U[KMX_NSLOW];
+		for (int s2 = 0; s2 < KMX_NSLOW; s2++) o_U[s2] = carve(blk * 4);
+		u64 o_Un = carve((u64)KMX_NSLOW * nb * KMX_CTR_STRIDE * 4), o_R = carve((u64)nb * KMX_RSIZE * 8), o_tc = carve((u64)nb * KMX_NTILES * 4);
+		u64 o_m = carve(nb * 4), o_h = carve(nb * 4), o_hpos = carve(blk * 4), o_sval = carve(blk * 4);
+		HIPCHK(hipMalloc(&m->d_block_scratch, off));
+		HIPCHK(hipMemsetAsync(m->d_block_scratch, 0, off, m->stream));     // R starts at epoch 0; epochs only grow
+		m->scratch_bytes = off; m->scratch_nb = nb; m->scratch_W = m->W;
+		char *base = (char *)m->d_block_scratch;
+		BlockDev &bd = m->bd;
+		bd.kmers = nullptr; bd.counts = nullptr;
+		bd.list[0] = (u32 *)(base + o_list0); bd.list[1] = (u32 *)(base + o_list1);
+		bd.n = (int *)(base + o_n); bd.status = (unsigned char *)(base + o_status);
+		for (int s2 = 0; s2 < KMX_NSLOW; s2++) bd.U[s2] = (u32 *)(base + o_U[s2]);
+		bd.Un = (int *)(base + o_Un); bd.R = (u64 *)(base + o_R); bd.tile_cnt = (int *)(base + o_tc);
+		bd.m = (int *)(base + o_m); bd.h = (int *)(base + o_h); bd.hpos = (u32 *)(base + o_hpos); bd.sval = (u32 *)(base + o_sval);
+		bd.stats = m->d_stats;
+		bd.debug_flags = getenv("KMX_DEBUG_FLAGS") ? atoi(getenv("KMX_DEBUG_FLAGS")) : 0;
+		TRY(dalloc(&m->d_rest_n, 1, false, m->stream));
+		TRY(dalloc(&m->d_stale_kmers, (u64)nb * 2, false, m->stream));
+		TRY(dalloc(&m->d_stale_counts, (u64)nb, false, m->stream));
+		const int tiles = kmxk::classify_tiles(kChunk);
+		TRY(dalloc(&m->d_tile_cnt, (u64)tiles, false, m->stream));
+		TRY(dalloc(&m->d_tile_off, (u64)tiles, false, m->stream));
+		TRY(dalloc(&m->d_total, 4, true, m->stream));
+		m->rest_cap = 0;
+	}
 	m->stg_n = 0;
-	// one slab for the block working set
-	u64 off = 0;
-	auto carve = [&](u64 bytes) { u64 o = off; off += (bytes + 255) & ~u64(255); return o; };
-	u64 o_list0 = carve(blk * 4), o_list1 = carve(blk * 4), o_n = carve(nb * 4), o_status = carve(blk);
-	u64 o_U[KMX_NSLOW];
-	for (int s2 = 0; s2 < KMX_NSLOW; s2++) o_U[s2] = carve(blk * 4);
-	u64 o_Un = carve(KMX_NSLOW * nb * 4), o_R = carve((u64)nb * KMX_RSIZE * 8), o_tc = carve((u64)nb * KMX_NTILES * 4);
-	u64 o_m = carve(nb * 4), o_h = carve(nb * 4), o_hpos = carve(blk * 4), o_sval = carve(blk * 4);
-	HIPCHK(hipMalloc(&m->d_block_scratch, off));
-	HIPCHK(hipMemsetAsync(m->d_block_scratch, 0, off, m->stream));
-	char *base = (char *)m->d_block_scratch;
-	BlockDev &bd = m->bd;
-	bd.kmers = nullptr; bd.counts = nullptr;
-	bd.list[0] = (u32 *)(base + o_list0); bd.list[1] = (u32 *)(base + o_list1);
-	bd.n = (int *)(base + o_n); bd.status = (unsigned char *)(base + o_status);
-	for (int s2 = 0; s2 < KMX_NSLOW; s2++) bd.U[s2] = (u32 *)(base + o_U[s2]);
-	bd.Un = (int *)(base + o_Un); bd.R = (u64 *)(base + o_R); bd.tile_cnt = (int *)(base + o_tc);
-	bd.m = (int *)(base + o_m); bd.h = (int *)(base + o_h); bd.hpos = (u32 *)(base + o_hpos); bd.sval = (u32 *)(base + o_sval);
-	bd.stats = m->d_stats;
 	// rest accumulators: grown on demand (see ensure_rest_capacity)
-	m->rest_cap = std::max<u64>(m->n_km / 8, 2 * blk) + blk;
-	TRY(dalloc(&m->d_rest_kmers, m->rest_cap * m->W, false, m->stream));
-	TRY(dalloc(&m->d_rest_counts, m->rest_cap, false, m->stream));
-	TRY(dalloc(&m->d_rest_n, 1, true, m->stream));
+	const u64 want_rest = std::max<u64>(m->n_km / 8, 2 * blk) + blk;
+	if (m->rest_cap < want_rest) {
+		hipFree(m->d_rest_kmers); hipFree(m->d_rest_counts);
+		m->d_rest_kmers = nullptr; m->d_rest_counts = nullptr;
+		TRY(dalloc(&m->d_rest_kmers, want_rest * m->W, false, m->stream));
+		TRY(dalloc(&m->d_rest_counts, want_rest, false, m->stream));
+		m->rest_cap = want_rest;
+	}
 	m->rest_upper = 0;
-	TRY(dalloc(&m->d_stale_kmers, (u64)nb * 2, true, m->stream));
-	TRY(dalloc(&m->d_stale_counts, (u64)nb, true, m->stream));
-	const int tiles = kmxk::classify_tiles(kChunk);
-	TRY(dalloc(&m->d_tile_cnt, (u64)tiles, false, m->stream));
-	TRY(dalloc(&m->d_tile_off, (u64)tiles, false, m->stream));
-	TRY(dalloc(&m->d_total, 4, true, m->stream));
+	HIPCHK(hipMemsetAsync(m->d_rest_n, 0, 8, m->stream));
+	HIPCHK(hipMemsetAsync(m->d_stale_kmers, 0, (u64)nb * 16, m->stream));
+	HIPCHK(hipMemsetAsync(m->d_stale_counts, 0, (u64)nb * 4, m->stream));
 	HIPCHK(hipMemsetAsync(m->d_stats, 0, ST_N * 8, m->stream));
-	m->epoch = 1; m->blocks = 0; m->rounds = 0;
+	m->blocks = 0; m->rounds = 0;
 	m->t_insert_kernels = 0; m->t_total = 0;
 	memset(m->h_stats, 0, sizeof m->h_stats);
 	m->state = ST_BUILDING;
@@ -402,7 +478,7 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 	int pp = 0;
 	kmxk::block_init(m->bd, nb, pp, (int)n_in_block, m->stream);
 	for (int t = 0; t < nb; t++) {
-		kmxk::round(m->md, m->bd, t, pp, &m->epoch, m->stream);
+		kmxk::round(m->md, m->bd, t, pp, &m->epoch, m->stream, &m->prof);
 		pp ^= 1;
 		m->rounds++;
 	}
@@ -429,7 +505,7 @@ extern "C" int kmx_insert_batch_dev(kmx_model *m, const uint64_t *d_kmers, const
 		const u64 c = std::min<u64>(kChunk, n - done);
 		const u64 *km = (const u64 *)d_kmers + done * m->W;
 		const u32 *ct = (const u32 *)d_counts + done;
-		kmxk::classify_count(m->md, km, ct, c, m->d_tile_cnt, m->d_tile_off, m->d_total, m->d_stats, m->stream);
+		kmxk::classify_count(m->md, km, ct, c, m->d_tile_cnt, m->d_tile_off, m->d_total, m->d_stats, m->stream, &m->prof);
 		HIPCHK(hipMemcpyAsync(m->h_total, m->d_total, 4, hipMemcpyDeviceToHost, m->stream));
 		HIPCHK(hipStreamSynchronize(m->stream));
 		const u64 add = (u64)*m->h_total;
@@ -478,69 +554,71 @@ extern "C" int kmx_insert_batch(kmx_model *m, const uint64_t *kmers, const uint3
 	return rc;
 }
 
-// KRestData::build (rest.hpp:95-135,157-161) from the survivors accumulated on the device; uploads the
-// device form for queries.  Host side: the table is small (a few % of the k-mers).
-static int rest_to_device(kmx_model *m, const std::vector<RestEnt> *sorted);
+// KRestData::build (rest.hpp:95-135,157-161) on the device: radix sort of the survivors + index kernels
+// (rest_device.hip).  The on-disk byte arrays are produced lazily by rest_materialize_host (save only).
+static int rest_to_device(kmx_model *m);
 
-static int build_rest(kmx_model *m)
+static int build_rest(kmx_model *m, u64 n)
 {
 	RestTable &r = m->rest;
 	free_rest_dev(r);
-	unsigned long long n = 0;
-	HIPCHK(hipMemcpyAsync(&n, m->d_rest_n, 8, hipMemcpyDeviceToHost, m->stream));
-	HIPCHK(hipStreamSynchronize(m->stream));
 	const int W = m->W, k = m->k;
-	std::vector<u64> hk(n * W);
-	std::vector<int> hc(n);
-	if (n) {
-		HIPCHK(hipMemcpy(hk.data(), m->d_rest_kmers, n * W * 8, hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(hc.data(), m->d_rest_counts, n * 4, hipMemcpyDeviceToHost));
-	}
-	std::vector<RestEnt> v(n);
-	for (u64 i = 0; i < n; i++) {
-		v[i].w[0] = W == 2 ? hk[2 * i] : 0;
-		v[i].w[1] = W == 2 ? hk[2 * i + 1] : hk[i];
-		v[i].c = hc[i];
-	}
-	std::sort(v.begin(), v.end(), [](const RestEnt &a, const RestEnt &b) { return a.w[0] != b.w[0] ? a.w[0] < b.w[0] : a.w[1] < b.w[1]; });
 	r.k = k;
 	r.pre_len = rest_prefix_len(k);
 	r.map_size = 1 << (2 * r.pre_len);
 	r.suff_group = (k - r.pre_len) / 4;
 	r.entries = n;
 	r.suff_bin_size = n * (u64)r.suff_group;
-	r.hash2index.assign(r.map_size, -1);
-	r.pre_buffer.assign(1, 0);
-	r.suffix_bin.assign(r.suff_bin_size, 0);
-	r.count_bin.resize(n);
-	const int sbits = 2 * (k - r.pre_len);
-	long long prev = -1;
-	for (u64 e = 0; e < n; e++) {
-		unsigned __int128 val = ((unsigned __int128)v[e].w[0] << 64) | v[e].w[1];
-		long long pre = (long long)(u64)(val >> sbits);
-		if (pre != prev) { r.hash2index[pre] = (int)r.pre_buffer.size() - 1; r.pre_buffer.push_back(0); prev = pre; }
-		r.pre_buffer.back() = (int)(e + 1);
-		for (int g = 0; g < r.suff_group; g++)
-			r.suffix_bin[e * (u64)r.suff_group + g] = (unsigned char)(val >> (8 * (r.suff_group - 1 - g)));
-		r.count_bin[e] = v[e].c;
-	}
-	r.pre_buffer_size = (int)r.pre_buffer.size();
-	return rest_to_device(m, &v);
+	r.host_valid = false;
+	HIPCHK(hipMalloc((void **)&r.d_sorted, n * W * 8 + 16));
+	HIPCHK(hipMalloc((void **)&r.d_cnt, n * 4 + 16));
+	HIPCHK(hipMalloc((void **)&r.d_suf, n * W * 8 + 16));
+	HIPCHK(hipMalloc((void **)&r.d_h2i, (u64)r.map_size * 4));
+	HIPCHK(hipMalloc((void **)&r.d_pre, ((u64)r.map_size + 2) * 4));
+	HIPCHK(hipMemsetAsync(r.d_h2i, 0xFF, (u64)r.map_size * 4, m->stream));
+	HIPCHK(kmxk::rest_sort(m->d_rest_kmers, m->d_rest_counts, n, W, k, r.d_sorted, r.d_cnt, m->stream));
+	HIPCHK(kmxk::rest_index(r.d_sorted, n, W, k, r.pre_len, r.d_h2i, r.d_pre, r.d_suf, m->d_total, m->stream));
+	HIPCHK(hipMemcpyAsync(m->h_total, m->d_total, 4, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipStreamSynchronize(m->stream));
+	r.pre_buffer_size = *m->h_total + 1;
+	return KMX_OK;
 }
 
-// device form: suffix integers (W words per row) instead of byte rows
-static int rest_to_device(kmx_model *m, const std::vector<RestEnt> *sorted)
+// on-disk arrays of rest.bin (Appendix B.2) from the device-resident sorted table
+static int rest_materialize_host(kmx_model *m)
+{
+	RestTable &r = m->rest;
+	if (r.host_valid) return KMX_OK;
+	const u64 n = r.entries;
+	const int W = m->W;
+	std::vector<u64> km(n * W + 1);
+	r.hash2index.resize(r.map_size); r.pre_buffer.resize(r.pre_buffer_size); r.count_bin.resize(n);
+	HIPCHK(hipMemcpy(r.hash2index.data(), r.d_h2i, (u64)r.map_size * 4, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(r.pre_buffer.data(), r.d_pre, (u64)r.pre_buffer_size * 4, hipMemcpyDeviceToHost));
+	if (n) {
+		HIPCHK(hipMemcpy(km.data(), r.d_sorted, n * W * 8, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(r.count_bin.data(), r.d_cnt, n * 4, hipMemcpyDeviceToHost));
+	}
+	r.suffix_bin.assign(r.suff_bin_size, 0);
+	for (u64 e = 0; e < n; e++) {
+		unsigned __int128 val = W == 2 ? (((unsigned __int128)km[2 * e] << 64) | km[2 * e + 1]) : (unsigned __int128)km[e];
+		for (int g = 0; g < r.suff_group; g++)
+			r.suffix_bin[e * (u64)r.suff_group + g] = (unsigned char)(val >> (8 * (r.suff_group - 1 - g)));
+	}
+	r.host_valid = true;
+	return KMX_OK;
+}
+
+// load path: device form (suffix integers, W words per row) from the byte rows read from rest.bin
+static int rest_to_device(kmx_model *m)
 {
 	RestTable &r = m->rest;
 	const int W = m->W;
 	const u64 n = r.entries;
 	std::vector<u64> suf(n * W + 1, 0);
-	const int sbits = 8 * r.suff_group;
 	for (u64 e = 0; e < n; e++) {
 		unsigned __int128 val = 0;
-		if (sorted) val = ((unsigned __int128)(*sorted)[e].w[0] << 64) | (*sorted)[e].w[1];
-		else for (int g = 0; g < r.suff_group; g++) val = (val << 8) | r.suffix_bin[e * (u64)r.suff_group + g];
-		if (sbits < 128) val &= (((unsigned __int128)1) << sbits) - 1;
+		for (int g = 0; g < r.suff_group; g++) val = (val << 8) | r.suffix_bin[e * (u64)r.suff_group + g];
 		if (W == 1) suf[e] = (u64)val;
 		else { suf[2 * e] = (u64)(val >> 64); suf[2 * e + 1] = (u64)val; }
 	}
@@ -552,6 +630,7 @@ static int rest_to_device(kmx_model *m, const std::vector<RestEnt> *sorted)
 	HIPCHK(hipMemcpy(r.d_pre, r.pre_buffer.data(), (u64)r.pre_buffer_size * 4, hipMemcpyHostToDevice));
 	if (n) HIPCHK(hipMemcpy(r.d_cnt, r.count_bin.data(), n * 4, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(r.d_suf, suf.data(), suf.size() * 8, hipMemcpyHostToDevice));
+	r.host_valid = true;
 	return KMX_OK;
 }
 
@@ -562,14 +641,16 @@ extern "C" int kmx_finish(kmx_model *m)
 	HIPCHK(hipSetDevice(m->device));
 	if (m->stg_n) TRY(process_block(m, 0, m->stg_n, true));   // push_last_to_array; an empty tail is skipped (divergence D1)
 	m->stg_n = 0;
+	unsigned long long n_rest = 0;
 	HIPCHK(hipMemcpyAsync(m->h_stats, m->d_stats, ST_N * 8, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipMemcpyAsync(&n_rest, m->d_rest_n, 8, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipStreamSynchronize(m->stream));
 	if (m->h_stats[ST_BAD_COUNT]) {
 		m->state = ST_EMPTY;
 		return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)m->h_stats[ST_BAD_COUNT], m->ci, m->cs);
 	}
-	TRY(build_rest(m));
-	free_build_state(m);
+	if (m->prof.on) prof_collect(m);
+	TRY(build_rest(m, n_rest));
 	fill_model_dev(m);
 	m->state = ST_READY;
 	return KMX_OK;
@@ -666,7 +747,7 @@ extern "C" int kmx_query_packed_dev(kmx_model *m, const uint64_t *d_kmers, uint6
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (m->state != ST_READY) return fail(KMX_E_STATE, "query before the model is built or loaded");
 	HIPCHK(hipSetDevice(m->device));
-	kmxk::query(m->md, (const u64 *)d_kmers, n, d_out, m->stream);
+	kmxk::query(m->md, (const u64 *)d_kmers, n, d_out, m->stream, &m->prof);
 	HIPCHK(hipGetLastError());
 	return KMX_OK;
 }
@@ -785,6 +866,7 @@ extern "C" int kmx_save(kmx_model *m, const char *dir)
 	}
 	fclose(f);
 	if (rc) return rc;
+	TRY(rest_materialize_host(m));
 	const RestTable &r = m->rest;
 	if (!(f = fopen((d + "/rest.bin").c_str(), "wb"))) return fail(KMX_E_IO, "cannot write %s/rest.bin", dir);
 	int h[4] = {r.k, r.pre_len, r.map_size, r.pre_buffer_size};
@@ -870,7 +952,7 @@ extern "C" int kmx_load(const char *dir, kmx_model **out)
 	}
 	fclose(f);
 	if (!ok) return bail(fail(KMX_E_IO, "short or unreadable %s/km.bin", dir));
-	rc = rest_to_device(m, nullptr);
+	rc = rest_to_device(m);
 	if (rc) return bail(rc);
 	fill_model_dev(m);
 	m->state = ST_READY;
@@ -885,7 +967,7 @@ extern "C" int kmx_get_stats(kmx_model *m, kmx_stats *st)
 	st->n_total = m->n_total; st->n_km = m->n_km;
 	for (int i = 0; i < 3; i++) { st->n_bf[i] = m->n_bf[i]; st->byte_bf[i] = m->byte_bf[i]; st->byte_bf_back[i] = m->byte_bf_back[i]; }
 	st->attempts = m->h_stats[ST_ATTEMPTS]; st->successes = m->h_stats[ST_SUCCESSES];
-	st->fast_commits = m->h_stats[ST_FAST]; st->contended = m->h_stats[ST_CONTENDED]; st->finisher_iters = m->h_stats[ST_FIN_ITERS];
+	st->fast_commits = m->h_stats[ST_SUCCESSES] - m->h_stats[ST_SLOW_SUCC]; st->contended = m->h_stats[ST_CONTENDED]; st->finisher_iters = m->h_stats[ST_FIN_ITERS];
 	st->rest_entries = m->rest.entries; st->km_byte_size = m->km_byte_size; st->byte_km_back = m->byte_km_back;
 	st->blocks = m->blocks; st->rounds = m->rounds;
 	st->k = m->k; st->ci = m->ci; st->cs = m->cs; st->nh = m->nh; st->nb = m->nb; st->bf_num = m->bf_num; st->device = m->device;
@@ -953,5 +1035,24 @@ extern "C" int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int it
 	*seconds = ms * 1e-3 / iters;
 	hipEventDestroy(e0); hipEventDestroy(e1);
 	hipFree(buf); hipFree(sink);
+	return KMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ kernel-class timing
+extern "C" int kmx_set_profile(kmx_model *m, int on)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	m->prof.on = on != 0;
+	return KMX_OK;
+}
+
+extern "C" int kmx_get_kernel_times(kmx_model *m, double *seconds, uint64_t *launches, int reset)
+{
+	if (!m || !seconds || !launches) return fail(KMX_E_ARG, "null argument");
+	HIPCHK(hipSetDevice(m->device));
+	HIPCHK(hipStreamSynchronize(m->stream));
+	prof_collect(m);
+	for (int c = 0; c < KC_N; c++) { seconds[c] = m->kc_seconds[c]; launches[c] = m->kc_launches[c]; }
+	if (reset) for (int c = 0; c < KC_N; c++) { m->kc_seconds[c] = 0; m->kc_launches[c] = 0; }
 	return KMX_OK;
 }

@@ -23,11 +23,13 @@ struct ModelDev {
 };
 
 // device-side statistics (one u64 each)
-enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_FAST, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_N };
+enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_N };
 
 #define KMX_RSIZE_LOG2 20
 #define KMX_RSIZE (1u << KMX_RSIZE_LOG2)      // reservation slots per list (ordered slow path)
-#define KMX_NSLOW 3                            // U lists: after the fast path, after slow sub-round 1, 2
+#define KMX_NSLOW 4                            // U lists: after the fast path and after each grid-wide slow sub-round
+#define KMX_CTR_STRIDE 32                      // ints between per-list counters: one 128-byte line each (same-line atomics serialise)
+#define UN_IDX(s, i, nb) ((((s) * (nb)) + (i)) * KMX_CTR_STRIDE)
 #define KMX_TILE 1024                          // slots per reorder tile
 #define KMX_NTILES (KMX_BUCKET / KMX_TILE)
 
@@ -39,7 +41,7 @@ struct BlockDev {
 	int *n;                  // [nb] current list lengths (buff_real_n, kmodel.hpp:277)
 	unsigned char *status;   // [nb*BUCKET] per slot: 0 undecided, 1 failed (survivor), 2 inserted
 	u32 *U[KMX_NSLOW];       // contended slot lists
-	int *Un;                 // [KMX_NSLOW*nb]
+	int *Un;                 // [KMX_NSLOW*nb*KMX_CTR_STRIDE], use UN_IDX
 	u64 *R;                  // [nb*KMX_RSIZE] epoch-tagged reservations
 	int *tile_cnt;           // [nb*NTILES]
 	int *m;                  // [nb] survivors of the round
@@ -47,6 +49,19 @@ struct BlockDev {
 	u32 *hpos;               // [nb*BUCKET] hole positions, left to right
 	u32 *sval;               // [nb*BUCKET] movers, right to left
 	u64 *stats;              // [ST_N]
+	int debug_flags;         // timing experiments only (results become wrong): 1 skip cell commits, 2 skip km_back inserts
 };
 
 enum { SLOT_UNDECIDED = 0, SLOT_FAILED = 1, SLOT_INSERTED = 2 };
+
+// Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
+enum { KC_CLASSIFY = 0, KC_CHECK_CLAIM, KC_VERIFY_COMMIT, KC_SLOW, KC_REORDER, KC_REST, KC_QUERY, KC_N };
+struct KernelProf {
+	bool on = false;
+	void *events = nullptr;      // std::vector<hipEvent_t>* owned by the host side
+	void *spans = nullptr;       // std::vector<int>* : class of span i uses events 2i, 2i+1
+	void (*begin)(KernelProf *, int cls, hipStream_t) = nullptr;
+	void (*end)(KernelProf *, hipStream_t) = nullptr;
+};
+#define KPROF_BEGIN(p, cls, st) do { if ((p) && (p)->on) (p)->begin((p), (cls), (st)); } while (0)
+#define KPROF_END(p, st) do { if ((p) && (p)->on) (p)->end((p), (st)); } while (0)

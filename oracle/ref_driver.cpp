@@ -30,7 +30,10 @@ int main(int argc, char **argv) {
 	std::string cmd = argv[1];
 	if (cmd == "build" && argc == 8) {
 		KModel *km = get_model(atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
+		auto t0 = std::chrono::high_resolution_clock::now();
 		km->init(argv[2]);
+		std::chrono::duration<double> dt = std::chrono::high_resolution_clock::now() - t0;
+		fprintf(stderr, "init_seconds %.6f\n", dt.count());
 		km->show_kmodel_info();
 		km->save(argv[3]);
 		return 0;

@@ -158,15 +158,27 @@ def have_ref() -> bool:
     return os.path.exists(REF_DRIVER)
 
 
-def ref_build(db_prefix: str, out_dir: str, ci: int, cs: int, nh: int, nb: int) -> None:
+def ref_build(db_prefix: str, out_dir: str, ci: int, cs: int, nh: int, nb: int) -> float:
+    """Runs the real reference build; returns the seconds KModel::init took (both passes + rest build)."""
     os.makedirs(out_dir, exist_ok=True)
-    subprocess.check_call([REF_DRIVER, "build", db_prefix, out_dir, str(ci), str(cs), str(nh), str(nb)],
-                          stdout=subprocess.DEVNULL)
+    p = subprocess.run([REF_DRIVER, "build", db_prefix, out_dir, str(ci), str(cs), str(nh), str(nb)],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True, text=True)
+    for line in p.stderr.splitlines():
+        if line.startswith("init_seconds"):
+            return float(line.split()[1])
+    return float("nan")
 
 
 def ref_query(model_dir: str, strs, tmp_prefix: str, t_num: int = 8) -> np.ndarray:
     with open(tmp_prefix + ".q.txt", "w") as f:
         f.write("\n".join(strs) + "\n")
-    subprocess.check_call([REF_DRIVER, "query", model_dir, tmp_prefix + ".q.txt", tmp_prefix + ".r.txt", str(t_num)],
-                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    p = subprocess.run([REF_DRIVER, "query", model_dir, tmp_prefix + ".q.txt", tmp_prefix + ".r.txt", str(t_num)],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True, text=True)
+    global last_ref_query_seconds
+    for line in p.stderr.splitlines():
+        if line.startswith("query_seconds"):
+            last_ref_query_seconds = float(line.split()[1])
     return np.loadtxt(tmp_prefix + ".r.txt", dtype=np.int32, ndmin=1)
+
+
+last_ref_query_seconds = float("nan")

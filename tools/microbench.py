@@ -8,8 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kmcex_amd import api
 
 res = []
-for mode, name in ((0, "gather8"), (1, "atomic_or8")):
-    for mb in (32, 128, 512, 2048, 8192):
+for mode, name in ((0, "gather8"), (1, "atomic_or8"), (2, "byte_store"), (3, "byte_gather"), (4, "store8"), (5, "atomic_or4")):
+    for mb in (32, 512, 2048, 8192):
         touches = 1 << 28
         s = api.microbench(mode, mb << 20, touches, 3)
         r = {"op": name, "footprint_MiB": mb, "touches": touches, "seconds": s, "Gtouch_per_s": touches / s / 1e9,
