@@ -93,9 +93,8 @@ def cpu_baseline(a):
 
 def main():
     a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from kmcex_amd import dist as kd
+    rank, local, world = kd.env_world()
     distributed = world > 1
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the KModel hot path has no CPU fallback")
@@ -106,7 +105,8 @@ def main():
     from kmcex_amd import KModel, api, synth_torch
 
     # ---- synthetic listing of this rank, resident in HBM
-    km, cnt = synth_torch.make_stream(a.n, a.k, a.ci, a.cs, dev, seed_k=1 + 1000003 * rank, seed_c=2 + 1000003 * rank)
+    seed_k, seed_c = kd.stream_seeds(rank)
+    km, cnt = synth_torch.make_stream(a.n, a.k, a.ci, a.cs, dev, seed_k=seed_k, seed_c=seed_c)
     n = km.numel()
     g = torch.Generator(device=dev)
     g.manual_seed(7 + rank)
@@ -142,15 +142,7 @@ def main():
         query_step()
     sync_all(distributed)
     t_q = time.perf_counter() - t0
-    if distributed:
-        tt = torch.tensor([t_ins, t_q], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_ins, t_q = tt.tolist()
-        nn = torch.tensor([n, q.numel()], dtype=torch.int64, device=dev)
-        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
-        n_all, nq_all = nn.tolist()
-    else:
-        n_all, nq_all = n, q.numel()
+    (t_ins, t_q), (n_all, nq_all) = kd.reduce_job([t_ins, t_q], [n, q.numel()], device=dev)   # MAX of times, SUM of units
     st = m.stats()
 
     # ---- roofline leg: same steps again with HIP events around every launch of each kernel class

@@ -1,0 +1,134 @@
+// include/kmodel.hpp -- drop-in C++ facade with the reference's own names over the C ABI (include/kmx.h).
+//
+// A program written against lzhLab/kmcEx's kmodel.hpp (README.md:64-93, main.cpp:143-149) compiles against
+// this header unchanged and links libkmx.so instead of pulling in the header-only CPU implementation:
+//
+//     KModel* km = get_model(ci, cs, n_hash, n_bit);      // kmodel.hpp:674
+//     km->init(kmc_database);                              // kmodel.hpp:57   (README: init_KModel)
+//     km->save(dir);                                       // kmodel.hpp:173  (README: save_model)
+//     KModel* km2 = get_model(dir);                        // kmodel.hpp:680
+//     std::vector<int> occ = km2->kmer_to_occ(kmers, 4);   // kmodel.hpp:90
+//
+// Error behaviour follows the reference: a message on stdout and exit(1) (kmodel.hpp:394-397, :682-685).
+// Unlike the reference the object has a destructor, so the device memory can be released.
+#pragma once
+#ifndef KMODEL_H
+#define KMODEL_H
+
+#include <cstdint>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "kmx.h"
+
+class KModel {
+public:
+	explicit KModel(kmx_model *h) : h_(h) {}
+	~KModel() { kmx_destroy(h_); }
+	KModel(const KModel &) = delete;
+	KModel &operator=(const KModel &) = delete;
+
+	// kmodel.hpp:57 -- two passes over the KMC listing, rest-table build
+	void init(std::string db_file) { check(kmx_build_from_kmc(h_, db_file.c_str())); }
+	void init_KModel(std::string db_file) { init(db_file); }                 // README.md:76
+
+	// kmodel.hpp:90 -- t_num is accepted for source compatibility; the batch runs on the GPU
+	std::vector<int> kmer_to_occ(std::vector<std::string> kmer_v, int t_num = 4)
+	{
+		(void)t_num;
+		const size_t n = kmer_v.size();
+		std::vector<int> occ_v(n);
+		if (!n) return occ_v;
+		const int len = (int)kmer_v[0].size();
+		std::string flat;
+		flat.reserve(n * (size_t)len);
+		for (size_t i = 0; i < n; i++) {
+			if ((int)kmer_v[i].size() != len) die("kmer_to_occ: all k-mers of a batch must have the same length");
+			flat += kmer_v[i];
+		}
+		static_assert(sizeof(int) == sizeof(int32_t), "int is 32 bits on every supported target");
+		check(kmx_query_ascii(h_, flat.data(), len, len, n, reinterpret_cast<int32_t *>(occ_v.data())));
+		return occ_v;
+	}
+
+	// kmodel.hpp:100
+	int kmer_to_occ(std::string kmer, uint32_t r_occ = 0)
+	{
+		(void)r_occ;
+		int32_t occ = 0;
+		check(kmx_query_ascii(h_, kmer.data(), (int)kmer.size(), (int)kmer.size(), 1, &occ));
+		return occ;
+	}
+
+	void save(std::string save_dir) { check(kmx_save(h_, save_dir.c_str())); }       // kmodel.hpp:173
+	void save_model(std::string save_dir) { save(save_dir); }                          // README.md:78
+
+	// kmodel.hpp:118, :127 -- same table, figures from kmx_get_stats
+	void show_header_info()
+	{
+		kmx_stats st;
+		kmx_get_stats(h_, &st);
+		std::cout << "KMCEX:" << std::endl;
+		std::cout << "   kmodel number hash                 :     " << st.nh << std::endl;
+		std::cout << "   kmodel bit array                   :     " << st.nb << std::endl;
+		std::cout << "   total kmercount                    :     " << st.n_total << std::endl;
+		std::cout << "   kmercount in blommfilter           :     " << st.n_total - st.n_km << std::endl;
+		std::cout << "   kmercount in kmodel                :     " << st.n_km << std::endl;
+	}
+	void show_kmodel_info()
+	{
+		kmx_stats st;
+		kmx_get_stats(h_, &st);
+		uint64_t bf = 0;
+		for (int i = 0; i < st.bf_num; i++) bf += st.byte_bf[i] + st.byte_bf_back[i];
+		const uint64_t km = 2 * st.km_byte_size * (uint64_t)st.nb, mb = 1024 * 1024;
+		double total_s = 0;
+		kmx_last_build_seconds(h_, nullptr, &total_s);
+		std::cout << "   kmercount hash map                 :     " << st.rest_entries << std::endl;
+		std::cout << "   memory bloomfilter                 :     " << bf / mb << "MB" << std::endl;
+		std::cout << "   memory bit array                   :     " << km / mb << "MB" << std::endl;
+		std::cout << "   total memory (without rest map)    :     " << (bf + km + st.byte_km_back) / mb << "MB" << std::endl;
+		std::cout << "   build time cost                    :     " << total_s << std::endl;
+	}
+
+	kmx_model *handle() { return h_; }
+
+private:
+	static void die(const char *msg)
+	{
+		std::cout << msg << std::endl;
+		std::exit(1);
+	}
+	static void check(int rc)
+	{
+		if (rc != KMX_OK) die(kmx_last_error());
+	}
+	kmx_model *h_;
+};
+
+// kmodel.hpp:674-677
+inline KModel *get_model(int ci = 1, int cs = 1023, int num_hash = 7, int num_bit = 5)
+{
+	kmx_model *h = nullptr;
+	if (kmx_create(ci, cs, num_hash, num_bit, &h) != KMX_OK) {
+		std::cout << kmx_last_error() << std::endl;
+		std::exit(1);
+	}
+	return new KModel(h);
+}
+
+// kmodel.hpp:680-696 (load_model in the README's vocabulary)
+inline KModel *get_model(std::string save_dir)
+{
+	kmx_model *h = nullptr;
+	if (kmx_load(save_dir.c_str(), &h) != KMX_OK) {
+		std::cout << kmx_last_error() << std::endl;
+		std::exit(1);
+	}
+	return new KModel(h);
+}
+inline KModel *load_model(std::string save_dir) { return get_model(save_dir); }
+
+#endif

@@ -65,6 +65,12 @@ int kmx_set_stream(kmx_model *m, void *hip_stream);
 /* KModel::init(db_file): two passes over the KMC listing + rest build      kmodel.hpp:57-86   */
 int kmx_build_from_kmc(kmx_model *m, const char *db_prefix);
 
+/* Host-only view of the KMC listing that init() consumes (CKMCFile::OpenForListing / ReadNextKmer / KmerCount /
+ * KmerLength, kmc_file.cpp:66-99, :428-515, :763, :740); needs no GPU.  kmx_kmc_read fills up to `capacity`
+ * k-mers (W words each) in listing order, already filtered by the header's [min_count, max_count].          */
+int kmx_kmc_info(const char *db_prefix, int *k, uint64_t *total_kmers);
+int kmx_kmc_read(const char *db_prefix, uint64_t *kmers, uint32_t *counts, uint64_t capacity, uint64_t *n_read);
+
 /* The same build, streamed.  begin = get_km_kmer_count's result + init_km_bit (kmodel.hpp:423-471):
  * n_bf[i] = number of k-mers with count ci+i (i < bf_num), n_total = KmerCount().                */
 int kmx_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total);

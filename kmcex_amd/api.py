@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "kmx_begin", "kmx_insert_batch", "kmx_insert_batch_dev", "kmx_finish", "kmx_build_dev", "kmx_build_host",
     "kmx_query_packed", "kmx_query_packed_dev", "kmx_query_ascii", "kmx_save", "kmx_load", "kmx_get_stats",
     "kmx_download", "kmx_debug_hash", "kmx_debug_min_kmer", "kmx_occubin", "kmx_microbench", "kmx_last_build_seconds",
-    "kmx_set_profile", "kmx_get_kernel_times",
+    "kmx_set_profile", "kmx_get_kernel_times", "kmx_kmc_info", "kmx_kmc_read",
 ]
 
 _lib = None
@@ -86,6 +86,8 @@ def load_library():
     L.kmx_occubin.argtypes = [i32, i32, vp, vp]
     L.kmx_microbench.argtypes = [i32, u64, u64, i32, C.POINTER(C.c_double)]
     L.kmx_last_build_seconds.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.kmx_kmc_info.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(u64)]
+    L.kmx_kmc_read.argtypes = [C.c_char_p, vp, vp, u64, C.POINTER(u64)]
     L.kmx_set_profile.argtypes = [vp, i32]
     L.kmx_get_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), i32]
     _lib = L
@@ -123,6 +125,20 @@ def debug_min_kmer(k: int, kmers: np.ndarray) -> np.ndarray:
     out = np.zeros_like(kmers)
     _chk(load_library().kmx_debug_min_kmer(k, kmers.ctypes.data, n, out.ctypes.data))
     return out
+
+
+def kmc_list(db_prefix: str):
+    """(k, total_kmers, kmers, counts) of a KMC database in listing order; host only."""
+    L = load_library()
+    k, total = C.c_int(0), C.c_uint64(0)
+    _chk(L.kmx_kmc_info(db_prefix.encode(), C.byref(k), C.byref(total)))
+    W = (k.value + 31) // 32
+    km = np.zeros(max(total.value, 1) * W, dtype=np.uint64)
+    cnt = np.zeros(max(total.value, 1), dtype=np.uint32)
+    n = C.c_uint64(0)
+    _chk(L.kmx_kmc_read(db_prefix.encode(), km.ctypes.data, cnt.ctypes.data, total.value, C.byref(n)))
+    km = km[: n.value * W]
+    return k.value, total.value, (km if W == 1 else km.reshape(-1, W)), cnt[: n.value]
 
 
 def microbench(mode: int, nbytes: int, touches: int, iters: int = 3) -> float:

@@ -741,6 +741,29 @@ extern "C" int kmx_build_from_kmc(kmx_model *m, const char *db_prefix)
 	return rc;
 }
 
+// ------------------------------------------------------------------------------------------ KMC listing (host only)
+extern "C" int kmx_kmc_info(const char *db_prefix, int *k, uint64_t *total_kmers)
+{
+	if (!db_prefix) return fail(KMX_E_ARG, "null argument");
+	kmx::KmcListing db;
+	if (!db.open(db_prefix)) return fail(KMX_E_IO, "can't open the kmer_data_base %s: %s", db_prefix, db.error().c_str());
+	if (k) *k = (int)db.kmer_length();
+	if (total_kmers) *total_kmers = db.kmer_count();
+	return KMX_OK;
+}
+
+extern "C" int kmx_kmc_read(const char *db_prefix, uint64_t *kmers, uint32_t *counts, uint64_t capacity, uint64_t *n_read)
+{
+	if (!db_prefix || !kmers || !counts || !n_read) return fail(KMX_E_ARG, "null argument");
+	kmx::KmcListing db;
+	if (!db.open(db_prefix)) return fail(KMX_E_IO, "can't open the kmer_data_base %s: %s", db_prefix, db.error().c_str());
+	const int W = db.words();
+	uint64_t n = 0;
+	for (size_t got; n < capacity && (got = db.next_batch(kmers + n * W, counts + n, (size_t)(capacity - n))) > 0;) n += got;
+	*n_read = n;
+	return KMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------ query
 extern "C" int kmx_query_packed_dev(kmx_model *m, const uint64_t *d_kmers, uint64_t n, int32_t *d_out)
 {

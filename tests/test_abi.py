@@ -1,0 +1,75 @@
+"""CPU: the C-ABI library loads, exports every symbol include/kmx.h declares, and fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from kmcex_amd import api, kmcdb, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "kmx.h")).read()
+    return sorted(set(re.findall(r"\b(kmx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_list_agree():
+    assert _declared() == sorted(api.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = api.load_library()
+    raw = ctypes.CDLL(api.lib_path())
+    for s in _declared():
+        assert hasattr(raw, s), s
+    assert L.kmx_last_error() is not None
+
+
+def test_occubin_host_table_matches_oracle():
+    import oracle_lib as O
+    for cs, nh in ((1023, 7), (4095, 9), (255, 7), (1023, 6)):
+        b, m = api.occubin(cs, nh)
+        ob, om = O.occubin_table(cs + 1, nh)
+        assert np.array_equal(b, ob) and np.array_equal(m, om)
+    with pytest.raises(api.KmxError):
+        api.occubin(63, 7)
+
+
+def test_kmc_reader_lists_what_the_writer_wrote(tmp_path):
+    """Our KMC listing reader (host C++, in libkmx.so) against the numpy KMC1 writer; no GPU involved."""
+    for k, ci, cs, n in ((31, 1, 1023, 30000), (55, 2, 4095, 5000), (21, 1, 255, 2000), (32, 1, 65535, 1000)):
+        km, cnt = synth.make_stream(n, k, ci, cs)
+        db = str(tmp_path / f"db{k}")
+        kmcdb.write_kmc1(db, km, cnt, k, ci, cs)
+        k2, total, okm, ocnt = api.kmc_list(db)
+        assert (k2, total) == (k, len(cnt))
+        assert np.array_equal(okm.reshape(km.shape), km) and np.array_equal(ocnt, cnt)
+    # counts outside [min_count, max_count] of the header are skipped, total_kmers is not (kmc_file.cpp:513, :763)
+    km, cnt = synth.make_stream(1000, 31, 1, 1023)
+    cnt2 = cnt.copy()
+    cnt2[::10] = 2000
+    db = str(tmp_path / "filtered")
+    kmcdb.write_kmc1(db, km, cnt2, 31, 1, 1023, counter_size=2)
+    _, total, okm, ocnt = api.kmc_list(db)
+    keep = cnt2 <= 1023
+    assert total == 1000 and np.array_equal(okm, km[keep]) and np.array_equal(ocnt, cnt2[keep])
+    with pytest.raises(api.KmxError):
+        api.kmc_list(str(tmp_path / "missing"))
+
+
+def test_tiny_golden_database_lists_in_order():
+    k, total, km, cnt = api.kmc_list(os.path.join(ROOT, "tests", "golden", "tiny", "db"))
+    assert k == 31 and total == len(cnt) == 20000
+    assert np.all(km[1:] > km[:-1])
+
+
+@pytest.mark.skipif(api.device_count() > 0, reason="this check is for machines without a GPU")
+def test_no_gpu_means_loud_failure_not_a_fallback():
+    with pytest.raises(api.KmxError) as e:
+        api.KModel(1, 1023, 7, 5)
+    assert e.value.code == -2
+    with pytest.raises(api.KmxError):
+        api.KModel.load(os.path.join(ROOT, "tests", "golden", "tiny"))
