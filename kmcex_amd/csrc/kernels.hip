@@ -20,6 +20,7 @@
 //                    single-workgroup finisher that iterates until the set is empty.
 //   R  reorder       the reference's unstable compaction (kmodel.hpp:529-540) as count/scatter/fill.
 #include "kmx_types.h"
+#include <cstdlib>
 
 __constant__ u32 c_seeds[128] = {   // tools.hpp:9 -- 128 consecutive primes (data)
 	46757, 46769, 46771, 46807, 46811, 46817, 46819, 46829, 46831, 46853, 46861, 46867, 46877, 46889, 46901, 46919,
@@ -48,7 +49,12 @@ template <int W> __device__ __forceinline__ void store_kmer(u64 *base, u64 i, co
 template <int W> __device__ __forceinline__ void bloom_insert_pm(const Premixed<W> &pm, const StrGeom g, u32 *bits, const ModU64 md, int nhash)
 {
 	if (!md.d) return;
-	for (int j = 0; j < nhash; j++) bloom_set(bits, mod_u64(murmur_seeded<W>(pm, g, c_seeds[j]), md));
+	for (int j = 0; j < nhash; j++) {
+		const u64 pos = mod_u64(murmur_seeded<W>(pm, g, c_seeds[j]), md);
+		// bits are only ever set, so a bit that reads 1 (even from a stale cache line) needs no atomic: late in a
+		// build most Bloom bits are already set and a load is 2-3x cheaper than a memory-side atomic
+		if (!bloom_get(bits, pos)) bloom_set(bits, pos);
+	}
 }
 template <int W> __device__ __forceinline__ bool bloom_check_pm(const Premixed<W> &pm, const StrGeom g, const u32 *bits, const ModU64 md, int nhash)
 {
@@ -281,15 +287,23 @@ __device__ __forceinline__ void block_count_add(u64 *gctr, bool pred, int *s_cnt
 	if (threadIdx.x == 0 && *s_cnt) atomicAdd(gctr, (u64)*s_cnt);
 }
 
+// slot x of list i -> index of its k-mer in buffer i, filling a pending hole of the last reorder on the way
+__device__ __forceinline__ u32 list_entry(const BlockDev &bd, int pp, u64 row, int x)
+{
+	u32 e = bd.list[pp][row + x];
+	return (e & LIST_HOLE) ? bd.mover[pp][row + (e & ~LIST_HOLE)] : e;
+}
+
 // lists of a fresh block: identity permutation (kmodel.hpp:509-513 fills row-major in listing order)
 __global__ __launch_bounds__(256) void k_block_init(BlockDev bd, int nb, int pp, int n_in_block)
 {
 	int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
 	bd.list[pp][(u64)i * KMX_BUCKET + x] = (u32)x;
+	if (x < KMX_NTILES) { bd.tile_cnt[0][i * KMX_NTILES + x] = 0; bd.tile_cnt[1][i * KMX_NTILES + x] = 0; }
 	if (x == 0) {
 		int lo = i * (int)KMX_BUCKET;
 		int ni = n_in_block - lo;
-		bd.n[i] = ni < 0 ? 0 : (ni > (int)KMX_BUCKET ? (int)KMX_BUCKET : ni);      // kmodel.hpp:521-525
+		bd.n[pp][i] = ni < 0 ? 0 : (ni > (int)KMX_BUCKET ? (int)KMX_BUCKET : ni);      // kmodel.hpp:521-525
 		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, nb)] = 0;
 	}
 }
@@ -297,45 +311,110 @@ __global__ __launch_bounds__(256) void k_block_init(BlockDev bd, int nb, int pp,
 // ------------------------------------------------------------------------------------------ A: check + claim
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_claim(ModelDev md, BlockDev bd, int t, int pp)
 {
+	__shared__ int s_fail;
+	if (threadIdx.x == 0) s_fail = 0;
+	__syncthreads();
 	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-	const int n = bd.n[i];
-	if (x >= n) return;
-	if (x == 0) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
+	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
-	const u32 idx = bd.list[pp][row + x];
-	u64 v[W];
-	load_kmer<W>(bd.kmers, row + idx, v);
-	const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
-	const int a = (i + t) % md.nb;                                  // kmodel.hpp:563
-	Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
-	Touches<NHM> tc;
-	gather_touches<W, NHM, false>(md, pm, a, tc);
-	if (touches_conflict<NHM>(md, tc, bin)) { bd.status[row + x] = SLOT_FAILED; return; }
-	bd.status[row + x] = SLOT_UNDECIDED;
-	u64 *cells = md.cells[a];
+	bool failed = false;
+	if (x < n) {
+		if (x == 0) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
+		const u32 raw = bd.list[pp][row + x];
+		const u32 idx = (raw & LIST_HOLE) ? bd.mover[pp][row + (raw & ~LIST_HOLE)] : raw;
+		if (raw & LIST_HOLE) bd.list[pp][row + x] = idx;            // later kernels of the round read plain entries
+		u64 v[W];
+		load_kmer<W>(bd.kmers, row + idx, v);
+		const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+		const int a = (i + t) % md.nb;                                  // kmodel.hpp:563
+		Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
+		Touches<NHM> tc;
+		gather_touches<W, NHM, false>(md, pm, a, tc);
+		failed = touches_conflict<NHM>(md, tc, bin);
+		bd.status[row + x] = failed ? SLOT_FAILED : SLOT_UNDECIDED;
+		if (!failed) {
+			u64 *cells = md.cells[a];
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh) {
+					u32 b = bit_in_cell(tc.pos[j]);
+					if (!((tc.cell[j] >> (16 + b)) & 1ULL)) atomicOr(cells + (tc.pos[j] >> 4), CELL_CLAIM((bin >> j) & 1u, b));
+				}
+		}
+	}
+	// survivors are counted per 1024-slot tile as they fail, so the reorder needs no counting pass
+	const u64 mask = __ballot(failed);
+	if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&s_fail, (int)__popcll(mask));
+	__syncthreads();
+	if (threadIdx.x == 0 && s_fail) atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (blockIdx.x >> 2), s_fail);
+}
+
+// ------------------------------------------------------------------------------------------ S: ordered slow path (helpers)
+__device__ __forceinline__ u64 resv_key(u64 epoch, u32 x) { return (epoch << 20) | (u64)(0xFFFFFu - x); }
+__device__ __forceinline__ u64 *resv_slot(const BlockDev &bd, int i, u64 pos) { return bd.R + (u64)i * KMX_RSIZE + (pos & (KMX_RSIZE - 1)); }
+__device__ __forceinline__ void mark_failed(const BlockDev &bd, int pp, int i, u64 row, u32 x)
+{
+	bd.status[row + x] = SLOT_FAILED;
+	atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (x >> 10), 1);      // contended k-mers only: rare
+}
+template <int NHM> __device__ __forceinline__ void reserve_untagged(const ModelDev &md, const BlockDev &bd, int i, const Touches<NHM> &tc, u64 key)
+{
 #pragma unroll
 	for (int j = 0; j < NHM; j++)
 		if (j < md.nh) {
 			u32 b = bit_in_cell(tc.pos[j]);
-			if (!((tc.cell[j] >> (16 + b)) & 1ULL)) atomicOr(cells + (tc.pos[j] >> 4), CELL_CLAIM((bin >> j) & 1u, b));
+			if (!((tc.cell[j] >> (16 + b)) & 1ULL)) atomicMax(resv_slot(bd, i, tc.pos[j]), key);
 		}
+}
+// drop this k-mer's claim bits (they are read by verify_commit only)
+template <int NHM> __device__ __forceinline__ void clear_claims(const ModelDev &md, int a, const Touches<NHM> &tc, u32 bin)
+{
+	u64 *cells = md.cells[a];
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if (j < md.nh) {
+			const u64 cb = CELL_CLAIM((bin >> j) & 1u, bit_in_cell(tc.pos[j]));
+			if (tc.cell[j] & cb) atomicAnd(cells + (tc.pos[j] >> 4), ~cb);
+		}
+}
+// A k-mer owns its outcome when it does not conflict with what is committed by now and holds the reservation of every
+// position that is still untagged.  (A position another k-mer of this pass has tagged meanwhile was won by a smaller
+// index -- it held our common slot -- so it is judged like committed state.)
+template <int NHM, bool COHERENT>
+__device__ __forceinline__ bool owns_outcome(const ModelDev &md, const BlockDev &bd, int i, const Touches<NHM> &tc, u32 bin, u64 key)
+{
+	bool mine = !touches_conflict<NHM>(md, tc, bin);
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if (j < md.nh) {
+			u32 b = bit_in_cell(tc.pos[j]);
+			if (!((tc.cell[j] >> (16 + b)) & 1ULL)) {
+				const u64 r = COHERENT ? cell_load_coherent(resv_slot(bd, i, tc.pos[j])) : *resv_slot(bd, i, tc.pos[j]);
+				mine &= (r == key);
+			}
+		}
+	return mine;
 }
 
 // ------------------------------------------------------------------------------------------ B: verify + commit
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_verify_commit(ModelDev md, BlockDev bd, int t, int pp)
+// Uncontended candidates commit.  Contended ones file a record in U[0] and place their reservations right away
+// (epoch `epoch`), which saves the first reserve pass of the ordered slow path; their claim bits must stay until
+// every verify_commit thread has read them, so they are dropped by the first slow kernel.
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_verify_commit(ModelDev md, BlockDev bd, int t, int pp, u64 epoch)
 {
 	__shared__ int s_cnt, s_base;
 	if (threadIdx.x == 0) s_cnt = 0;
 	__syncthreads();
 	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
 	const u64 row = (u64)i * KMX_BUCKET;
-	const bool active = x < bd.n[i] && bd.status[row + x] == SLOT_UNDECIDED;
+	const bool active = x < bd.n[pp][i] && bd.status[row + x] == SLOT_UNDECIDED;
 	bool contended = false;
+	u64 v[W];
+	u32 bin = 0;
 	if (active) {
 		const u32 idx = bd.list[pp][row + x];
-		u64 v[W];
 		load_kmer<W>(bd.kmers, row + idx, v);
-		const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+		bin = md.bin_of_occ[bd.counts[row + idx]];
 		const int a = (i + t) % md.nb;
 		Aligned<W> al = left_align<W>(v, md.k);
 		Premixed<W> pm = premix_string<W>(al, md.gfull);
@@ -352,156 +431,146 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_verify_
 		if (!contended) {
 			commit_touches<W, NHM>(md, tc, bin, a, al, bd.debug_flags);
 			bd.status[row + x] = SLOT_INSERTED;
-		}
+		} else reserve_untagged<NHM>(md, bd, i, tc, resv_key(epoch, (u32)x));
 	}
 	const int p = block_append_slot(bd.Un + UN_IDX(0, i, md.nb), contended, &s_cnt, &s_base);
-	if (contended) bd.U[0][row + p] = (u32)x;
+	if (contended) {
+		bd.U[0][row + p] = (u32)x;
+		bd.Ubin[0][row + p] = bin;
+		store_kmer<W>(bd.Ukm[0], row + p, v);
+	}
 }
 
 // ------------------------------------------------------------------------------------------ S: ordered slow path
-__device__ __forceinline__ u64 resv_key(u64 epoch, u32 x) { return (epoch << 20) | (u64)(0xFFFFFu - x); }
-__device__ __forceinline__ u64 *resv_slot(const BlockDev &bd, int i, u64 pos) { return bd.R + (u64)i * KMX_RSIZE + (pos & (KMX_RSIZE - 1)); }
-
-// s == 0 also drops the claim bits of the contended k-mers: claims are read by verify_commit only, and fast-path
-// claims need no cleaning (their positions are tagged now; claims matter on untagged positions only).
+// Grid-stride over the records of level s (the set is ~0.5 % of a round at 10^8 k-mers, most of it in round 0).
+#define SLOW_BLOCKS 64
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_reserve(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch)
 {
-	const int i = blockIdx.y, u = blockIdx.x * 256 + threadIdx.x;
-	if (u >= bd.Un[UN_IDX(s, i, md.nb)]) return;
+	const int i = blockIdx.y, lv = s & 1;
+	const int cnt = bd.Un[UN_IDX(lv, i, md.nb)];
 	const u64 row = (u64)i * KMX_BUCKET;
-	const u32 x = bd.U[s][row + u];
-	const u32 idx = bd.list[pp][row + x];
-	u64 v[W];
-	load_kmer<W>(bd.kmers, row + idx, v);
-	const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
 	const int a = (i + t) % md.nb;
-	Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
-	Touches<NHM> tc;
-	gather_touches<W, NHM, false>(md, pm, a, tc);
-	if (s == 0) {
-		u64 *cells = md.cells[a];
-#pragma unroll
-		for (int j = 0; j < NHM; j++)
-			if (j < md.nh) {
-				const u64 cb = CELL_CLAIM((bin >> j) & 1u, bit_in_cell(tc.pos[j]));
-				if (tc.cell[j] & cb) atomicAnd(cells + (tc.pos[j] >> 4), ~cb);
-			}
+	if (blockIdx.x == 0 && threadIdx.x == 0) bd.Un[UN_IDX(lv ^ 1, i, md.nb)] = 0;   // the other level was consumed by the previous pass
+	for (int u = blockIdx.x * 256 + threadIdx.x; u < cnt; u += SLOW_BLOCKS * 256) {
+		const u32 x = bd.U[lv][row + u], bin = bd.Ubin[lv][row + u];
+		u64 v[W];
+		load_kmer<W>(bd.Ukm[lv], row + u, v);
+		Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
+		Touches<NHM> tc;
+		gather_touches<W, NHM, false>(md, pm, a, tc);
+		if (touches_conflict<NHM>(md, tc, bin)) { mark_failed(bd, pp, i, row, x); continue; }
+		reserve_untagged<NHM>(md, bd, i, tc, resv_key(epoch, x));
 	}
-	if (touches_conflict<NHM>(md, tc, bin)) { bd.status[row + x] = SLOT_FAILED; return; }
-	const u64 key = resv_key(epoch, x);
-#pragma unroll
-	for (int j = 0; j < NHM; j++)
-		if (j < md.nh) {
-			u32 b = bit_in_cell(tc.pos[j]);
-			if (!((tc.cell[j] >> (16 + b)) & 1ULL)) atomicMax(resv_slot(bd, i, tc.pos[j]), key);
-		}
 }
 
+// resolve pass of level s: winners commit, the rest move to level s+1.  Level 0 holds verify_commit's reservations
+// and still carries the claim bits, which are dropped here.
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch)
 {
 	__shared__ int s_cnt, s_base, s_succ;
-	if (threadIdx.x == 0) { s_cnt = 0; s_succ = 0; }
-	__syncthreads();
-	const int i = blockIdx.y, u = blockIdx.x * 256 + threadIdx.x;
+	const int i = blockIdx.y, lv = s & 1;
+	const int cnt = bd.Un[UN_IDX(lv, i, md.nb)];
 	const u64 row = (u64)i * KMX_BUCKET;
-	bool mine = false, defer = false;
-	u32 x = 0;
-	if (u < bd.Un[UN_IDX(s, i, md.nb)]) {
-		x = bd.U[s][row + u];
-		if (bd.status[row + x] == SLOT_UNDECIDED) {
-			const u32 idx = bd.list[pp][row + x];
-			u64 v[W];
-			load_kmer<W>(bd.kmers, row + idx, v);
-			const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
-			const int a = (i + t) % md.nb;
-			Aligned<W> al = left_align<W>(v, md.k);
-			Premixed<W> pm = premix_string<W>(al, md.gfull);
-			Touches<NHM> tc;
-			gather_touches<W, NHM, false>(md, pm, a, tc);
-			const u64 key = resv_key(epoch, x);
-			// A position that another k-mer of this sub-round has tagged since the reserve pass was won by a smaller
-			// index (it held our common slot), so it is re-checked like committed state; if it now conflicts we stay
-			// undecided and the next reserve pass marks us failed.
-			mine = !touches_conflict<NHM>(md, tc, bin);
-#pragma unroll
-			for (int j = 0; j < NHM; j++)
-				if (j < md.nh) {
-					u32 b = bit_in_cell(tc.pos[j]);
-					if (!((tc.cell[j] >> (16 + b)) & 1ULL)) mine &= (*resv_slot(bd, i, tc.pos[j]) == key);
-				}
-			if (mine) {
-				commit_touches<W, NHM>(md, tc, bin, a, al);
-				bd.status[row + x] = SLOT_INSERTED;
-			}
-			defer = !mine;
-		}
+	const int a = (i + t) % md.nb;
+	if (threadIdx.x == 0) {
+		s_succ = 0;
+		if (s == 0 && blockIdx.x == 0 && cnt) { atomicAdd(bd.stats + ST_CONTENDED, (u64)cnt); atomicMax(bd.stats + ST_MAX_U0, (u64)cnt); }
 	}
-	const int p = block_append_slot(bd.Un + UN_IDX(s + 1, i, md.nb), defer, &s_cnt, &s_base);
-	if (defer) bd.U[s + 1][row + p] = x;
-	block_count_add(bd.stats + ST_SLOW_SUCC, mine, &s_succ);
+	for (int base = blockIdx.x * 256; base < cnt; base += SLOW_BLOCKS * 256) {      // uniform trip count per workgroup
+		if (threadIdx.x == 0) s_cnt = 0;
+		__syncthreads();
+		const int u = base + threadIdx.x;
+		bool mine = false, defer = false;
+		u32 x = 0, bin = 0;
+		u64 v[W];
+		if (u < cnt) {
+			x = bd.U[lv][row + u];
+			bin = bd.Ubin[lv][row + u];
+			load_kmer<W>(bd.Ukm[lv], row + u, v);
+			if (bd.status[row + x] == SLOT_UNDECIDED) {
+				Aligned<W> al = left_align<W>(v, md.k);
+				Premixed<W> pm = premix_string<W>(al, md.gfull);
+				Touches<NHM> tc;
+				gather_touches<W, NHM, false>(md, pm, a, tc);
+				if (s == 0) clear_claims<NHM>(md, a, tc, bin);
+				mine = owns_outcome<NHM, false>(md, bd, i, tc, bin, resv_key(epoch, x));
+				if (mine) {
+					commit_touches<W, NHM>(md, tc, bin, a, al);
+					bd.status[row + x] = SLOT_INSERTED;
+				}
+				defer = !mine;
+			}
+		}
+		const int p = block_append_slot(bd.Un + UN_IDX(lv ^ 1, i, md.nb), defer, &s_cnt, &s_base);
+		if (defer) {
+			bd.U[lv ^ 1][row + p] = x;
+			bd.Ubin[lv ^ 1][row + p] = bin;
+			store_kmer<W>(bd.Ukm[lv ^ 1], row + p, v);
+		}
+		const u64 mk = __ballot(mine);
+		if ((threadIdx.x & 63) == 0 && mk) atomicAdd(&s_succ, (int)__popcll(mk));
+		__syncthreads();
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)s_succ);
 }
 
-// Finisher: ONE workgroup per list iterates reserve/resolve until its set is empty.  Every iteration
-// decides at least the smallest undecided index, so the loop ends after at most |U| iterations.
-template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch0)
+// Finisher: ONE workgroup per list iterates reserve/resolve over level s until nothing is undecided.  Every
+// iteration decides at least the smallest undecided index, so the loop ends after at most |U| iterations.
+// s == 0 (no grid-wide pass ran): the first iteration resolves verify_commit's reservations (epoch_b) and drops the
+// claim bits; afterwards it reserves for itself with epochs epoch0, epoch0+1, ...
+template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch_b, u64 epoch0)
 {
 	__shared__ int s_pending, s_succ;
-	const int i = blockIdx.x;
-	const int n = bd.Un[UN_IDX(s, i, md.nb)];
+	const int i = blockIdx.x, lv = s & 1;
+	const int n = bd.Un[UN_IDX(lv, i, md.nb)];
 	if (n == 0) return;
 	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;
-	if (threadIdx.x == 0) s_succ = 0;
+	if (threadIdx.x == 0) {
+		s_succ = 0;
+		atomicMax(bd.stats + ST_MAX_UFIN, (u64)n);
+		if (s == 0) { atomicAdd(bd.stats + ST_CONTENDED, (u64)n); atomicMax(bd.stats + ST_MAX_U0, (u64)n); }
+	}
 	u64 epoch = epoch0;
-	for (;; epoch++) {
+	bool first = s == 0;
+	u64 iters = 0;
+	for (;; iters++) {
 		if (threadIdx.x == 0) s_pending = 0;
 		__syncthreads();
-		for (int u = threadIdx.x; u < n; u += 1024) {
-			const u32 x = bd.U[s][row + u];
-			if (bd.status[row + x] != SLOT_UNDECIDED) continue;
-			const u32 idx = bd.list[pp][row + x];
-			u64 v[W];
-			load_kmer<W>(bd.kmers, row + idx, v);
-			const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
-			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
-			Touches<NHM> tc;
-			gather_touches<W, NHM, true>(md, pm, a, tc);
-			if (touches_conflict<NHM>(md, tc, bin)) { bd.status[row + x] = SLOT_FAILED; continue; }
-			const u64 key = resv_key(epoch, x);
-#pragma unroll
-			for (int j = 0; j < NHM; j++)
-				if (j < md.nh) {
-					u32 b = bit_in_cell(tc.pos[j]);
-					if (!((tc.cell[j] >> (16 + b)) & 1ULL)) atomicMax(resv_slot(bd, i, tc.pos[j]), key);
-				}
-			s_pending = 1;
+		if (!first) {
+			for (int u = threadIdx.x; u < n; u += 1024) {
+				const u32 x = bd.U[lv][row + u];
+				if (bd.status[row + x] != SLOT_UNDECIDED) continue;
+				const u32 bin = bd.Ubin[lv][row + u];
+				u64 v[W];
+				load_kmer<W>(bd.Ukm[lv], row + u, v);
+				Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
+				Touches<NHM> tc;
+				gather_touches<W, NHM, true>(md, pm, a, tc);
+				if (touches_conflict<NHM>(md, tc, bin)) { mark_failed(bd, pp, i, row, x); continue; }
+				reserve_untagged<NHM>(md, bd, i, tc, resv_key(epoch, x));
+				s_pending = 1;
+			}
+			__threadfence();
+			__syncthreads();
+			const int pending = s_pending;
+			__syncthreads();
+			if (!pending) break;
 		}
-		__threadfence();
-		__syncthreads();
-		const int pending = s_pending;
-		__syncthreads();
-		if (!pending) break;
 		int succ = 0;
 		for (int u = threadIdx.x; u < n; u += 1024) {
-			const u32 x = bd.U[s][row + u];
+			const u32 x = bd.U[lv][row + u];
 			if (bd.status[row + x] != SLOT_UNDECIDED) continue;
-			const u32 idx = bd.list[pp][row + x];
+			const u32 bin = bd.Ubin[lv][row + u];
 			u64 v[W];
-			load_kmer<W>(bd.kmers, row + idx, v);
-			const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+			load_kmer<W>(bd.Ukm[lv], row + u, v);
 			Aligned<W> al = left_align<W>(v, md.k);
 			Premixed<W> pm = premix_string<W>(al, md.gfull);
 			Touches<NHM> tc;
 			gather_touches<W, NHM, true>(md, pm, a, tc);
-			const u64 key = resv_key(epoch, x);
-			bool mine = !touches_conflict<NHM>(md, tc, bin);     // see k_slow_resolve
-#pragma unroll
-			for (int j = 0; j < NHM; j++)
-				if (j < md.nh) {
-					u32 b = bit_in_cell(tc.pos[j]);
-					if (!((tc.cell[j] >> (16 + b)) & 1ULL)) mine &= (cell_load_coherent(resv_slot(bd, i, tc.pos[j])) == key);
-				}
-			if (mine) {
+			if (first) clear_claims<NHM>(md, a, tc, bin);
+			if (owns_outcome<NHM, true>(md, bd, i, tc, bin, resv_key(first ? epoch_b : epoch, x))) {
 				commit_touches<W, NHM>(md, tc, bin, a, al);
 				bd.status[row + x] = SLOT_INSERTED;
 				succ++;
@@ -510,45 +579,30 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 		if (succ) atomicAdd(&s_succ, succ);
 		__threadfence();
 		__syncthreads();
+		if (!first) epoch++;
+		first = false;
 	}
 	if (threadIdx.x == 0) {
-		atomicAdd(bd.stats + ST_FIN_ITERS, (u64)(epoch - epoch0));
+		atomicAdd(bd.stats + ST_FIN_ITERS, iters);
 		if (s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)s_succ);
 	}
 }
 
 // ------------------------------------------------------------------------------------------ R: reorder
-// reorder_buffer (kmodel.hpp:529-540): m survivors; survivors already below m stay; the i-th hole from
-// the left (below m) receives the i-th survivor from the right (at or above m).
-__global__ __launch_bounds__(256) void k_reorder_count(BlockDev bd)
-{
-	__shared__ int s_tmp[4];
-	const int i = blockIdx.y, tile = blockIdx.x;
-	const int n = bd.n[i];
-	const u64 row = (u64)i * KMX_BUCKET;
-	int c = 0;
-#pragma unroll
-	for (int q = 0; q < 4; q++) {
-		int x = tile * KMX_TILE + threadIdx.x * 4 + q;
-		c += (x < n && bd.status[row + x] == SLOT_FAILED) ? 1 : 0;
-	}
-	int tot;
-	block_excl_scan_256(c, s_tmp, &tot);
-	if (threadIdx.x == 0) {
-		bd.tile_cnt[i * KMX_NTILES + tile] = tot;
-		if (tile == 0) bd.h[i] = 0;
-	}
-}
-
-__global__ __launch_bounds__(256) void k_reorder_scatter(BlockDev bd, int pp)
+// reorder_buffer (kmodel.hpp:529-540): m survivors; survivors already below m stay; the i-th hole from the left
+// (below m) receives the i-th survivor from the right (at or above m).  ONE launch: the tile survivor counts were
+// accumulated while the slots failed; holes are written as (LIST_HOLE | rank) and filled lazily from mover[] by the
+// next round's check_claim (or by rest_append after the last round), so no grid-wide fill pass is needed.
+// Also closes the round's books: successes = n - m, contended = |U0|; resets the counters of the next round.
+__global__ __launch_bounds__(256) void k_reorder(BlockDev bd, int pp, int nb)
 {
 	__shared__ int s_tmp[4];
 	__shared__ int s_m, s_off;
 	const int i = blockIdx.y, tile = blockIdx.x;
-	const int n = bd.n[i];
+	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
 	{   // every workgroup scans the 256 tile counts of its list
-		int c = bd.tile_cnt[i * KMX_NTILES + threadIdx.x];
+		int c = bd.tile_cnt[pp][i * KMX_NTILES + threadIdx.x];
 		int tot;
 		int ex = block_excl_scan_256(c, s_tmp, &tot);
 		if ((int)threadIdx.x == tile) s_off = ex;
@@ -566,34 +620,21 @@ __global__ __launch_bounds__(256) void k_reorder_scatter(BlockDev bd, int pp)
 	int before = block_excl_scan_256(c, s_tmp, nullptr) + s_off;
 	const u32 *oldl = bd.list[pp] + row;
 	u32 *newl = bd.list[pp ^ 1] + row;
+	u32 *mv = bd.mover[pp ^ 1] + row;
 #pragma unroll
 	for (int q = 0; q < 4; q++) {
 		int x = tile * KMX_TILE + threadIdx.x * 4 + q;
-		if (x == m) bd.h[i] = m - before;                    // survivors at or above m == holes below m
 		if (x < n) {
-			if (x < m) {
-				if (f[q]) newl[x] = oldl[x];
-				else bd.hpos[row + (x - before)] = (u32)x;
-			} else if (f[q]) bd.sval[row + (m - before - 1)] = oldl[x];
+			if (x < m) newl[x] = f[q] ? oldl[x] : (LIST_HOLE | (u32)(x - before));     // hole number x-before, left to right
+			else if (f[q]) mv[m - before - 1] = oldl[x];                                // survivor number m-before-1 from the right
 		}
 		before += f[q];
 	}
-	if (tile == 0 && threadIdx.x == 0) bd.m[i] = m;
-}
-
-// also closes the round's books: successes = n - m, contended = |U0|; resets the U counters for the next round
-__global__ __launch_bounds__(256) void k_reorder_fill(BlockDev bd, int pp, int nb)
-{
-	const int i = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
-	const u64 row = (u64)i * KMX_BUCKET;
-	if (r < bd.h[i]) bd.list[pp ^ 1][row + bd.hpos[row + r]] = bd.sval[row + r];
-	if (r == 0) {
-		const int n = bd.n[i], m = bd.m[i];
+	bd.tile_cnt[pp ^ 1][i * KMX_NTILES + tile] = 0;                 // next round counts into the other buffer
+	if (tile == 0 && threadIdx.x == 0) {
 		if (n > m) atomicAdd(bd.stats + ST_SUCCESSES, (u64)(n - m));
-		const int c = bd.Un[UN_IDX(0, i, nb)];
-		if (c) atomicAdd(bd.stats + ST_CONTENDED, (u64)c);
 		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, nb)] = 0;
-		bd.n[i] = m;
+		bd.n[pp ^ 1][i] = m;
 	}
 }
 
@@ -606,7 +647,7 @@ template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev b
 	if (threadIdx.x == 0) s_cnt = 0;
 	__syncthreads();
 	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-	const int n = bd.n[i];
+	const int n = bd.n[pp][i];
 	if (x == 0 && n == 0) stale_counts[i] = 0;
 	const bool act = x < n;
 	const u64 mask = __ballot(act);
@@ -620,7 +661,7 @@ template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev b
 	if (!act) return;
 	const u64 p = s_base + (u64)wbase + (u64)__popcll(mask & ((1ULL << lane) - 1));
 	const u64 row = (u64)i * KMX_BUCKET;
-	const u32 idx = bd.list[pp][row + x];
+	const u32 idx = list_entry(bd, pp, row, x);
 	u64 v[W];
 	load_kmer<W>(bd.kmers, row + idx, v);
 	const int c = (int)bd.counts[row + idx];
@@ -956,31 +997,37 @@ void block_init(const BlockDev &bd, int nb, int pp, int n_in_block, hipStream_t 
 	hipLaunchKernelGGL(k_block_init, dim3(KMX_BUCKET / 256, nb), dim3(256), 0, st, bd, nb, pp, n_in_block);
 }
 
-// one round t of one block: A, B, ordered slow sub-rounds, finisher, reorder.  `epoch` advances.
-void round(const ModelDev &md, const BlockDev &bd, int t, int pp, u64 *epoch, hipStream_t st, KernelProf *prof)
+// one round t of one block: A, B, `nsub` grid-wide ordered sub-rounds, finisher, reorder.  `epoch` advances.
+// The single-workgroup finisher decides whatever the sub-rounds leave (everything when nsub == 0), so nsub only
+// trades launches for finisher iterations; the host picks it from the contention it has observed so far.
+void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 *epoch, hipStream_t st, KernelProf *prof)
 {
 	const int nb = md.nb;
-	const dim3 grid(KMX_BUCKET / 256, nb), blk(256);
+	if (nsub < 0) nsub = 0;
+	if (nsub > KMX_MAX_NSUB) nsub = KMX_MAX_NSUB;
+	const dim3 grid(KMX_BUCKET / 256, nb), blk(256), sgrid(SLOW_BLOCKS, nb);
 	KPROF_BEGIN(prof, KC_CHECK_CLAIM, st);
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_claim<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
 	KPROF_END(prof, st);
+	const u64 eb = (*epoch)++;                                 // verify_commit's reservations
 	KPROF_BEGIN(prof, KC_VERIFY_COMMIT, st);
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_verify_commit<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_verify_commit<W, NHM>), grid, blk, 0, st, md, bd, t, pp, eb));
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_SLOW, st);
-	for (int s = 0; s + 1 < KMX_NSLOW; s++) {
-		u64 e = (*epoch)++;
-		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_reserve<W, NHM>), grid, blk, 0, st, md, bd, t, pp, s, e));
-		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_resolve<W, NHM>), grid, blk, 0, st, md, bd, t, pp, s, e));
+	for (int s = 0; s < nsub; s++) {
+		u64 e = eb;
+		if (s > 0) {
+			e = (*epoch)++;
+			DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_reserve<W, NHM>), sgrid, blk, 0, st, md, bd, t, pp, s, e));
+		}
+		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_resolve<W, NHM>), sgrid, blk, 0, st, md, bd, t, pp, s, e));
 	}
-	u64 e0 = *epoch;
+	const u64 e0 = *epoch;
 	*epoch += (1ULL << 19);                                    // the finisher may use up to |U| <= 2^18 epochs
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb), dim3(1024), 0, st, md, bd, t, pp, KMX_NSLOW - 1, e0));
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb), dim3(1024), 0, st, md, bd, t, pp, nsub, eb, e0));
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_REORDER, st);
-	hipLaunchKernelGGL(k_reorder_count, dim3(KMX_NTILES, nb), dim3(256), 0, st, bd);
-	hipLaunchKernelGGL(k_reorder_scatter, dim3(KMX_NTILES, nb), dim3(256), 0, st, bd, pp);
-	hipLaunchKernelGGL(k_reorder_fill, dim3(KMX_BUCKET / 2 / 256, nb), dim3(256), 0, st, bd, pp, nb);
+	hipLaunchKernelGGL(k_reorder, dim3(KMX_NTILES, nb), dim3(256), 0, st, bd, pp, nb);
 	KPROF_END(prof, st);
 }
 

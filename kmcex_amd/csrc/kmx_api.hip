@@ -21,7 +21,7 @@ int classify_tiles(u64 n);
 void classify_count(const ModelDev &, const u64 *, const u32 *, u64, int *, int *, int *, u64 *, hipStream_t, KernelProf *);
 void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int *, u64 *, u32 *, u64, hipStream_t);
 void block_init(const BlockDev &, int, int, int, hipStream_t);
-void round(const ModelDev &, const BlockDev &, int, int, u64 *, hipStream_t, KernelProf *);
+void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, hipStream_t, KernelProf *);
 void rest_append(const ModelDev &, const BlockDev &, int, u64 *, int *, unsigned long long *, u64 *, int *, hipStream_t);
 void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *);
 void cells_from_disk(const unsigned char *, const unsigned char *, u64, u64 *, u64, hipStream_t);
@@ -154,7 +154,9 @@ struct kmx_model {
 	u64 *d_stats = nullptr, *d_nbf = nullptr;
 	int *d_tile_cnt = nullptr, *d_tile_off = nullptr, *d_total = nullptr;
 	int *h_total = nullptr;                                    // pinned
+	u64 *h_feedback = nullptr;                                 // pinned: ST_MAX_U0 as of some earlier block (heuristic input)
 	u64 epoch = 1, blocks = 0, rounds = 0;
+	int nsub = 1;                                              // grid-wide ordered passes in round 0 (see process_block)
 	u64 h_stats[ST_N] = {0};
 	double t_insert_kernels = 0, t_total = 0;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -280,6 +282,8 @@ extern "C" int kmx_create(int ci, int cs, int nh, int nb, kmx_model **out)
 	HIPCHK(hipMalloc((void **)&m->d_nbf, 3 * 8));
 	HIPCHK(hipMemset(m->d_stats, 0, ST_N * 8));
 	HIPCHK(hipHostMalloc((void **)&m->h_total, 64));
+	HIPCHK(hipHostMalloc((void **)&m->h_feedback, 64));
+	m->h_feedback[0] = ~0ULL; m->h_feedback[1] = 0;
 	HIPCHK(hipEventCreate(&m->ev0));
 	HIPCHK(hipEventCreate(&m->ev1));
 	m->prof.events = &m->prof_events; m->prof.spans = &m->prof_spans; m->prof.begin = prof_begin; m->prof.end = prof_end;
@@ -296,6 +300,7 @@ extern "C" int kmx_destroy(kmx_model *m)
 	free_arrays(m);
 	hipFree(m->d_bin_of_occ); hipFree(m->d_mean_of_bin); hipFree(m->d_stats); hipFree(m->d_nbf);
 	if (m->h_total) hipHostFree(m->h_total);
+	if (m->h_feedback) hipHostFree(m->h_feedback);
 	if (m->ev0) hipEventDestroy(m->ev0);
 	if (m->ev1) hipEventDestroy(m->ev1);
 	for (hipEvent_t e : m->prof_events) hipEventDestroy(e);
@@ -384,11 +389,13 @@ extern "C" int kmx_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n
 		// one slab for the block working set
 		u64 off = 0;
 		auto carve = [&](u64 bytes) { u64 o = off; off += (bytes + 255) & ~u64(255); return o; };
-		u64 o_list0 = carve(blk * 4), o_list1 = carve(blk * 4), o_n = carve(nb * 4), o_status = carve(blk);
+		u64 o_list0 = carve(blk * 4), o_list1 = carve(blk * 4), o_mv0 = carve(blk * 4), o_mv1 = carve(blk * 4);
+		u64 o_n0 = carve(nb * 4), o_n1 = carve(nb * 4), o_status = carve(blk);
 		u64 o_U[KMX_NSLOW];
-		for (int s2 = 0; s2 < KMX_NSLOW; s2++) o_U[s2] = carve(blk * 4);
-		u64 o_Un = carve((u64)KMX_NSLOW * nb * KMX_CTR_STRIDE * 4), o_R = carve((u64)nb * KMX_RSIZE * 8), o_tc = carve((u64)nb * KMX_NTILES * 4);
-		u64 o_m = carve(nb * 4), o_h = carve(nb * 4), o_hpos = carve(blk * 4), o_sval = carve(blk * 4);
+		u64 o_Ub[KMX_NSLOW], o_Uk[KMX_NSLOW];
+		for (int s2 = 0; s2 < KMX_NSLOW; s2++) { o_U[s2] = carve(blk * 4); o_Ub[s2] = carve(blk * 4); o_Uk[s2] = carve(blk * 8 * m->W); }
+		u64 o_Un = carve((u64)KMX_NSLOW * nb * KMX_CTR_STRIDE * 4), o_R = carve((u64)nb * KMX_RSIZE * 8);
+		u64 o_tc0 = carve((u64)nb * KMX_NTILES * 4), o_tc1 = carve((u64)nb * KMX_NTILES * 4);
 		HIPCHK(hipMalloc(&m->d_block_scratch, off));
 		HIPCHK(hipMemsetAsync(m->d_block_scratch, 0, off, m->stream));     // R starts at epoch 0; epochs only grow
 		m->scratch_bytes = off; m->scratch_nb = nb; m->scratch_W = m->W;
@@ -396,10 +403,11 @@ extern "C" int kmx_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n
 		BlockDev &bd = m->bd;
 		bd.kmers = nullptr; bd.counts = nullptr;
 		bd.list[0] = (u32 *)(base + o_list0); bd.list[1] = (u32 *)(base + o_list1);
-		bd.n = (int *)(base + o_n); bd.status = (unsigned char *)(base + o_status);
-		for (int s2 = 0; s2 < KMX_NSLOW; s2++) bd.U[s2] = (u32 *)(base + o_U[s2]);
-		bd.Un = (int *)(base + o_Un); bd.R = (u64 *)(base + o_R); bd.tile_cnt = (int *)(base + o_tc);
-		bd.m = (int *)(base + o_m); bd.h = (int *)(base + o_h); bd.hpos = (u32 *)(base + o_hpos); bd.sval = (u32 *)(base + o_sval);
+		bd.mover[0] = (u32 *)(base + o_mv0); bd.mover[1] = (u32 *)(base + o_mv1);
+		bd.n[0] = (int *)(base + o_n0); bd.n[1] = (int *)(base + o_n1); bd.status = (unsigned char *)(base + o_status);
+		for (int s2 = 0; s2 < KMX_NSLOW; s2++) { bd.U[s2] = (u32 *)(base + o_U[s2]); bd.Ubin[s2] = (u32 *)(base + o_Ub[s2]); bd.Ukm[s2] = (u64 *)(base + o_Uk[s2]); }
+		bd.Un = (int *)(base + o_Un); bd.R = (u64 *)(base + o_R);
+		bd.tile_cnt[0] = (int *)(base + o_tc0); bd.tile_cnt[1] = (int *)(base + o_tc1);
 		bd.stats = m->d_stats;
 		bd.debug_flags = getenv("KMX_DEBUG_FLAGS") ? atoi(getenv("KMX_DEBUG_FLAGS")) : 0;
 		TRY(dalloc(&m->d_rest_n, 1, false, m->stream));
@@ -427,6 +435,14 @@ extern "C" int kmx_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n
 	HIPCHK(hipMemsetAsync(m->d_stale_counts, 0, (u64)nb * 4, m->stream));
 	HIPCHK(hipMemsetAsync(m->d_stats, 0, ST_N * 8, m->stream));
 	m->blocks = 0; m->rounds = 0;
+	m->h_feedback[0] = ~0ULL; m->h_feedback[1] = 0;
+	{   // first guess of the contended set per list in round 0: a candidate is contended when one of its nh positions
+		// is also claimed with the other value by one of the ~2^18*nh/2 opposite claims spread over the L positions
+		const double L = (double)m->km_byte_size * 8.0;
+		const double p = L > 0 ? std::min(1.0, (double)m->nh * m->nh * 131072.0 / L) : 1.0;
+		const double u0 = 157000.0 * p;
+		m->nsub = u0 <= 4096 ? 0 : (u0 <= 16384 ? 2 : (u0 <= 49152 ? 5 : 8));
+	}
 	m->t_insert_kernels = 0; m->t_total = 0;
 	memset(m->h_stats, 0, sizeof m->h_stats);
 	m->state = ST_BUILDING;
@@ -477,11 +493,28 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 	m->bd.counts = m->d_stg_counts + head;
 	int pp = 0;
 	kmxk::block_init(m->bd, nb, pp, (int)n_in_block, m->stream);
+	// Contention feedback (pinned words copied back after every block, so they lag by a block or two; they steer a
+	// launch-count heuristic only, never the result): the largest contended set per list, and the largest set that
+	// reached the single-workgroup finisher.  Small sets are decided by the finisher alone; when too much reaches it,
+	// grid-wide ordered passes are added in front of it.
+	static const int force0 = getenv("KMX_NSUB0") ? atoi(getenv("KMX_NSUB0")) : -1;
+	static const int force1 = getenv("KMX_NSUB1") ? atoi(getenv("KMX_NSUB1")) : -1;
+	const u64 u0 = ((volatile u64 *)m->h_feedback)[0], ufin = ((volatile u64 *)m->h_feedback)[1];
+	if (u0 != ~0ULL) {
+		if (ufin > 2048) m->nsub = std::min(m->nsub + 2, KMX_MAX_NSUB);
+		else if (ufin < 256 && m->nsub > 0 && u0 <= 4096) m->nsub--;
+		else if (m->nsub == 0 && u0 > 4096) m->nsub = 1;
+	}
 	for (int t = 0; t < nb; t++) {
-		kmxk::round(m->md, m->bd, t, pp, &m->epoch, m->stream, &m->prof);
+		int nsub = t == 0 ? m->nsub : m->nsub / 2;
+		if (t == 0 && force0 >= 0) nsub = force0;
+		if (t > 0 && force1 >= 0) nsub = force1;
+		kmxk::round(m->md, m->bd, t, pp, nsub, &m->epoch, m->stream, &m->prof);
 		pp ^= 1;
 		m->rounds++;
 	}
+	HIPCHK(hipMemcpyAsync(m->h_feedback, m->d_stats + ST_MAX_U0, 16, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipMemsetAsync(m->d_stats + ST_MAX_U0, 0, 16, m->stream));
 	TRY(ensure_rest_capacity(m, n_in_block + (u64)nb));
 	if (final_partial) {
 		int row = (int)((n_in_block - 1) / KMX_BUCKET);

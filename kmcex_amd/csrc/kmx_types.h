@@ -23,11 +23,12 @@ struct ModelDev {
 };
 
 // device-side statistics (one u64 each)
-enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_N };
+enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_MAX_U0, ST_MAX_UFIN, ST_N };
 
 #define KMX_RSIZE_LOG2 20
 #define KMX_RSIZE (1u << KMX_RSIZE_LOG2)      // reservation slots per list (ordered slow path)
-#define KMX_NSLOW 4                            // U lists: after the fast path and after each grid-wide slow sub-round
+#define KMX_NSLOW 2                            // contended-record levels, ping-pong: pass s reads level s&1, defers to (s+1)&1
+#define KMX_MAX_NSUB 16                        // most grid-wide ordered passes per round
 #define KMX_CTR_STRIDE 32                      // ints between per-list counters: one 128-byte line each (same-line atomics serialise)
 #define UN_IDX(s, i, nb) ((((s) * (nb)) + (i)) * KMX_CTR_STRIDE)
 #define KMX_TILE 1024                          // slots per reorder tile
@@ -37,20 +38,25 @@ enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, 
 struct BlockDev {
 	const u64 *kmers;        // [nb*BUCKET][W] this block's k-mers in listing order (buffer i = slice i)
 	const u32 *counts;       // [nb*BUCKET]
-	u32 *list[2];            // ping-pong: list[pp][i*BUCKET + x] = index into buffer i of slot x
-	int *n;                  // [nb] current list lengths (buff_real_n, kmodel.hpp:277)
+	// Lists are index permutations, ping-pong by round parity pp.  An entry with bit 31 set is a hole of the last
+	// reorder that has not been filled yet: its value is mover[pp][entry & 0x7FFFFFFF] (resolved by check_claim).
+	u32 *list[2];            // list[pp][i*BUCKET + x] = index into buffer i of slot x
+	u32 *mover[2];           // mover[pp][i*BUCKET + r] = r-th survivor from the right of the previous round
+	int *n[2];               // n[pp][i] current list lengths (buff_real_n, kmodel.hpp:277)
+	int *tile_cnt[2];        // tile_cnt[pp][i*NTILES + tile] survivors (failed slots) per 1024-slot tile, counted as they fail
 	unsigned char *status;   // [nb*BUCKET] per slot: 0 undecided, 1 failed (survivor), 2 inserted
-	u32 *U[KMX_NSLOW];       // contended slot lists
+	// contended k-mers; level (s & 1) = still undecided after s grid-wide resolve passes.  A record carries what the ordered
+	// slow path needs (slot, bin, packed k-mer) so that its latency-bound kernels skip three dependent loads.
+	u32 *U[KMX_NSLOW];       // slot x in the list
+	u32 *Ubin[KMX_NSLOW];    // occurrence bin
+	u64 *Ukm[KMX_NSLOW];     // [..][W] packed k-mer
 	int *Un;                 // [KMX_NSLOW*nb*KMX_CTR_STRIDE], use UN_IDX
 	u64 *R;                  // [nb*KMX_RSIZE] epoch-tagged reservations
-	int *tile_cnt;           // [nb*NTILES]
-	int *m;                  // [nb] survivors of the round
-	int *h;                  // [nb] holes below m
-	u32 *hpos;               // [nb*BUCKET] hole positions, left to right
-	u32 *sval;               // [nb*BUCKET] movers, right to left
 	u64 *stats;              // [ST_N]
 	int debug_flags;         // timing experiments only (results become wrong): 1 skip cell commits, 2 skip km_back inserts
 };
+
+#define LIST_HOLE 0x80000000u
 
 enum { SLOT_UNDECIDED = 0, SLOT_FAILED = 1, SLOT_INSERTED = 2 };
 
