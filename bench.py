@@ -178,9 +178,19 @@ def main():
         dv = kt[dom]
         per_launch = alg.get(dom, 0) * a.steps / max(dv["launches"], 1)
         ach = per_launch / (dv["seconds"] / max(dv["launches"], 1)) / 1e9
+        # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+        # runs of this same command, tools/pmc_summary.py); only valid for the default workload they were taken on
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic_default_workload.json")
+        kname = {"check_claim": "k_round_check_claim", "verify_commit": "k_round_verify_commit", "classify": "k_classify_count"}.get(dom)
+        if a.n == 100_000_000 and (a.k, a.nh, a.nb, a.ci, a.cs) == (31, 7, 5, 1, 1023) and os.path.exists(pmc_file) and kname:
+            pm = json.load(open(pmc_file))
+            for kn, kv in pm["kernels"].items():
+                if kn.startswith(kname):
+                    traffic, traffic_src = kv["hbm_bytes_per_launch"], "profiles/pmc_traffic_default_workload.json"
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                "traffic": None, "alg_bytes_per_launch": per_launch, "avg_launch_us": classes[dom]["avg_launch_us"],
-                "launches": dv["launches"]}
+                "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": per_launch,
+                "avg_launch_us": classes[dom]["avg_launch_us"], "launches": dv["launches"]}
         # the random-access ceiling of this chip for 8-byte touches over a footprint like the coupled arrays'
         foot = max(int(st.km_byte_size) * 4 * a.nb, 1 << 26)
         tg = api.microbench(0, foot, 1 << 27, 3)

@@ -84,6 +84,9 @@ template <typename T> __device__ __forceinline__ T wave_append_slot(T *ctr, bool
 	return base + (T)__popcll(mask & ((1ULL << lane) - 1));
 }
 
+// wait until every vector-memory operation of this wave (loads, stores, atomics) has been acknowledged
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ u64 cell_load_coherent(const u64 *p)
 {
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_load sc1: bypasses this CU's L1
@@ -396,6 +399,23 @@ __device__ __forceinline__ bool owns_outcome(const ModelDev &md, const BlockDev 
 	return mine;
 }
 
+template <int W> __device__ __forceinline__ void rec_store(u64 *rec, u64 slot, u32 x, u32 bin, const u64 *v)
+{
+	u64 *r = rec + slot * (1 + W);
+	r[0] = (u64)x | ((u64)bin << 32);
+#pragma unroll
+	for (int w = 0; w < W; w++) r[1 + w] = v[w];
+}
+template <int W> __device__ __forceinline__ void rec_load(const u64 *rec, u64 slot, u32 &x, u32 &bin, u64 *v)
+{
+	const u64 *r = rec + slot * (1 + W);
+	const u64 h = r[0];
+	x = (u32)h;
+	bin = (u32)(h >> 32);
+#pragma unroll
+	for (int w = 0; w < W; w++) v[w] = r[1 + w];
+}
+
 // ------------------------------------------------------------------------------------------ B: verify + commit
 // Uncontended candidates commit.  Contended ones file a record in U[0] and place their reservations right away
 // (epoch `epoch`), which saves the first reserve pass of the ordered slow path; their claim bits must stay until
@@ -434,11 +454,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_verify_
 		} else reserve_untagged<NHM>(md, bd, i, tc, resv_key(epoch, (u32)x));
 	}
 	const int p = block_append_slot(bd.Un + UN_IDX(0, i, md.nb), contended, &s_cnt, &s_base);
-	if (contended) {
-		bd.U[0][row + p] = (u32)x;
-		bd.Ubin[0][row + p] = bin;
-		store_kmer<W>(bd.Ukm[0], row + p, v);
-	}
+	if (contended) rec_store<W>(bd.Urec[0], row + p, (u32)x, bin, v);
 }
 
 // ------------------------------------------------------------------------------------------ S: ordered slow path
@@ -452,9 +468,9 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_reserve(
 	const int a = (i + t) % md.nb;
 	if (blockIdx.x == 0 && threadIdx.x == 0) bd.Un[UN_IDX(lv ^ 1, i, md.nb)] = 0;   // the other level was consumed by the previous pass
 	for (int u = blockIdx.x * 256 + threadIdx.x; u < cnt; u += SLOW_BLOCKS * 256) {
-		const u32 x = bd.U[lv][row + u], bin = bd.Ubin[lv][row + u];
+		u32 x, bin;
 		u64 v[W];
-		load_kmer<W>(bd.Ukm[lv], row + u, v);
+		rec_load<W>(bd.Urec[lv], row + u, x, bin, v);
 		Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
 		Touches<NHM> tc;
 		gather_touches<W, NHM, false>(md, pm, a, tc);
@@ -484,9 +500,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve(
 		u32 x = 0, bin = 0;
 		u64 v[W];
 		if (u < cnt) {
-			x = bd.U[lv][row + u];
-			bin = bd.Ubin[lv][row + u];
-			load_kmer<W>(bd.Ukm[lv], row + u, v);
+			rec_load<W>(bd.Urec[lv], row + u, x, bin, v);
 			if (bd.status[row + x] == SLOT_UNDECIDED) {
 				Aligned<W> al = left_align<W>(v, md.k);
 				Premixed<W> pm = premix_string<W>(al, md.gfull);
@@ -502,11 +516,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve(
 			}
 		}
 		const int p = block_append_slot(bd.Un + UN_IDX(lv ^ 1, i, md.nb), defer, &s_cnt, &s_base);
-		if (defer) {
-			bd.U[lv ^ 1][row + p] = x;
-			bd.Ubin[lv ^ 1][row + p] = bin;
-			store_kmer<W>(bd.Ukm[lv ^ 1], row + p, v);
-		}
+		if (defer) rec_store<W>(bd.Urec[lv ^ 1], row + p, x, bin, v);
 		const u64 mk = __ballot(mine);
 		if ((threadIdx.x & 63) == 0 && mk) atomicAdd(&s_succ, (int)__popcll(mk));
 		__syncthreads();
@@ -540,11 +550,10 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 		__syncthreads();
 		if (!first) {
 			for (int u = threadIdx.x; u < n; u += 1024) {
-				const u32 x = bd.U[lv][row + u];
-				if (bd.status[row + x] != SLOT_UNDECIDED) continue;
-				const u32 bin = bd.Ubin[lv][row + u];
+				u32 x, bin;
 				u64 v[W];
-				load_kmer<W>(bd.Ukm[lv], row + u, v);
+				rec_load<W>(bd.Urec[lv], row + u, x, bin, v);
+				if (bd.status[row + x] != SLOT_UNDECIDED) continue;
 				Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
 				Touches<NHM> tc;
 				gather_touches<W, NHM, true>(md, pm, a, tc);
@@ -552,7 +561,7 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 				reserve_untagged<NHM>(md, bd, i, tc, resv_key(epoch, x));
 				s_pending = 1;
 			}
-			__threadfence();
+			drain_vmem();                                      // our atomics are performed; readers use sc1 loads
 			__syncthreads();
 			const int pending = s_pending;
 			__syncthreads();
@@ -560,11 +569,10 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 		}
 		int succ = 0;
 		for (int u = threadIdx.x; u < n; u += 1024) {
-			const u32 x = bd.U[lv][row + u];
-			if (bd.status[row + x] != SLOT_UNDECIDED) continue;
-			const u32 bin = bd.Ubin[lv][row + u];
+			u32 x, bin;
 			u64 v[W];
-			load_kmer<W>(bd.Ukm[lv], row + u, v);
+			rec_load<W>(bd.Urec[lv], row + u, x, bin, v);
+			if (bd.status[row + x] != SLOT_UNDECIDED) continue;
 			Aligned<W> al = left_align<W>(v, md.k);
 			Premixed<W> pm = premix_string<W>(al, md.gfull);
 			Touches<NHM> tc;
@@ -577,7 +585,7 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 			}
 		}
 		if (succ) atomicAdd(&s_succ, succ);
-		__threadfence();
+		drain_vmem();
 		__syncthreads();
 		if (!first) epoch++;
 		first = false;

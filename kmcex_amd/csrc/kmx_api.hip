@@ -392,8 +392,7 @@ extern "C" int kmx_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n
 		u64 o_list0 = carve(blk * 4), o_list1 = carve(blk * 4), o_mv0 = carve(blk * 4), o_mv1 = carve(blk * 4);
 		u64 o_n0 = carve(nb * 4), o_n1 = carve(nb * 4), o_status = carve(blk);
 		u64 o_U[KMX_NSLOW];
-		u64 o_Ub[KMX_NSLOW], o_Uk[KMX_NSLOW];
-		for (int s2 = 0; s2 < KMX_NSLOW; s2++) { o_U[s2] = carve(blk * 4); o_Ub[s2] = carve(blk * 4); o_Uk[s2] = carve(blk * 8 * m->W); }
+		for (int s2 = 0; s2 < KMX_NSLOW; s2++) o_U[s2] = carve(blk * 8 * (1 + m->W));
 		u64 o_Un = carve((u64)KMX_NSLOW * nb * KMX_CTR_STRIDE * 4), o_R = carve((u64)nb * KMX_RSIZE * 8);
 		u64 o_tc0 = carve((u64)nb * KMX_NTILES * 4), o_tc1 = carve((u64)nb * KMX_NTILES * 4);
 		HIPCHK(hipMalloc(&m->d_block_scratch, off));
@@ -405,7 +404,7 @@ extern "C" int kmx_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n
 		bd.list[0] = (u32 *)(base + o_list0); bd.list[1] = (u32 *)(base + o_list1);
 		bd.mover[0] = (u32 *)(base + o_mv0); bd.mover[1] = (u32 *)(base + o_mv1);
 		bd.n[0] = (int *)(base + o_n0); bd.n[1] = (int *)(base + o_n1); bd.status = (unsigned char *)(base + o_status);
-		for (int s2 = 0; s2 < KMX_NSLOW; s2++) { bd.U[s2] = (u32 *)(base + o_U[s2]); bd.Ubin[s2] = (u32 *)(base + o_Ub[s2]); bd.Ukm[s2] = (u64 *)(base + o_Uk[s2]); }
+		for (int s2 = 0; s2 < KMX_NSLOW; s2++) bd.Urec[s2] = (u64 *)(base + o_U[s2]);
 		bd.Un = (int *)(base + o_Un); bd.R = (u64 *)(base + o_R);
 		bd.tile_cnt[0] = (int *)(base + o_tc0); bd.tile_cnt[1] = (int *)(base + o_tc1);
 		bd.stats = m->d_stats;

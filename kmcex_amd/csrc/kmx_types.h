@@ -45,11 +45,10 @@ struct BlockDev {
 	int *n[2];               // n[pp][i] current list lengths (buff_real_n, kmodel.hpp:277)
 	int *tile_cnt[2];        // tile_cnt[pp][i*NTILES + tile] survivors (failed slots) per 1024-slot tile, counted as they fail
 	unsigned char *status;   // [nb*BUCKET] per slot: 0 undecided, 1 failed (survivor), 2 inserted
-	// contended k-mers; level (s & 1) = still undecided after s grid-wide resolve passes.  A record carries what the ordered
-	// slow path needs (slot, bin, packed k-mer) so that its latency-bound kernels skip three dependent loads.
-	u32 *U[KMX_NSLOW];       // slot x in the list
-	u32 *Ubin[KMX_NSLOW];    // occurrence bin
-	u64 *Ukm[KMX_NSLOW];     // [..][W] packed k-mer
+	// contended k-mers; level (s & 1) = still undecided after s grid-wide resolve passes.  A record carries what the
+	// ordered slow path needs -- word 0 = slot | bin << 32, then the W packed k-mer words -- so that its latency-bound
+	// kernels reach the cells after ONE dependent load.
+	u64 *Urec[KMX_NSLOW];    // [nb*BUCKET][1 + W]
 	int *Un;                 // [KMX_NSLOW*nb*KMX_CTR_STRIDE], use UN_IDX
 	u64 *R;                  // [nb*KMX_RSIZE] epoch-tagged reservations
 	u64 *stats;              // [ST_N]
