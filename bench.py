@@ -64,7 +64,7 @@ def cpu_baseline(a):
     from kmcex_amd import kmcdb, synth
     n = a.cpu_sample
     km, cnt = synth.make_stream(n, a.k, a.ci, a.cs)
-    q = query_set(km, a.k, max_present=min(len(km), 1_000_000))
+    q = query_set(km, a.k, max_present=min(len(km), 1_000_000))      # +10 % absent draws
     ncpu = os.cpu_count() or 1
     out = {"unit": "k-mers/s", "sample": f"{len(cnt)} synthetic {a.k}-mers (same generator, D1 counts), "
            f"insert = KModel::init incl. both passes and rest build; query = {len(q)} k-mers"}
@@ -114,7 +114,7 @@ def main():
     perm = torch.randperm(n, device=dev, generator=g)[:nq]
     q = km[perm].clone()
     q[: nq // 2] = synth_torch.revcomp(q[: nq // 2], a.k)
-    q = torch.cat([q, synth_torch.random_kmers(max(nq // 10, 10), a.k, 999 + rank, dev)])
+    q = torch.cat([q, synth_torch.random_kmers(max(nq // 10, 10), a.k, 0xABCDEF0123 + rank * (1 << 32), dev)])
     out = torch.empty(q.numel(), dtype=torch.int32, device=dev)
     del perm
 

@@ -61,6 +61,13 @@ def load_library():
         except Exception as e:  # noqa: BLE001
             if not os.path.exists(path):
                 raise KmxError(-2, f"libkmx.so is missing and could not be built ({e}); there is no CPU fallback")
+    # A process that also uses PyTorch-ROCm must end up with ONE HIP runtime: torch bundles its own libamdhip64
+    # (same SONAME as /opt/rocm's).  Importing torch first makes libkmx.so bind to the copy torch already loaded;
+    # the other order leaves torch unable to see the GPU ("No HIP GPUs are available").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
     L.kmx_last_error.restype = C.c_char_p

@@ -20,6 +20,7 @@ CASE = {c[0]: c for c in CASES}
 SMALL = ["tiny_k31", "k31_ci2_200k", "k55_nh9_nb6", "k21_nh6_nb3", "k32_nb4"]
 LARGE = ["k31_multiblock_ci1", "k31_multiblock_ci2", "k55_multiblock"]
 MAX_PRESENT = 400000
+ABSENT_SEED = 0xABCDEF0123                     # far outside the index range of any stream, so these draws are absent
 
 
 def query_set(km, k, seed=7, max_present=MAX_PRESENT):
@@ -31,7 +32,7 @@ def query_set(km, k, seed=7, max_present=MAX_PRESENT):
     q = km[idx].copy()
     h = len(q) // 2
     q[:h] = synth.revcomp(q[:h], k)
-    absent = synth.random_kmers(max(len(q) // 10, 10), k, seed_k=999)
+    absent = synth.random_kmers(max(len(q) // 10, 10), k, seed_k=ABSENT_SEED)
     return np.concatenate([q, absent])
 
 

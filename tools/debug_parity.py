@@ -36,6 +36,6 @@ for name, idxs in (("bf", [0]), ("bf_back", [0]), ("km_back", [0]), ("tag", rang
         b = o.array_bytes(name, i)
         x = np.unpackbits(a ^ b)
         print(name, i, "len", len(a), len(b), "diff bits", int(x.sum()), "popcount dev/ora", int(np.unpackbits(a).sum()), int(np.unpackbits(b).sum()), flush=True)
-q = np.concatenate([km[::7], synth.random_kmers(5000, k, seed_k=999)])
+q = np.concatenate([km[::7], synth.random_kmers(5000, k, seed_k=0xABCDEF0123)])
 r1, r2 = m.kmer_to_occ_packed(q), o.query_packed(k, q)
 print("query mismatches", int((r1 != r2).sum()), len(q))
