@@ -686,20 +686,12 @@ template <int W> __device__ __forceinline__ u64 shr128_lo(const u64 *v, int s)  
 	return s ? (v[0] << (64 - s)) | (v[1] >> s) : v[1];
 }
 
-// KRestData::check_kmer (rest.hpp:223-251) incl. its inclusive upper bound; rows are suffix integers
-template <int W> __device__ __forceinline__ int rest_check(const ModelDev &md, const u64 *v)
+// KRestData::check_kmer (rest.hpp:223-251), literally: binary search over the prefix group with an INCLUSIVE upper
+// bound, so the first row of the next group can match too.  Rows are suffix integers (same order as the byte rows).
+template <int W> __device__ __forceinline__ int rest_check_reference(const ModelDev &md, u32 pre, const u64 *key)
 {
-	if (!md.rest_entries) return 0;
-	const int sbits = 2 * (md.k - md.rest_pre_len);
-	const u32 pre = (u32)shr128_lo<W>(v, sbits);
 	const int g = md.rest_h2i[pre];
 	if (g < 0) return 0;
-	u64 key[W];
-	if (W == 1) key[0] = v[0] & ((1ULL << sbits) - 1);
-	else {
-		if (sbits >= 64) { key[0] = sbits >= 128 ? v[0] : v[0] & ((1ULL << (sbits - 64)) - 1); key[W - 1] = v[W - 1]; }
-		else { key[0] = 0; key[W - 1] = v[W - 1] & ((1ULL << sbits) - 1); }
-	}
 	int low = md.rest_pre[g], high = md.rest_pre[g + 1], mid = 0;
 	bool found = false;
 	while (low <= high) {
@@ -716,6 +708,46 @@ template <int W> __device__ __forceinline__ int rest_check(const ModelDev &md, c
 		else { found = true; break; }
 	}
 	return found ? md.rest_cnt[mid] : 0;
+}
+
+// The same answer with ~3 touches instead of ~12: rows are bucketed by the top F bits of the k-mer (a bucket lies
+// inside one prefix group and holds < 1 row on average), so an exact match is found by scanning the bucket; when
+// there is none, the only row the reference could still return is the first row of the next group, and only if
+// its suffix equals ours -- then, and only then, the literal search above is replayed.
+template <int W> __device__ __forceinline__ int rest_check(const ModelDev &md, const u64 *v)
+{
+	if (!md.rest_entries) return 0;
+	const int sbits = 2 * (md.k - md.rest_pre_len);
+	const u32 pre = (u32)shr128_lo<W>(v, sbits);
+	u64 key[W];
+	if (W == 1) key[0] = v[0] & ((1ULL << sbits) - 1);
+	else {
+		if (sbits >= 64) { key[0] = sbits >= 128 ? v[0] : v[0] & ((1ULL << (sbits - 64)) - 1); key[W - 1] = v[W - 1]; }
+		else { key[0] = 0; key[W - 1] = v[W - 1] & ((1ULL << sbits) - 1); }
+	}
+	const u32 b = (u32)shr128_lo<W>(v, 2 * md.k - md.rest_fbits);
+	u32 lo = md.rest_fine[b], hi = md.rest_fine[b + 1];
+	while (hi - lo > 4) {                                   // skewed data: narrow long buckets first
+		const u32 mid = (lo + hi) >> 1;
+		bool less = false, eq = true;
+#pragma unroll
+		for (int w = 0; w < W; w++) {
+			const u64 r = md.rest_suf[(u64)mid * W + w];
+			if (eq && r != key[w]) { less = r < key[w]; eq = false; }
+		}
+		if (eq) return md.rest_cnt[mid];
+		if (less) lo = mid + 1; else hi = mid;
+	}
+	for (u32 e = lo; e < hi; e++) {
+		bool eq = true;
+#pragma unroll
+		for (int w = 0; w < W; w++) eq &= md.rest_suf[(u64)e * W + w] == key[w];
+		if (eq) return md.rest_cnt[e];
+	}
+	bool q_eq = true;
+#pragma unroll
+	for (int w = 0; w < W; w++) q_eq &= md.rest_q[(u64)pre * W + w] == key[w];
+	return q_eq ? rest_check_reference<W>(md, pre, key) : 0;
 }
 
 // check_all_bf (kmodel.hpp:361-371): filter order {0} for ci==1, {1,0,2} otherwise

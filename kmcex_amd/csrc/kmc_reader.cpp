@@ -1,12 +1,17 @@
 // kmc_reader.cpp -- see kmc_reader.h.  Format per SURVEY.md Appendix B.3 (kmc_file.cpp:132-292, :428-515).
 #include "kmc_reader.h"
+#include <algorithm>
 #include <cstring>
+#include <thread>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace kmx {
 
 namespace {
-constexpr size_t kChunk = size_t(1) << 25;            // same read granularity as the reference (kmc_file.cpp:18)
-
 bool read_file(const std::string &path, std::vector<unsigned char> &out)
 {
 	FILE *f = fopen(path.c_str(), "rb");
@@ -82,65 +87,136 @@ bool KmcListing::open(const std::string &prefix)
 	prefix_mask_ = (uint64_t(1) << (2 * p_)) - 1;
 	suf_bytes_ = (k_ - p_) / 4;
 	rec_bytes_ = suf_bytes_ + counter_size_;
-	suf_ = fopen((prefix + ".kmc_suf").c_str(), "rb");
-	char mk[4];
-	if (!suf_ || fread(mk, 1, 4, suf_) != 4 || memcmp(mk, "KMCS", 4)) {
-		err_ = "cannot open " + prefix + ".kmc_suf (missing or no KMCS marker)";
+	// the record file is mapped, not read: decode threads pull straight from the page cache
+	const int fd = ::open((prefix + ".kmc_suf").c_str(), O_RDONLY);
+	struct stat sb;
+	if (fd < 0 || fstat(fd, &sb) != 0 || sb.st_size < 8) {
+		if (fd >= 0) ::close(fd);
+		err_ = "cannot open " + prefix + ".kmc_suf";
 		close();
 		return false;
 	}
-	buf_.resize(kChunk - kChunk % rec_bytes_);
+	map_len_ = (size_t)sb.st_size;
+	void *mp = mmap(nullptr, map_len_, PROT_READ, MAP_SHARED, fd, 0);
+	::close(fd);
+	if (mp == MAP_FAILED) { map_ = nullptr; err_ = "cannot map " + prefix + ".kmc_suf"; close(); return false; }
+	map_ = (const unsigned char *)mp;
+	madvise(mp, map_len_, MADV_SEQUENTIAL);
+	if (memcmp(map_, "KMCS", 4)) { err_ = prefix + ".kmc_suf has no KMCS marker"; close(); return false; }
+	// a truncated file ends the listing early, like the reference's EOF
+	const uint64_t recs_in_file = (map_len_ - 4 >= 4 ? map_len_ - 8 : 0) / rec_bytes_;
+	avail_ = std::min<uint64_t>(total_, recs_in_file);
 	restart();
 	return true;
 }
 
 void KmcListing::close()
 {
-	if (suf_) fclose(suf_);
-	suf_ = nullptr;
+	if (map_) munmap((void *)map_, map_len_);
+	map_ = nullptr;
+	map_len_ = 0;
 	lut_.clear();
 }
 
-void KmcListing::restart()
-{
-	if (!suf_) return;
-	fseek(suf_, 4, SEEK_SET);
-	buf_pos_ = buf_len_ = 0;
-	lut_idx_ = 0;
-	rec_ = 0;
-}
+void KmcListing::restart() { rec_ = 0; }
 
-bool KmcListing::fill()
+// Decode records [rec0, rec0 + n_recs) (fixed size, so any range can be decoded on its own): the prefix of a record is
+// the index of the LUT entry that contains it (kmc_file.cpp:439-449; "& prefix_mask" folds KMC2's per-bin LUTs).
+// Counts outside [min_count, max_count] are skipped exactly like ReadNextKmer does (kmc_file.cpp:513).
+size_t KmcListing::decode_range(const unsigned char *recs, uint64_t rec0, size_t n_recs, uint64_t *kmers, uint32_t *counts) const
 {
-	buf_len_ = fread(buf_.data(), 1, buf_.size(), suf_);
-	buf_pos_ = 0;
-	return buf_len_ >= rec_bytes_;
+	const int W = words();
+	const size_t n_lut = lut_.size() - 1;
+	// last LUT entry <= rec0 that is followed by a larger one
+	size_t idx = (size_t)(std::upper_bound(lut_.begin(), lut_.begin() + n_lut, rec0) - lut_.begin());
+	idx = idx ? idx - 1 : 0;
+	size_t out = 0;
+	for (size_t j = 0; j < n_recs; j++) {
+		const uint64_t rec = rec0 + j;
+		while (idx + 1 < n_lut && lut_[idx + 1] <= rec) idx++;
+		const unsigned char *r = recs + j * rec_bytes_;
+		uint32_t c = 0;
+		for (uint32_t b = 0; b < counter_size_; b++) c |= (uint32_t)r[suf_bytes_ + b] << (8 * b);
+		if (c < min_count_ || c > max_count_) continue;
+		if (W == 1) {
+			uint64_t v = idx & prefix_mask_;
+			for (uint32_t b = 0; b < suf_bytes_; b++) v = (v << 8) | r[b];
+			kmers[out] = v;
+		} else {
+			unsigned __int128 v = idx & prefix_mask_;
+			for (uint32_t b = 0; b < suf_bytes_; b++) v = (v << 8) | r[b];
+			kmers[2 * out] = (uint64_t)(v >> 64);
+			kmers[2 * out + 1] = (uint64_t)v;
+		}
+		counts[out++] = c;
+	}
+	return out;
 }
 
 size_t KmcListing::next_batch(uint64_t *kmers, uint32_t *counts, size_t max_n)
 {
+	if (!map_ || rec_ >= avail_ || !max_n) return 0;
 	const int W = words();
-	const int sbits = 8 * (int)suf_bytes_;
-	const size_t n_lut = lut_.size() - 1;
+	const size_t got = (size_t)std::min<uint64_t>(max_n, avail_ - rec_);
+	const unsigned char *recs = map_ + 4 + rec_ * rec_bytes_;
+	const uint64_t rec0 = rec_;
+	rec_ += got;
+	int T = threads_;
+	if ((size_t)T > got / 65536 + 1) T = (int)(got / 65536 + 1);
+	if (T <= 1) return decode_range(recs, rec0, got, kmers, counts);
+	// each thread decodes a contiguous slice into the matching slice of the output; slices are closed up afterwards
+	// if the count filter dropped anything (rare: KMC already applied -ci/-cs)
+	std::vector<size_t> kept(T, 0);
+	std::vector<std::thread> th;
+	const size_t per = (got + T - 1) / T;
+	for (int t = 0; t < T; t++)
+		th.emplace_back([&, t] {
+			const size_t lo = (size_t)t * per, hi = std::min(got, lo + per);
+			if (lo < hi) kept[t] = decode_range(recs + lo * rec_bytes_, rec0 + lo, hi - lo, kmers + lo * W, counts + lo);
+		});
+	for (auto &x : th) x.join();
 	size_t out = 0;
-	while (out < max_n && rec_ < total_) {
-		if (buf_pos_ + rec_bytes_ > buf_len_ && !fill()) break;      // truncated file: stop like EOF
-		while (lut_idx_ + 1 < n_lut && lut_[lut_idx_ + 1] <= rec_) lut_idx_++;   // (:439-445) skip empty prefixes
-		const unsigned char *r = &buf_[buf_pos_];
-		buf_pos_ += rec_bytes_;
-		rec_++;
-		uint32_t c = 0;
-		for (uint32_t b = 0; b < counter_size_; b++) c |= (uint32_t)r[suf_bytes_ + b] << (8 * b);
-		if (c < min_count_ || c > max_count_) continue;                 // (:513)
-		unsigned __int128 v = lut_idx_ & prefix_mask_;                  // (:449) "& prefix_mask" for KMC2
-		for (uint32_t b = 0; b < suf_bytes_; b++) v = (v << 8) | r[b];
-		(void)sbits;
-		if (W == 1) kmers[out] = (uint64_t)v;
-		else { kmers[2 * out] = (uint64_t)(v >> 64); kmers[2 * out + 1] = (uint64_t)v; }
-		counts[out] = c;
-		out++;
+	for (int t = 0; t < T; t++) {
+		const size_t lo = (size_t)t * per;
+		if (kept[t] && out != lo) {
+			memmove(kmers + out * W, kmers + lo * W, kept[t] * W * sizeof(uint64_t));
+			memmove(counts + out, counts + lo, kept[t] * sizeof(uint32_t));
+		}
+		out += kept[t];
 	}
 	return out;
+}
+
+void KmcListing::count_classes(uint32_t ci, uint32_t cs, int bf_num, uint64_t n_bf[3], uint64_t *out_of_range) const
+{
+	n_bf[0] = n_bf[1] = n_bf[2] = 0;
+	*out_of_range = 0;
+	if (!map_) return;
+	const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)threads_, avail_ / 65536 + 1));
+	std::vector<uint64_t> acc((size_t)T * 8, 0);
+	auto work = [&](int t) {
+		const uint64_t per = (avail_ + T - 1) / T, lo = (uint64_t)t * per, hi = std::min(avail_, lo + per);
+		uint64_t a[4] = {0, 0, 0, 0};
+		for (uint64_t r = lo; r < hi; r++) {
+			const unsigned char *p = map_ + 4 + r * rec_bytes_ + suf_bytes_;
+			uint32_t c = 0;
+			for (uint32_t b = 0; b < counter_size_; b++) c |= (uint32_t)p[b] << (8 * b);
+			if (c < min_count_ || c > max_count_) continue;              // not listed
+			if (c < ci || c > cs) a[3]++;
+			else if (c < ci + (uint32_t)bf_num) a[c - ci]++;
+		}
+		for (int q = 0; q < 4; q++) acc[(size_t)t * 8 + q] = a[q];
+	};
+	if (T == 1) work(0);
+	else {
+		std::vector<std::thread> th;
+		for (int t = 0; t < T; t++) th.emplace_back(work, t);
+		for (auto &x : th) x.join();
+	}
+	for (int t = 0; t < T; t++) {
+		for (int q = 0; q < 3; q++) n_bf[q] += acc[(size_t)t * 8 + q];
+		*out_of_range += acc[(size_t)t * 8 + 3];
+	}
 }
 
 }   // namespace kmx

@@ -8,7 +8,6 @@
 // a time, so that the host feed is a memcpy-speed loop rather than the reference's per-k-mer string build.
 #pragma once
 #include <cstdint>
-#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -29,15 +28,19 @@ public:
 	// Next batch in listing order; counts outside [min_count, max_count] are skipped exactly like
 	// ReadNextKmer does (kmc_file.cpp:513).  Returns the number of k-mers produced (0 at the end).
 	size_t next_batch(uint64_t *kmers, uint32_t *counts, size_t max_n);
+	void set_threads(int t) { threads_ = t < 1 ? 1 : t; }       // decode threads per batch (records are fixed-size)
+	// Pass 1 of KModel::init (kmodel.hpp:423-428) without materialising k-mers: number of listed k-mers per count
+	// ci+i (i < bf_num) and the number of listed counts outside [ci, cs].  Does not move the listing cursor.
+	void count_classes(uint32_t ci, uint32_t cs, int bf_num, uint64_t n_bf[3], uint64_t *out_of_range) const;
 	const std::string &error() const { return err_; }
 
 private:
-	bool fill();
-	FILE *suf_ = nullptr;
+	size_t decode_range(const unsigned char *recs, uint64_t rec0, size_t n_recs, uint64_t *kmers, uint32_t *counts) const;
+	int threads_ = 1;
+	const unsigned char *map_ = nullptr;    // the whole .kmc_suf, mapped read-only; records start at map_ + 4
+	size_t map_len_ = 0;
 	std::vector<uint64_t> lut_;      // concatenated LUT(s); lut_[size] sentinel = total
-	std::vector<unsigned char> buf_;
-	size_t buf_pos_ = 0, buf_len_ = 0;
-	uint64_t lut_idx_ = 0, rec_ = 0, total_ = 0, max_count_ = 0, prefix_mask_ = 0;
+	uint64_t rec_ = 0, avail_ = 0, total_ = 0, max_count_ = 0, prefix_mask_ = 0;
 	uint32_t k_ = 0, mode_ = 0, counter_size_ = 0, p_ = 0, min_count_ = 0, version_ = 0;
 	uint32_t suf_bytes_ = 0, rec_bytes_ = 0;
 	std::string err_;

@@ -12,7 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace kmxk {
@@ -31,6 +34,8 @@ void debug_min_kmer(int, const u64 *, u64, u64 *, hipStream_t);
 void micro(int, u64 *, u64, u64, u64, u64 *, hipStream_t);
 hipError_t rest_sort(const u64 *, const int *, u64, int, int, u64 *, int *, hipStream_t);
 hipError_t rest_index(const u64 *, u64, int, int, int, int *, int *, u64 *, int *, hipStream_t);
+void rest_expand(const int *, const int *, const u64 *, int, int, int, int, u64 *, hipStream_t);
+void rest_accel(const u64 *, u64, int, int, int, const int *, const int *, const u64 *, int, u32 *, u64 *, hipStream_t);
 }   // namespace kmxk
 
 // ------------------------------------------------------------------------------------------ errors
@@ -115,6 +120,9 @@ struct RestTable {
 	int *d_h2i = nullptr, *d_pre = nullptr, *d_cnt = nullptr;     // d_cnt: counts in sorted order
 	u64 *d_suf = nullptr;
 	u64 *d_sorted = nullptr;       // sorted k-mers [entries][W] (kept for save after a device build)
+	int fbits = 0;                 // lookup accelerators (see ModelDev)
+	u32 *d_fine = nullptr;
+	u64 *d_q = nullptr;
 };
 static int rest_prefix_len(int k) { for (int i = 7; i >= 3; i--) if ((k - i) % 4 == 0) return i; return 3; }   // rest.hpp:78-83
 
@@ -242,9 +250,10 @@ static void free_build_state(kmx_model *m)
 
 static void free_rest_dev(RestTable &r)
 {
-	hipFree(r.d_h2i); hipFree(r.d_pre); hipFree(r.d_cnt); hipFree(r.d_suf); hipFree(r.d_sorted);
+	hipFree(r.d_h2i); hipFree(r.d_pre); hipFree(r.d_cnt); hipFree(r.d_suf); hipFree(r.d_sorted); hipFree(r.d_fine); hipFree(r.d_q);
 	r.d_h2i = r.d_pre = r.d_cnt = nullptr;
-	r.d_suf = r.d_sorted = nullptr;
+	r.d_suf = r.d_sorted = r.d_q = nullptr;
+	r.d_fine = nullptr;
 }
 
 static void free_arrays(kmx_model *m)
@@ -347,6 +356,7 @@ static void fill_model_dev(kmx_model *m)
 	md.bin_of_occ = m->d_bin_of_occ; md.mean_of_bin = m->d_mean_of_bin;
 	md.rest_pre_len = m->rest.pre_len; md.rest_W = m->W; md.rest_entries = m->rest.entries;
 	md.rest_h2i = m->rest.d_h2i; md.rest_pre = m->rest.d_pre; md.rest_suf = m->rest.d_suf; md.rest_cnt = m->rest.d_cnt;
+	md.rest_fbits = m->rest.fbits; md.rest_fine = m->rest.d_fine; md.rest_q = m->rest.d_q;
 }
 
 static int alloc_arrays(kmx_model *m)
@@ -589,6 +599,7 @@ extern "C" int kmx_insert_batch(kmx_model *m, const uint64_t *kmers, const uint3
 // KRestData::build (rest.hpp:95-135,157-161) on the device: radix sort of the survivors + index kernels
 // (rest_device.hip).  The on-disk byte arrays are produced lazily by rest_materialize_host (save only).
 static int rest_to_device(kmx_model *m);
+static int rest_build_accel(kmx_model *m);
 
 static int build_rest(kmx_model *m, u64 n)
 {
@@ -613,6 +624,22 @@ static int build_rest(kmx_model *m, u64 n)
 	HIPCHK(hipMemcpyAsync(m->h_total, m->d_total, 4, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipStreamSynchronize(m->stream));
 	r.pre_buffer_size = *m->h_total + 1;
+	return rest_build_accel(m);
+}
+
+// bucket index + next-group table for k_query's lookup (device only)
+static int rest_build_accel(kmx_model *m)
+{
+	RestTable &r = m->rest;
+	int F = 1;
+	while ((1ULL << F) < r.entries * 2 && F < 26) F++;
+	F = std::max(F, 2 * r.pre_len);
+	F = std::min(F, 2 * r.k);
+	r.fbits = F;
+	HIPCHK(hipMalloc((void **)&r.d_fine, ((1ULL << F) + 2) * 4));
+	HIPCHK(hipMalloc((void **)&r.d_q, (u64)r.map_size * m->W * 8));
+	kmxk::rest_accel(r.d_sorted, r.entries, m->W, r.k, F, r.d_h2i, r.d_pre, r.d_suf, r.map_size, r.d_fine, r.d_q, m->stream);
+	HIPCHK(hipGetLastError());
 	return KMX_OK;
 }
 
@@ -662,8 +689,10 @@ static int rest_to_device(kmx_model *m)
 	HIPCHK(hipMemcpy(r.d_pre, r.pre_buffer.data(), (u64)r.pre_buffer_size * 4, hipMemcpyHostToDevice));
 	if (n) HIPCHK(hipMemcpy(r.d_cnt, r.count_bin.data(), n * 4, hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(r.d_suf, suf.data(), suf.size() * 8, hipMemcpyHostToDevice));
+	HIPCHK(hipMalloc((void **)&r.d_sorted, n * W * 8 + 16));
+	kmxk::rest_expand(r.d_h2i, r.d_pre, r.d_suf, r.map_size, W, r.k, r.pre_len, r.d_sorted, m->stream);
 	r.host_valid = true;
-	return KMX_OK;
+	return rest_build_accel(m);
 }
 
 extern "C" int kmx_finish(kmx_model *m)
@@ -735,31 +764,72 @@ extern "C" int kmx_build_host(kmx_model *m, int k, const uint64_t *kmers, const 
 	return rc;
 }
 
-// KModel::init(db_file) (kmodel.hpp:57-86): pass 1 counts on the host while listing, pass 2 streams batches
+// KModel::init(db_file) (kmodel.hpp:57-86).  Pass 1 counts the Bloom classes while listing (kmodel.hpp:423-428);
+// pass 2 streams the listing to the GPU: a producer thread decodes batches (parallel record decode, kmc_reader.cpp)
+// into two pinned buffers while the previous batch is copied (hipMemcpyAsync) and inserted, so the host feed
+// overlaps the kernels.
+namespace {
+struct FeedSlot {
+	u64 *km = nullptr;
+	u32 *cnt = nullptr;
+	size_t n = 0;
+	bool full = false, last = false;
+};
+}   // namespace
+
 extern "C" int kmx_build_from_kmc(kmx_model *m, const char *db_prefix)
 {
 	if (!m || !db_prefix) return fail(KMX_E_ARG, "null argument");
 	kmx::KmcListing db;
 	if (!db.open(db_prefix)) return fail(KMX_E_IO, "can't open the kmer_data_base %s: %s", db_prefix, db.error().c_str());
+	unsigned hw = std::thread::hardware_concurrency();
+	db.set_threads(hw > 16 ? 16 : (hw ? (int)hw : 1));
 	const int k = (int)db.kmer_length(), W = db.words();
 	const size_t B = size_t(1) << 22;
-	u64 *hk = nullptr;
-	u32 *hc = nullptr;
 	HIPCHK(hipSetDevice(m->device));
-	HIPCHK(hipHostMalloc((void **)&hk, B * W * 8));
-	HIPCHK(hipHostMalloc((void **)&hc, B * 4));
+	FeedSlot slot[2];
+	u64 *dk = nullptr;
+	u32 *dc = nullptr;
+	auto cleanup = [&] {
+		for (auto &sl : slot) { if (sl.km) hipHostFree(sl.km); if (sl.cnt) hipHostFree(sl.cnt); }
+		hipFree(dk); hipFree(dc);
+	};
+	for (auto &sl : slot)
+		if (hipHostMalloc((void **)&sl.km, B * W * 8) != hipSuccess || hipHostMalloc((void **)&sl.cnt, B * 4) != hipSuccess) { cleanup(); return fail(KMX_E_NOMEM, "pinned allocation failed"); }
+	if (hipMalloc((void **)&dk, B * W * 8) != hipSuccess || hipMalloc((void **)&dc, B * 4) != hipSuccess) { cleanup(); return fail(KMX_E_NOMEM, "device allocation failed"); }
+	hipEventRecord(m->ev0, m->stream);
 	uint64_t nbf[3] = {0, 0, 0};
 	int rc = KMX_OK;
-	for (size_t got; (got = db.next_batch((uint64_t *)hk, hc, B)) > 0;)      // pass 1 (kmodel.hpp:423-428)
-		for (size_t i = 0; i < got; i++) {
-			if (hc[i] < (u32)m->ci || hc[i] > (u32)m->cs) { rc = fail(KMX_E_RANGE, "count %u outside [ci=%d, cs=%d]", hc[i], m->ci, m->cs); break; }
-			if (hc[i] < (u32)(m->ci + m->bf_num)) nbf[hc[i] - (u32)m->ci]++;
-		}
+	uint64_t bad = 0;
+	db.count_classes((u32)m->ci, (u32)m->cs, m->bf_num, nbf, &bad);          // pass 1 (kmodel.hpp:423-428), parallel, counts only
+	if (bad) rc = fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)bad, m->ci, m->cs);
 	if (!rc) rc = kmx_begin(m, k, nbf, db.kmer_count());
 	if (!rc) {
-		hipEventRecord(m->ev0, m->stream);
 		db.restart();                                                          // kmodel.hpp:430
-		for (size_t got; !rc && (got = db.next_batch((uint64_t *)hk, hc, B)) > 0;) rc = kmx_insert_batch(m, (const uint64_t *)hk, hc, got);   // pass 2
+		std::mutex mu;
+		std::condition_variable cv;
+		std::thread producer([&] {
+			for (int s = 0;; s ^= 1) {
+				{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !slot[s].full; }); }
+				const size_t got = db.next_batch((uint64_t *)slot[s].km, slot[s].cnt, B);
+				{ std::lock_guard<std::mutex> lk(mu); slot[s].n = got; slot[s].last = got == 0; slot[s].full = true; }
+				cv.notify_all();
+				if (!got) break;
+			}
+		});
+		for (int s = 0;; s ^= 1) {                                              // pass 2 (kmodel.hpp:68-74)
+			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return slot[s].full; }); }
+			if (slot[s].last) break;
+			if (!rc) {
+				const size_t n = slot[s].n;
+				if (hipMemcpyAsync(dk, slot[s].km, n * W * 8, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
+				    hipMemcpyAsync(dc, slot[s].cnt, n * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
+				else rc = kmx_insert_batch_dev(m, (const uint64_t *)dk, dc, n);  // synchronises the stream, so the slot is free again
+			}
+			{ std::lock_guard<std::mutex> lk(mu); slot[s].full = false; }
+			cv.notify_all();
+		}
+		producer.join();
 	}
 	if (!rc) rc = kmx_finish(m);
 	if (!rc) {
@@ -769,7 +839,7 @@ extern "C" int kmx_build_from_kmc(kmx_model *m, const char *db_prefix)
 		hipEventElapsedTime(&ms, m->ev0, m->ev1);
 		m->t_total = ms * 1e-3;
 	}
-	hipHostFree(hk); hipHostFree(hc);
+	cleanup();
 	return rc;
 }
 

@@ -20,6 +20,11 @@ struct ModelDev {
 	const int *rest_pre;                       // pre_buffer[groups+1]
 	const u64 *rest_suf;                       // [entries][W] suffix value (low 2*(k-pre_len) bits)
 	const int *rest_cnt;                       // count_bin[entries]
+	// device-only accelerators of the lookup (same answers as the reference's binary search, far fewer touches)
+	int rest_fbits;                            // F: rows are bucketed by the top F bits of the 2k-bit k-mer
+	const u32 *rest_fine;                      // [2^F + 1] first row of every bucket
+	const u64 *rest_q;                         // [4^pre_len][W] suffix of the first row of the NEXT group (the one row the
+	                                           // reference's inclusive upper bound can still match), all-ones if none
 };
 
 // device-side statistics (one u64 each)

@@ -69,6 +69,50 @@ __global__ __launch_bounds__(256) void k_rest_index(const u64 *km, u64 n, int W,
 	if (e == n - 1) { pre[gid + 1] = (int)n; *groups = gid + 1; }
 }
 
+// rows of a loaded rest.bin carry only suffixes: rebuild the full packed k-mers, prefix by prefix
+__global__ __launch_bounds__(256) void k_rest_expand(const int *h2i, const int *pre, const u64 *suf, int map_size, int W, int sbits, u64 *out)
+{
+	int P = blockIdx.x * 256 + threadIdx.x;
+	if (P >= map_size) return;
+	const int g = h2i[P];
+	if (g < 0) return;
+	for (int e = pre[g]; e < pre[g + 1]; e++) {
+		if (W == 1) out[e] = ((u64)P << sbits) | suf[e];
+		else {
+			unsigned __int128 v = ((unsigned __int128)suf[2 * (u64)e] << 64) | suf[2 * (u64)e + 1];
+			v |= (unsigned __int128)(u64)P << sbits;
+			out[2 * (u64)e] = (u64)(v >> 64);
+			out[2 * (u64)e + 1] = (u64)v;
+		}
+	}
+}
+
+// fine[b] = first row whose top F bits are >= b (lower bound over the sorted k-mers); fine[2^F] = n
+__global__ __launch_bounds__(256) void k_fine_index(const u64 *km, u64 n, int W, int shift, u64 nbuckets, u32 *fine)
+{
+	u64 b = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (b > nbuckets) return;
+	if (b == nbuckets) { fine[b] = (u32)n; return; }
+	const unsigned __int128 thr = (unsigned __int128)b << shift;
+	u64 lo = 0, hi = n;
+	while (lo < hi) {
+		const u64 mid = (lo + hi) >> 1;
+		const unsigned __int128 v = W == 1 ? (unsigned __int128)km[mid] : (((unsigned __int128)km[2 * mid] << 64) | km[2 * mid + 1]);
+		if (v < thr) lo = mid + 1; else hi = mid;
+	}
+	fine[b] = (u32)lo;
+}
+
+// q[P] = suffix of the first row of the group after P's group (all-ones: none)
+__global__ __launch_bounds__(256) void k_next_first(const int *h2i, const int *pre, const u64 *suf, u64 n, int map_size, int W, u64 *q)
+{
+	int P = blockIdx.x * 256 + threadIdx.x;
+	if (P >= map_size) return;
+	const int g = h2i[P];
+	u64 e = g >= 0 ? (u64)pre[g + 1] : n;
+	for (int w = 0; w < W; w++) q[(u64)P * W + w] = e < n ? suf[e * W + w] : ~0ULL;
+}
+
 inline unsigned nblk(u64 n) { return (unsigned)((n + 255) / 256); }
 
 }   // namespace
@@ -136,6 +180,19 @@ hipError_t rest_index(const u64 *km_sorted, u64 n, int W, int k, int pre_len, in
 	hipStreamSynchronize(st);
 	hipFree(tmp); hipFree(flag); hipFree(scan);
 	return e;
+}
+
+void rest_expand(const int *h2i, const int *pre, const u64 *suf, int map_size, int W, int k, int pre_len, u64 *out, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_rest_expand, dim3(nblk(map_size)), dim3(256), 0, st, h2i, pre, suf, map_size, W, 2 * (k - pre_len), out);
+}
+
+// lookup accelerators for k_query: bucket index over the top F bits and the per-prefix "next group's first row"
+void rest_accel(const u64 *km_sorted, u64 n, int W, int k, int F, const int *h2i, const int *pre, const u64 *suf, int map_size, u32 *fine, u64 *q, hipStream_t st)
+{
+	const u64 nbuckets = 1ULL << F;
+	hipLaunchKernelGGL(k_fine_index, dim3(nblk(nbuckets + 1)), dim3(256), 0, st, km_sorted, n, W, 2 * k - F, nbuckets, fine);
+	hipLaunchKernelGGL(k_next_first, dim3(nblk(map_size)), dim3(256), 0, st, h2i, pre, suf, n, map_size, W, q);
 }
 
 }   // namespace kmxk
