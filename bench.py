@@ -38,8 +38,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=100_000_000, help="k-mer draws per rank")
-    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--kmers", dest="n", type=int, default=100_000_000, help="k-mer draws per rank")
+    ap.add_argument("--kmer-len", dest="k", type=int, default=31)
     ap.add_argument("--ci", type=int, default=1)
     ap.add_argument("--cs", type=int, default=1023)
     ap.add_argument("--nh", type=int, default=7)
@@ -98,10 +98,18 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the KModel hot path has no CPU fallback")
+    # rehearsal on a one-GPU box: KMX_BENCH_REHEARSAL=1 puts every rank on cuda:0 and reduces over gloo (CPU tensors);
+    # the real multi-GPU run is one rank per GPU over RCCL ("nccl")
+    rehearsal = os.environ.get("KMX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if distributed:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     from kmcex_amd import KModel, api, synth_torch
 
     # ---- synthetic listing of this rank, resident in HBM
@@ -142,7 +150,7 @@ def main():
         query_step()
     sync_all(distributed)
     t_q = time.perf_counter() - t0
-    (t_ins, t_q), (n_all, nq_all) = kd.reduce_job([t_ins, t_q], [n, q.numel()], device=dev)   # MAX of times, SUM of units
+    (t_ins, t_q), (n_all, nq_all) = kd.reduce_job([t_ins, t_q], [n, q.numel()], device="cpu" if rehearsal else dev)   # MAX of times, SUM of units
     st = m.stats()
 
     # ---- roofline leg: same steps again with HIP events around every launch of each kernel class
