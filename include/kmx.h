@@ -105,6 +105,8 @@ int kmx_download(kmx_model *m, int which, int index, uint8_t *dst, uint64_t capa
  * hashes[n*n_seeds]: murmur_hash64 of the k-mer string (whole=1) or its (k-2)-mer (whole=0).       */
 int kmx_debug_hash(int k, const uint64_t *kmers, uint64_t n, const uint32_t *seeds, int n_seeds, int whole, uint64_t *hashes);
 int kmx_debug_min_kmer(int k, const uint64_t *kmers, uint64_t n, uint64_t *out);
+/* out[i] = h[i] % d with the device's exact reciprocal modulo (`% length`, kmodel.hpp:378,503,600,633), d up to 2^63 */
+int kmx_debug_mod(const uint64_t *h, uint64_t n, uint64_t d, uint64_t *out);
 /* OccuBin tables (occu_bin.hpp:27-83): bin_of_occ[cs+1], mean_of_bin[2^nh]                         */
 int kmx_occubin(int cs, int nh, uint32_t *bin_of_occ, uint32_t *mean_of_bin);
 

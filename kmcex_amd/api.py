@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "kmx_begin", "kmx_insert_batch", "kmx_insert_batch_dev", "kmx_finish", "kmx_build_dev", "kmx_build_host",
     "kmx_query_packed", "kmx_query_packed_dev", "kmx_query_ascii", "kmx_save", "kmx_load", "kmx_get_stats",
     "kmx_download", "kmx_debug_hash", "kmx_debug_min_kmer", "kmx_occubin", "kmx_microbench", "kmx_last_build_seconds",
-    "kmx_set_profile", "kmx_get_kernel_times", "kmx_kmc_info", "kmx_kmc_read",
+    "kmx_set_profile", "kmx_get_kernel_times", "kmx_kmc_info", "kmx_kmc_read", "kmx_debug_mod",
 ]
 
 _lib = None
@@ -91,6 +91,7 @@ def load_library():
     L.kmx_debug_hash.argtypes = [i32, vp, u64, vp, i32, i32, vp]
     L.kmx_debug_min_kmer.argtypes = [i32, vp, u64, vp]
     L.kmx_occubin.argtypes = [i32, i32, vp, vp]
+    L.kmx_debug_mod.argtypes = [vp, u64, u64, vp]
     L.kmx_microbench.argtypes = [i32, u64, u64, i32, C.POINTER(C.c_double)]
     L.kmx_last_build_seconds.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.kmx_kmc_info.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(u64)]
@@ -131,6 +132,13 @@ def debug_min_kmer(k: int, kmers: np.ndarray) -> np.ndarray:
     n = kmers.size // ((k + 31) // 32)
     out = np.zeros_like(kmers)
     _chk(load_library().kmx_debug_min_kmer(k, kmers.ctypes.data, n, out.ctypes.data))
+    return out
+
+
+def debug_mod(h: np.ndarray, d: int) -> np.ndarray:
+    h = np.ascontiguousarray(h, dtype=np.uint64)
+    out = np.zeros_like(h)
+    _chk(load_library().kmx_debug_mod(h.ctypes.data, len(h), d, out.ctypes.data))
     return out
 
 

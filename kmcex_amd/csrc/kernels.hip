@@ -916,6 +916,11 @@ template <int W> __global__ void k_debug_hash(int k, const u64 *kmers, u64 n, co
 	Premixed<W> pm = premix_string<W>(whole ? al : drop_first_base<W>(al), g);
 	for (int s = 0; s < n_seeds; s++) out[i * n_seeds + s] = murmur_seeded<W>(pm, g, seeds[s]);
 }
+__global__ void k_debug_mod(const u64 *h, u64 n, ModU64 md, u64 *out)
+{
+	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = mod_u64(h[i], md);
+}
 template <int W> __global__ void k_debug_min_kmer(int k, const u64 *kmers, u64 n, u64 *out)
 {
 	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1098,6 +1103,10 @@ void cells_to_disk(const u64 *cells, u64 ncells, u64 nbytes, int which, unsigned
 void debug_hash(int k, const u64 *kmers, u64 n, const u32 *seeds, int n_seeds, int whole, u64 *out, hipStream_t st)
 {
 	DISPATCH_W((k + 31) / 32, hipLaunchKernelGGL(k_debug_hash<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, k, kmers, n, seeds, n_seeds, whole, out));
+}
+void debug_mod(const u64 *h, u64 n, u64 d, u64 *out, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_debug_mod, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h, n, make_mod(d), out);
 }
 void debug_min_kmer(int k, const u64 *kmers, u64 n, u64 *out, hipStream_t st)
 {

@@ -31,6 +31,7 @@ void cells_from_disk(const unsigned char *, const unsigned char *, u64, u64 *, u
 void cells_to_disk(const u64 *, u64, u64, int, unsigned char *, hipStream_t);
 void debug_hash(int, const u64 *, u64, const u32 *, int, int, u64 *, hipStream_t);
 void debug_min_kmer(int, const u64 *, u64, u64 *, hipStream_t);
+void debug_mod(const u64 *, u64, u64, u64 *, hipStream_t);
 void micro(int, u64 *, u64, u64, u64, u64 *, hipStream_t);
 hipError_t rest_sort(const u64 *, const int *, u64, int, int, u64 *, int *, hipStream_t);
 hipError_t rest_index(const u64 *, u64, int, int, int, int *, int *, u64 *, int *, hipStream_t);
@@ -1136,6 +1137,19 @@ extern "C" int kmx_debug_min_kmer(int k, const uint64_t *kmers, uint64_t n, uint
 	kmxk::debug_min_kmer(k, dk, n, dout, nullptr);
 	HIPCHK(hipMemcpy(out, dout, n * W * 8, hipMemcpyDeviceToHost));
 	hipFree(dk); hipFree(dout);
+	return KMX_OK;
+}
+
+extern "C" int kmx_debug_mod(const uint64_t *h, uint64_t n, uint64_t d, uint64_t *out)
+{
+	if (!d || !n) return fail(KMX_E_ARG, "bad arguments");
+	u64 *dh = nullptr, *dout = nullptr;
+	HIPCHK(hipMalloc((void **)&dh, n * 8));
+	HIPCHK(hipMalloc((void **)&dout, n * 8));
+	HIPCHK(hipMemcpy(dh, h, n * 8, hipMemcpyHostToDevice));
+	kmxk::debug_mod(dh, n, d, dout, nullptr);
+	HIPCHK(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
+	hipFree(dh); hipFree(dout);
 	return KMX_OK;
 }
 

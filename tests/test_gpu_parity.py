@@ -52,6 +52,17 @@ def test_device_min_kmer_matches_oracle(k):
     assert np.array_equal(dev.reshape(exp.shape), exp)
 
 
+def test_device_modulo_is_exact_for_large_lengths():
+    """`hash % length` with lengths far beyond 2^32 bits (a 10^10-k-mer model has 3.5*10^10 positions per array)."""
+    rng = np.random.default_rng(3)
+    h = rng.integers(0, 1 << 64, size=20000, dtype=np.uint64)
+    h[:8] = [0, 1, 2**64 - 1, 2**63, 2**32, 2**32 - 1, 12345678901234567, 2**64 - 2]
+    for d in [1, 2, 3, 7, 56, 2**32 - 1, 2**32, 2**32 + 1, 34999999944, 8 * 7 * 625000000, 2**40 - 87, 2**40, 2**63 - 25, 2**63]:
+        dev = api.debug_mod(h, d)
+        exp = np.array([int(x) % d for x in h], dtype=np.uint64)
+        assert np.array_equal(dev, exp), d
+
+
 def _build_both(name):
     _, k, ci, cs, nh, nb, n = CASE[name]
     km, cnt = synth.make_stream(n, k, ci, cs)
