@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_histogram(const u32 *counts, u64 n, int
 // ------------------------------------------------------------------------------------------ classification
 // Pass 2 front end (kmodel.hpp:70-73): Bloom-class k-mers are inserted right here (commutative ORs, any
 // order); coupled-array k-mers are compacted, in listing order, into the staging stream.
-#define CLS_TILE 2048
+#define CLS_TILE KMX_CLS_TILE
 template <int W> __global__ __launch_bounds__(256) void k_classify_count(ModelDev md, const u64 *kmers, const u32 *counts, u64 n, int *tile_cnt, u64 *stats)
 {
 	__shared__ int s_cnt;
@@ -1022,13 +1022,20 @@ void histogram(const u32 *counts, u64 n, int ci, int cs, int bf_num, u64 *n_bf, 
 // returns the number of classification tiles
 int classify_tiles(u64 n) { return (int)((n + CLS_TILE - 1) / CLS_TILE); }
 
-void classify_count(const ModelDev &md, const u64 *kmers, const u32 *counts, u64 n, int *tile_cnt, int *tile_off, int *total, u64 *stats, hipStream_t st, KernelProf *prof)
+// Front end of `n` k-mers cut into chunks of `chunk` k-mers (a multiple of CLS_TILE): ONE launch inserts every
+// Bloom-class k-mer and counts the coupled-array k-mers per tile; one small scan per chunk turns the counts into
+// offsets relative to the chunk start and the chunk's total (totals[c]).
+void classify_count(const ModelDev &md, const u64 *kmers, const u32 *counts, u64 n, u64 chunk, int *tile_cnt, int *tile_off, int *totals, u64 *stats, hipStream_t st, KernelProf *prof)
 {
-	int tiles = classify_tiles(n);
+	if (!n) return;
+	const int tiles = classify_tiles(n), tiles_per_chunk = (int)(chunk / CLS_TILE);
 	KPROF_BEGIN(prof, KC_CLASSIFY, st);
 	DISPATCH_W(words(md), hipLaunchKernelGGL(k_classify_count<W>, dim3(tiles), dim3(256), 0, st, md, kmers, counts, n, tile_cnt, stats));
 	KPROF_END(prof, st);
-	hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, (const int *)tile_cnt, tile_off, tiles, total);
+	for (int c = 0, t0 = 0; t0 < tiles; c++, t0 += tiles_per_chunk) {
+		const int nt = tiles - t0 < tiles_per_chunk ? tiles - t0 : tiles_per_chunk;
+		hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, (const int *)(tile_cnt + t0), tile_off + t0, nt, totals + c);
+	}
 }
 
 void classify_scatter(const ModelDev &md, const u64 *kmers, const u32 *counts, u64 n, const int *tile_off, u64 *stg_kmers, u32 *stg_counts, u64 stg_base, hipStream_t st)

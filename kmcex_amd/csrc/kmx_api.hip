@@ -21,7 +21,7 @@
 namespace kmxk {
 void histogram(const u32 *, u64, int, int, int, u64 *, u64 *, hipStream_t);
 int classify_tiles(u64 n);
-void classify_count(const ModelDev &, const u64 *, const u32 *, u64, int *, int *, int *, u64 *, hipStream_t, KernelProf *);
+void classify_count(const ModelDev &, const u64 *, const u32 *, u64, u64, int *, int *, int *, u64 *, hipStream_t, KernelProf *);
 void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int *, u64 *, u32 *, u64, hipStream_t);
 void block_init(const BlockDev &, int, int, int, hipStream_t);
 void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, hipStream_t, KernelProf *);
@@ -162,6 +162,11 @@ struct kmx_model {
 	int *d_stale_counts = nullptr;
 	u64 *d_stats = nullptr, *d_nbf = nullptr;
 	int *d_tile_cnt = nullptr, *d_tile_off = nullptr, *d_total = nullptr;
+	u64 tile_cap = 0;                                          // tiles the two arrays above can hold
+	int *d_totals = nullptr, *h_totals = nullptr;              // per-chunk totals of one insert_batch call (h_: pinned)
+	u64 totals_cap = 0;
+	hipStream_t side = nullptr;                                // front-end (classification + Bloom insert) of later chunks
+	hipEvent_t ev_in = nullptr, ev_side = nullptr;
 	int *h_total = nullptr;                                    // pinned
 	u64 *h_feedback = nullptr;                                 // pinned: ST_MAX_U0 as of some earlier block (heuristic input)
 	u64 epoch = 1, blocks = 0, rounds = 0;
@@ -245,6 +250,7 @@ static void free_build_state(kmx_model *m)
 	hipFree(m->d_stale_counts); m->d_stale_counts = nullptr;
 	hipFree(m->d_tile_cnt); m->d_tile_cnt = nullptr;
 	hipFree(m->d_tile_off); m->d_tile_off = nullptr;
+	m->tile_cap = 0;
 	hipFree(m->d_total); m->d_total = nullptr;
 	m->stg_n = m->stg_cap = 0;
 }
@@ -296,6 +302,9 @@ extern "C" int kmx_create(int ci, int cs, int nh, int nb, kmx_model **out)
 	m->h_feedback[0] = ~0ULL; m->h_feedback[1] = 0;
 	HIPCHK(hipEventCreate(&m->ev0));
 	HIPCHK(hipEventCreate(&m->ev1));
+	HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+	HIPCHK(hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming));
+	HIPCHK(hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming));
 	m->prof.events = &m->prof_events; m->prof.spans = &m->prof_spans; m->prof.begin = prof_begin; m->prof.end = prof_end;
 	*out = m;
 	return KMX_OK;
@@ -313,6 +322,11 @@ extern "C" int kmx_destroy(kmx_model *m)
 	if (m->h_feedback) hipHostFree(m->h_feedback);
 	if (m->ev0) hipEventDestroy(m->ev0);
 	if (m->ev1) hipEventDestroy(m->ev1);
+	if (m->ev_in) hipEventDestroy(m->ev_in);
+	if (m->ev_side) hipEventDestroy(m->ev_side);
+	if (m->side) { hipStreamSynchronize(m->side); hipStreamDestroy(m->side); }
+	hipFree(m->d_totals);
+	if (m->h_totals) hipHostFree(m->h_totals);
 	for (hipEvent_t e : m->prof_events) hipEventDestroy(e);
 	delete m;
 	return KMX_OK;
@@ -423,9 +437,6 @@ extern "C" int kmx_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n
 		TRY(dalloc(&m->d_rest_n, 1, false, m->stream));
 		TRY(dalloc(&m->d_stale_kmers, (u64)nb * 2, false, m->stream));
 		TRY(dalloc(&m->d_stale_counts, (u64)nb, false, m->stream));
-		const int tiles = kmxk::classify_tiles(kChunk);
-		TRY(dalloc(&m->d_tile_cnt, (u64)tiles, false, m->stream));
-		TRY(dalloc(&m->d_tile_off, (u64)tiles, false, m->stream));
 		TRY(dalloc(&m->d_total, 4, true, m->stream));
 		m->rest_cap = 0;
 	}
@@ -538,30 +549,71 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 	return KMX_OK;
 }
 
+// Pass 2 for one batch (kmodel.hpp:68-74).  The batch is cut into chunks of kChunk k-mers.  The front end of chunk 0
+// (classification + Bloom insert, commutative) runs on the model's stream; the front end of all later chunks runs as
+// ONE launch on a side stream, underneath the ordered coupled-array rounds of the earlier chunks, which leave the
+// memory system idle in their latency-bound tails.  The compaction into the staging stream and the rounds stay in
+// order on the model's stream.
 extern "C" int kmx_insert_batch_dev(kmx_model *m, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (m->state != ST_BUILDING) return fail(KMX_E_STATE, "insert_batch before begin");
+	if (!n) return KMX_OK;
 	HIPCHK(hipSetDevice(m->device));
 	const u64 blk = (u64)m->nb * KMX_BUCKET;
-	for (u64 done = 0; done < n;) {
-		const u64 c = std::min<u64>(kChunk, n - done);
-		const u64 *km = (const u64 *)d_kmers + done * m->W;
-		const u32 *ct = (const u32 *)d_counts + done;
-		kmxk::classify_count(m->md, km, ct, c, m->d_tile_cnt, m->d_tile_off, m->d_total, m->d_stats, m->stream, &m->prof);
-		HIPCHK(hipMemcpyAsync(m->h_total, m->d_total, 4, hipMemcpyDeviceToHost, m->stream));
+	const u64 n_chunks = (n + kChunk - 1) / kChunk, tiles = (u64)kmxk::classify_tiles(n);
+	if (tiles > m->tile_cap) {
 		HIPCHK(hipStreamSynchronize(m->stream));
-		const u64 add = (u64)*m->h_total;
-		if (m->km_byte_size == 0 && add) { done += c; continue; }             // divergence D2: no arrays to insert into
+		hipFree(m->d_tile_cnt); hipFree(m->d_tile_off);
+		m->d_tile_cnt = m->d_tile_off = nullptr;
+		TRY(dalloc(&m->d_tile_cnt, tiles, false, m->stream));
+		TRY(dalloc(&m->d_tile_off, tiles, false, m->stream));
+		m->tile_cap = tiles;
+	}
+	if (n_chunks > m->totals_cap) {
+		HIPCHK(hipStreamSynchronize(m->stream));
+		hipFree(m->d_totals);
+		if (m->h_totals) hipHostFree(m->h_totals);
+		m->d_totals = nullptr; m->h_totals = nullptr;
+		TRY(dalloc(&m->d_totals, n_chunks, false, m->stream));
+		HIPCHK(hipHostMalloc((void **)&m->h_totals, n_chunks * 4));
+		m->totals_cap = n_chunks;
+	}
+	const u64 *km0 = (const u64 *)d_kmers;
+	const u32 *ct0 = (const u32 *)d_counts;
+	const u64 c0 = std::min<u64>(kChunk, n);
+	const int tiles0 = kmxk::classify_tiles(c0);
+	kmxk::classify_count(m->md, km0, ct0, c0, kChunk, m->d_tile_cnt, m->d_tile_off, m->d_totals, m->d_stats, m->stream, &m->prof);
+	HIPCHK(hipMemcpyAsync(m->h_totals, m->d_totals, 4, hipMemcpyDeviceToHost, m->stream));
+	if (n_chunks > 1) {
+		HIPCHK(hipEventRecord(m->ev_in, m->stream));             // the input (and the zeroed filters) are ready
+		HIPCHK(hipStreamWaitEvent(m->side, m->ev_in, 0));
+		kmxk::classify_count(m->md, km0 + c0 * m->W, ct0 + c0, n - c0, kChunk, m->d_tile_cnt + tiles0, m->d_tile_off + tiles0,
+		                     m->d_totals + 1, m->d_stats, m->side, &m->prof);
+		HIPCHK(hipMemcpyAsync(m->h_totals + 1, m->d_totals + 1, (n_chunks - 1) * 4, hipMemcpyDeviceToHost, m->side));
+		HIPCHK(hipEventRecord(m->ev_side, m->side));
+	}
+	HIPCHK(hipStreamSynchronize(m->stream));
+	for (u64 ci = 0, done = 0; ci < n_chunks; ci++) {
+		const u64 c = std::min<u64>(kChunk, n - done);
+		const u64 *km = km0 + done * m->W;
+		const u32 *ct = ct0 + done;
+		if (ci == 1) {                                           // the side stream's results: wait once, in stream order too
+			HIPCHK(hipEventSynchronize(m->ev_side));
+			HIPCHK(hipStreamWaitEvent(m->stream, m->ev_side, 0));
+		}
+		const u64 add = (u64)m->h_totals[ci];
+		done += c;
+		if (m->km_byte_size == 0 && add) continue;               // divergence D2: no arrays to insert into
 		if (m->stg_n + add > m->stg_cap) return fail(KMX_E_STATE, "staging overflow");
-		kmxk::classify_scatter(m->md, km, ct, c, m->d_tile_off, m->d_stg_kmers, m->d_stg_counts, m->stg_n, m->stream);
+		kmxk::classify_scatter(m->md, km, ct, c, m->d_tile_off + ci * (kChunk / KMX_CLS_TILE), m->d_stg_kmers, m->d_stg_counts, m->stg_n, m->stream);
 		m->stg_n += add;
 		u64 head = 0;
 		while (m->stg_n - head >= blk) {
 			TRY(process_block(m, head, blk, false));
 			head += blk;
 		}
-		if (head) {                                                           // carry the remainder (< one block) to the front
+		if (head) {                                              // carry the remainder (< one block) to the front
 			const u64 rem = m->stg_n - head;
 			if (rem) {
 				HIPCHK(hipMemcpyAsync(m->d_stg_kmers, m->d_stg_kmers + head * m->W, rem * m->W * 8, hipMemcpyDeviceToDevice, m->stream));
@@ -569,7 +621,6 @@ extern "C" int kmx_insert_batch_dev(kmx_model *m, const uint64_t *d_kmers, const
 			}
 			m->stg_n = rem;
 		}
-		done += c;
 	}
 	HIPCHK(hipGetLastError());
 	return KMX_OK;

@@ -30,6 +30,7 @@ struct ModelDev {
 // device-side statistics (one u64 each)
 enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_MAX_U0, ST_MAX_UFIN, ST_N };
 
+#define KMX_CLS_TILE 2048                      // k-mers per classification tile (front end)
 #define KMX_RSIZE_LOG2 20
 #define KMX_RSIZE (1u << KMX_RSIZE_LOG2)      // reservation slots per list (ordered slow path)
 #define KMX_NSLOW 2                            // contended-record levels, ping-pong: pass s reads level s&1, defers to (s+1)&1

@@ -55,11 +55,14 @@ def revcomp(kmers: np.ndarray, k: int) -> np.ndarray:
     # 128-bit value v = hi:lo ; reverse groups -> (rev(lo) : rev(hi)), complement, shift right by 128-2k
     nh, nl = _rev2_u64(~lo), _rev2_u64(~hi)
     s = 128 - 2 * k
-    assert 0 < s < 64
-    s_, c_ = np.uint64(s), np.uint64(64 - s)
+    assert 0 <= s < 64
     out = np.empty_like(a)
-    out[:, 1] = (nl >> s_) | (nh << c_)
-    out[:, 0] = nh >> s_
+    if s == 0:
+        out[:, 1], out[:, 0] = nl, nh
+    else:
+        s_, c_ = np.uint64(s), np.uint64(64 - s)
+        out[:, 1] = (nl >> s_) | (nh << c_)
+        out[:, 0] = nh >> s_
     return out.reshape(kmers.shape)
 
 

@@ -180,3 +180,46 @@ def test_error_behaviour():
         m.init("/nonexistent/db")                            # reference: message + exit(1)
     with pytest.raises(api.KmxError):
         KModel.load("/nonexistent/dir")
+
+
+def _random_configs(n_cfg, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n_cfg:
+        k = int(rng.choice([8, 11, 15, 16, 17, 23, 31, 32, 33, 40, 47, 55, 63, 64]))
+        nh = int(rng.integers(3, 17))
+        nb = int(rng.choice([1, 2, 3, 5, 6, 8, 16]))
+        ci = int(rng.choice([1, 2, 3]))
+        e3 = 1 << nh
+        cs_min = e3 // 4 + 3 * (e3 // 2) + e3 // 4          # smallest cs the OccuBin table accepts comfortably
+        cs = int(min(65535, cs_min + int(rng.integers(0, 3000))))
+        n = int(rng.choice([50, 700, 6000, 60000, 300000]))
+        if 4 ** k < 4 * n:                                    # not enough distinct k-mers
+            continue
+        out.append((k, ci, cs, nh, nb, n, int(rng.integers(1, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _random_configs(28, 20261003), ids=lambda c: "k%d_ci%d_cs%d_nh%d_nb%d_n%d" % c[:6])
+def test_random_configurations_bit_exact(cfg, tmp_path):
+    """Random (k, ci, cs, nh, nb, N): both template paths (nh <= 8 / > 8, one / two words), nb from 1 to 16, tiny to
+    multi-list inputs, every Bloom class layout.  Arrays, statistics, files and answers must equal the oracle's."""
+    k, ci, cs, nh, nb, n, seed = cfg
+    km, cnt = synth.make_stream(n, k, ci, cs, seed_k=seed, seed_c=seed + 1)
+    m = KModel(ci, cs, nh, nb)
+    m.build_packed(k, km, cnt)
+    o = O.OracleModel(ci, cs, nh, nb)
+    o.build(k, km, cnt)
+    st, so = m.stats(), o.stats()
+    _check_arrays(m, o, nb, st.bf_num)
+    assert (st.attempts, st.successes, st.rest_entries) == (so.attempts, so.successes, so.rest_entries)
+    d1, d2 = str(tmp_path / "g"), str(tmp_path / "o")
+    os.makedirs(d1)
+    m.save(d1)
+    o.save(d2)
+    for f in ("header", "km.bin", "rest.bin"):
+        assert sha_file(os.path.join(d1, f)) == sha_file(os.path.join(d2, f)), f
+    q = np.concatenate([km, synth.revcomp(km, k), synth.random_kmers(max(len(cnt) // 2, 20), k, seed_k=0xABCDEF0123)])
+    assert np.array_equal(m.kmer_to_occ_packed(q), o.query_packed(k, q))
+    m2 = KModel.load(d2)                                      # files written by the oracle load and answer identically
+    assert np.array_equal(m2.kmer_to_occ_packed(q), o.query_packed(k, q))
