@@ -86,7 +86,8 @@ int kmx_build_host(kmx_model *m, int k, const uint64_t *kmers, const uint32_t *c
 /* vector<int> KModel::kmer_to_occ(vector<string>, t_num)                   kmodel.hpp:90-98   */
 int kmx_query_packed(kmx_model *m, const uint64_t *kmers, uint64_t n, int32_t *out);
 int kmx_query_packed_dev(kmx_model *m, const uint64_t *d_kmers, uint64_t n, int32_t *d_out);
-/* n records of `stride` bytes holding `len` characters each (not NUL-terminated)                 */
+/* n records of `stride` bytes holding `len` characters each (not NUL-terminated), 2 <= len <= 64.  Strings of
+ * the model's k over ACGT take the packed kernel; anything else is hashed byte for byte like the reference does. */
 int kmx_query_ascii(kmx_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out);
 
 /* KModel::save(dir) -> header, km.bin, rest.bin (dir must exist)           kmodel.hpp:173-206 */

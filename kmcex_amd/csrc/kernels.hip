@@ -750,27 +750,27 @@ template <int W> __device__ __forceinline__ int rest_check(const ModelDev &md, c
 	return q_eq ? rest_check_reference<W>(md, pre, key) : 0;
 }
 
-// check_all_bf (kmodel.hpp:361-371): filter order {0} for ci==1, {1,0,2} otherwise
-template <int W> __device__ __forceinline__ int check_all_bf(const ModelDev &md, const Premixed<W> &pf, const Premixed<W> &pb)
+// check_all_bf (kmodel.hpp:361-371): filter order {0} for ci==1, {1,0,2} otherwise.  PW = words of the pre-mixed string.
+template <int PW> __device__ __forceinline__ int check_all_bf(const ModelDev &md, const StrGeom gf, const StrGeom gb, const Premixed<PW> &pf, const Premixed<PW> &pb)
 {
 	for (int j = 0; j < md.bf_num; j++) {
 		int i = md.ci == 1 ? j : (j == 0 ? 1 : (j == 1 ? 0 : 2));
-		bool a = bloom_check_pm<W>(pf, md.gfull, md.bf[i], md.bf_mod[i], md.nh - 1);
-		bool b = a && bloom_check_pm<W>(pb, md.gback, md.bf_back[i], md.bf_back_mod[i], md.nh - 2);
+		bool a = bloom_check_pm<PW>(pf, gf, md.bf[i], md.bf_mod[i], md.nh - 1);
+		bool b = a && bloom_check_pm<PW>(pb, gb, md.bf_back[i], md.bf_back_mod[i], md.nh - 2);
 		if (a && b) return i + md.ci;
 	}
 	return 0;
 }
 
 // one coupled array: -1 if a tag is missing, else the value bits, hash j -> bit j (kmodel.hpp:630-642)
-template <int W> __device__ __forceinline__ int decode_array(const ModelDev &md, const Premixed<W> &pf, int a)
+template <int PW> __device__ __forceinline__ int decode_array(const ModelDev &md, const StrGeom gf, const Premixed<PW> &pf, int a)
 {
 	if (!md.km_mod.d) return -1;
 	const u64 *cells = md.cells[a];
 	int v = 0;
 	bool ok = true;
 	for (int j = 0; j < md.nh && ok; j++) {
-		u64 pos = mod_u64(murmur_seeded<W>(pf, md.gfull, c_seeds[(a * md.nh + j) & 127]), md.km_mod);
+		u64 pos = mod_u64(murmur_seeded<PW>(pf, gf, c_seeds[(a * md.nh + j) & 127]), md.km_mod);
 		u64 cell = cells[pos >> 4];
 		u32 b = bit_in_cell(pos);
 		ok = (cell >> (16 + b)) & 1ULL;
@@ -779,7 +779,66 @@ template <int W> __device__ __forceinline__ int decode_array(const ModelDev &md,
 	return ok ? v : -1;
 }
 
-// get_candidates (kmodel.hpp:326-342); returns -2 when the neighbour contributes nothing
+// the part of get_candidates (kmodel.hpp:326-342) after canonicalisation and the rest lookup; -2 = contributes nothing
+template <int PW> __device__ __forceinline__ int candidate_from_filters(const ModelDev &md, const StrGeom gf, const StrGeom gb, const Premixed<PW> &pf, const Premixed<PW> &pb)
+{
+	int occ = check_all_bf<PW>(md, gf, gb, pf, pb);
+	if (occ != 0) return occ;
+	if (bloom_check_pm<PW>(pb, gb, md.km_back, md.km_back_mod, md.nh - 2)) {
+		int result = -1;                                     // find_bitarray_one (kmodel.hpp:650-671, quirk Q3)
+		for (int a = 0; a < md.nb; a++) {
+			int d = decode_array<PW>(md, gf, pf, a);
+			if (d >= 0) { result = d; if (d != 0) break; }
+		}
+		if (result > -1) return result;
+	}
+	return -2;
+}
+
+// kmer_to_occ after canonicalisation and the rest lookup (kmodel.hpp:107-115) + kmer_to_bin (:286-323).
+// `neighbours(cand)` fills the up-to-8 neighbour candidates (get_neighbor_kmer_bin, :344-359) and returns their number.
+template <int PW, typename NEIGH>
+__device__ __forceinline__ int occ_from_filters(const ModelDev &md, const StrGeom gf, const StrGeom gb, const Premixed<PW> &pf, const Premixed<PW> &pb, NEIGH neighbours)
+{
+	const bool in_back = bloom_check_pm<PW>(pb, gb, md.km_back, md.km_back_mod, md.nh - 2);
+	const int occ = check_all_bf<PW>(md, gf, gb, pf, pb);
+	if (!in_back) return occ;                                // :109-111
+	int nv = 0, first = 0;
+	for (int a = 0; a < md.nb; a++) {                        // find_bitarray (:625-646)
+		int d = decode_array<PW>(md, gf, pf, a);
+		if (d > 0) { if (nv == 0) first = d; nv++; }
+	}
+	int bin;
+	if (nv == 0) bin = occ;
+	else if (nv == 1) {
+		bin = first;
+		if (occ) {
+			int cand[8];
+			int nc = neighbours(cand), cnt = 0;
+			for (int c = 0; c < 8; c++) cnt += (c < nc && cand[c] < md.ci + md.bf_num) ? 1 : 0;
+			if (cnt >= nc / 2) bin = occ;
+		}
+	} else {
+		int cand[8];
+		int nc = neighbours(cand);
+		if (nc <= 0) bin = 0;
+		else {
+			int min_dist = 2 << 20;
+			bin = first;
+			for (int a = 0; a < md.nb; a++) {
+				int d = decode_array<PW>(md, gf, pf, a);
+				if (d <= 0) continue;
+				int cur = 2 << 20;
+				for (int c = 0; c < 8; c++)
+					if (c < nc) { int dd = d > cand[c] ? d - cand[c] : cand[c] - d; cur = dd < cur ? dd : cur; }
+				if (min_dist > cur) { min_dist = cur; bin = d; }
+			}
+		}
+	}
+	return (int)md.mean_of_bin[bin];
+}
+
+// get_candidates (kmodel.hpp:326-342) on a packed k-mer; returns -2 when the neighbour contributes nothing
 template <int W> __device__ __forceinline__ int neighbour_candidate(const ModelDev &md, u64 *nv)
 {
 	min_kmer<W>(nv, md.k);
@@ -788,17 +847,7 @@ template <int W> __device__ __forceinline__ int neighbour_candidate(const ModelD
 	Aligned<W> al = left_align<W>(nv, md.k);
 	Premixed<W> pf = premix_string<W>(al, md.gfull);
 	Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-	int occ = check_all_bf<W>(md, pf, pb);
-	if (occ != 0) return occ;
-	if (bloom_check_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2)) {
-		int result = -1;                                     // find_bitarray_one (kmodel.hpp:650-671, quirk Q3)
-		for (int a = 0; a < md.nb; a++) {
-			int d = decode_array<W>(md, pf, a);
-			if (d >= 0) { result = d; if (d != 0) break; }
-		}
-		if (result > -1) return result;
-	}
-	return -2;
+	return candidate_from_filters<W>(md, md.gfull, md.gback, pf, pb);
 }
 
 // get_neighbor_kmer_bin (kmodel.hpp:344-359): 4 successors then 4 predecessors, bases in ACGT order
@@ -828,7 +877,7 @@ template <int W> __device__ __forceinline__ int neighbour_bins(const ModelDev &m
 	return nc;
 }
 
-// KModel::kmer_to_occ (kmodel.hpp:100-116) + kmer_to_bin (:286-323)
+// KModel::kmer_to_occ (kmodel.hpp:100-116) on packed k-mers
 template <int W> __global__ __launch_bounds__(256) void k_query(ModelDev md, const u64 *kmers, u64 n, int *out)
 {
 	const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -841,42 +890,148 @@ template <int W> __global__ __launch_bounds__(256) void k_query(ModelDev md, con
 	Aligned<W> al = left_align<W>(v, md.k);
 	Premixed<W> pf = premix_string<W>(al, md.gfull);
 	Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-	const bool in_back = bloom_check_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
-	occ = check_all_bf<W>(md, pf, pb);
-	if (!in_back) { out[q] = occ; return; }                  // :109-111
-	int nv = 0, first = 0;
-	for (int a = 0; a < md.nb; a++) {                        // find_bitarray (:625-646)
-		int d = decode_array<W>(md, pf, a);
-		if (d > 0) { if (nv == 0) first = d; nv++; }
-	}
-	int bin;
-	if (nv == 0) bin = occ;
-	else if (nv == 1) {
-		bin = first;
-		if (occ) {
-			int cand[8];
-			int nc = neighbour_bins<W>(md, v, cand), cnt = 0;
-			for (int c = 0; c < 8; c++) cnt += (c < nc && cand[c] < md.ci + md.bf_num) ? 1 : 0;
-			if (cnt >= nc / 2) bin = occ;
-		}
-	} else {
-		int cand[8];
-		int nc = neighbour_bins<W>(md, v, cand);
-		if (nc <= 0) bin = 0;
-		else {
-			int min_dist = 2 << 20;
-			bin = first;
-			for (int a = 0; a < md.nb; a++) {
-				int d = decode_array<W>(md, pf, a);
-				if (d <= 0) continue;
-				int cur = 2 << 20;
-				for (int c = 0; c < 8; c++)
-					if (c < nc) { int dd = d > cand[c] ? d - cand[c] : cand[c] - d; cur = dd < cur ? dd : cur; }
-				if (min_dist > cur) { min_dist = cur; bin = d; }
+	out[q] = occ_from_filters<W>(md, md.gfull, md.gback, pf, pb, [&](int *cand) { return neighbour_bins<W>(md, v, cand); });
+}
+
+// ------------------------------------------------------------------------------------------ query on raw strings
+// kmer_to_occ for strings the packed form cannot hold (characters outside ACGT, length != k): the reference hashes
+// the bytes it is given, treats unknown characters as 'A' only where it converts to 2-bit codes (tools.hpp:63-76,
+// rest.hpp:22-34) and canonicalises through one u64 (tools.hpp:160-167).  Same decision tree, on byte strings of one
+// common length L <= 64 (string byte i lives in b[i >> 3], bits 8*(i & 7)).
+struct AStr { u64 b[8]; };
+
+__device__ __forceinline__ u32 code_of_byte(u32 c) { return c == 'C' ? 1u : (c == 'G' ? 2u : (c == 'T' ? 3u : 0u)); }
+
+// 2-bit codes of all L characters as a 128-bit integer (first character most significant)
+__device__ __forceinline__ void astr_codes(const AStr &s, int L, u64 &hi, u64 &lo)
+{
+	hi = lo = 0;
+#pragma unroll
+	for (int w = 0; w < 8; w++)
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			if (8 * w + j < L) {
+				const u32 c = code_of_byte((u32)(s.b[w] >> (8 * j)) & 0xFFu);
+				hi = (hi << 2) | (lo >> 62);
+				lo = (lo << 2) | c;
 			}
-		}
+}
+// zero everything from byte L on
+__device__ __forceinline__ void astr_clip(AStr &s, int L)
+{
+#pragma unroll
+	for (int w = 0; w < 8; w++) {
+		const int keep = L - 8 * w;                             // bytes of this word that belong to the string
+		if (keep <= 0) s.b[w] = 0;
+		else if (keep < 8) s.b[w] &= (1ULL << (8 * keep)) - 1;
 	}
-	out[q] = (int)md.mean_of_bin[bin];
+}
+__device__ __forceinline__ AStr astr_drop_first(const AStr &s)              // s[1:]
+{
+	AStr r;
+#pragma unroll
+	for (int w = 0; w < 8; w++) r.b[w] = (s.b[w] >> 8) | (w + 1 < 8 ? s.b[w + 1] << 56 : 0);
+	return r;
+}
+__device__ __forceinline__ AStr astr_shift_in_front(const AStr &s, u32 c)    // c + s
+{
+	AStr r;
+#pragma unroll
+	for (int w = 0; w < 8; w++) r.b[w] = (s.b[w] << 8) | (w ? s.b[w - 1] >> 56 : (u64)c);
+	return r;
+}
+__device__ __forceinline__ void astr_set(AStr &s, int i, u32 c)
+{
+#pragma unroll
+	for (int w = 0; w < 8; w++)
+		if ((i >> 3) == w) s.b[w] = (s.b[w] & ~(0xFFULL << (8 * (i & 7)))) | ((u64)c << (8 * (i & 7)));
+}
+// Tools::get_min_kmer on a byte string (tools.hpp:160-167, quirk Q4 for L > 32)
+__device__ __forceinline__ void astr_min_kmer(AStr &s, int L)
+{
+	u64 hi, u;
+	astr_codes(s, L, hi, u);
+	const u64 r32 = rev2_u64(~u);
+	u64 rc;
+	if (L <= 32) rc = r32 >> (64 - 2 * L);
+	else { const int sh = 2 * (L - 32); rc = sh >= 64 ? ~0ULL : ((r32 << sh) | ((1ULL << sh) - 1)); }
+	if (u <= rc) return;
+#pragma unroll
+	for (int w = 7; w >= 0; w--) {                             // uint64_to_string: last character from the low bits
+		u64 word = 0;
+#pragma unroll
+		for (int j = 7; j >= 0; j--)
+			if (8 * w + j < L) {
+				const u32 c = (u32)(rc & 3);
+				word |= (u64)(c == 0 ? 'A' : (c == 1 ? 'C' : (c == 2 ? 'G' : 'T'))) << (8 * j);
+				rc >>= 2;
+			}
+		s.b[w] = word;
+	}
+}
+__device__ __forceinline__ Premixed<2> astr_premix(const AStr &s, const StrGeom g)
+{
+	Premixed<2> p;
+	p.tail = 0;
+#pragma unroll
+	for (int b = 0; b < 8; b++) {
+		p.blk[b] = premix(s.b[b]);
+		if (b == g.nblk) p.tail = g.rem ? (s.b[b] & ((1ULL << (8 * g.rem)) - 1)) : 0;
+	}
+	return p;
+}
+// KRestData::check_kmer on a byte string: 0 unless the length is the table's k (rest.hpp:224-226, quirk Q7)
+template <int W> __device__ __forceinline__ int astr_rest_check(const ModelDev &md, const AStr &s, int L)
+{
+	if (L != md.k) return 0;
+	u64 hi, lo, v[W];
+	astr_codes(s, L, hi, lo);
+	v[W - 1] = lo;
+	if (W == 2) v[0] = hi;
+	return rest_check<W>(md, v);
+}
+template <int W> __device__ __forceinline__ int astr_candidate(const ModelDev &md, const StrGeom gf, const StrGeom gb, AStr t, int L)
+{
+	astr_min_kmer(t, L);
+	const int r = astr_rest_check<W>(md, t, L);
+	if (r > 0) return (int)md.bin_of_occ[r];
+	Premixed<2> pf = astr_premix(t, gf);
+	Premixed<2> pb = astr_premix(astr_drop_first(t), gb);
+	return candidate_from_filters<2>(md, gf, gb, pf, pb);
+}
+
+template <int W> __global__ __launch_bounds__(256) void k_query_ascii(ModelDev md, StrGeom gf, StrGeom gb, int L, const unsigned char *strs, int stride, u64 n, int *out)
+{
+	const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (q >= n) return;
+	AStr s;
+	const unsigned char *p = strs + q * (u64)stride;
+#pragma unroll
+	for (int w = 0; w < 8; w++) {
+		u64 word = 0;
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			if (8 * w + j < L) word |= (u64)p[8 * w + j] << (8 * j);
+		s.b[w] = word;
+	}
+	astr_min_kmer(s, L);
+	const int occ = astr_rest_check<W>(md, s, L);
+	if (occ != 0) { out[q] = occ; return; }
+	Premixed<2> pf = astr_premix(s, gf);
+	Premixed<2> pb = astr_premix(astr_drop_first(s), gb);
+	out[q] = occ_from_filters<2>(md, gf, gb, pf, pb, [&](int *cand) {
+		int nc = 0;
+		const AStr t1 = astr_drop_first(s);                      // kmer.substr(1): still holds s[L-1] at byte L-2
+		for (int x = 0; x < 8; x++) {
+			const u32 X = (u32)"ACGT"[x & 3];
+			AStr t;
+			if (x < 4) { t = t1; astr_set(t, L - 1, X); }      // drop the first character, append X
+			else { t = astr_shift_in_front(s, X); astr_clip(t, L); }   // prepend X, drop the last character
+			const int c = astr_candidate<W>(md, gf, gb, t, L);
+			if (c != -2) cand[nc++] = c;
+		}
+		return nc;
+	});
 }
 
 // ------------------------------------------------------------------------------------------ layout conversion
@@ -1094,6 +1249,13 @@ void query(const ModelDev &md, const u64 *kmers, u64 n, int *out, hipStream_t st
 	KPROF_BEGIN(prof, KC_QUERY, st);
 	DISPATCH_W(words(md), hipLaunchKernelGGL(k_query<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, md, kmers, n, out));
 	KPROF_END(prof, st);
+}
+
+void query_ascii(const ModelDev &md, int L, const unsigned char *strs, int stride, u64 n, int *out, hipStream_t st)
+{
+	if (!n) return;
+	const StrGeom gf = make_geom(L), gb = make_geom(L >= 2 ? L - 2 : 0);
+	DISPATCH_W(words(md), hipLaunchKernelGGL(k_query_ascii<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, md, gf, gb, L, strs, stride, n, out));
 }
 
 void cells_from_disk(const unsigned char *val, const unsigned char *tag, u64 nbytes, u64 *cells, u64 ncells, hipStream_t st)

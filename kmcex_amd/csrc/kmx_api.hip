@@ -27,6 +27,7 @@ void block_init(const BlockDev &, int, int, int, hipStream_t);
 void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, hipStream_t, KernelProf *);
 void rest_append(const ModelDev &, const BlockDev &, int, u64 *, int *, unsigned long long *, u64 *, int *, hipStream_t);
 void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *);
+void query_ascii(const ModelDev &, int, const unsigned char *, int, u64, int *, hipStream_t);
 void cells_from_disk(const unsigned char *, const unsigned char *, u64, u64 *, u64, hipStream_t);
 void cells_to_disk(const u64 *, u64, u64, int, unsigned char *, hipStream_t);
 void debug_hash(int, const u64 *, u64, const u32 *, int, int, u64 *, hipStream_t);
@@ -947,15 +948,18 @@ extern "C" int kmx_query_packed(kmx_model *m, const uint64_t *kmers, uint64_t n,
 	return rc;
 }
 
-// vector<string> front door: strings are packed on the host (2 bits/base), the lookup runs on the device.
-// Strings that the packed form cannot represent (length != k, characters outside ACGT) are rejected.
+// vector<string> front door (kmodel.hpp:90-116).  Strings of the model's k that hold only ACGT are packed on the host
+// (2 bits/base) and take the packed kernel; anything else -- other characters, another length -- is answered by the
+// byte-string kernel, which hashes the bytes as they are, exactly like the reference does.
 extern "C" int kmx_query_ascii(kmx_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (m->state != ST_READY) return fail(KMX_E_STATE, "query before the model is built or loaded");
-	if (len != m->k) return fail(KMX_E_ARG, "k-mer length %d does not match the model's k=%d", len, m->k);
-	std::vector<u64> pk(n * m->W);
-	for (u64 i = 0; i < n; i++) {
+	if (len < 2 || len > 64 || stride < len) return fail(KMX_E_ARG, "k-mer strings must hold 2..64 characters (got %d, stride %d)", len, stride);
+	if (!n) return KMX_OK;
+	bool clean = len == m->k;
+	std::vector<u64> pk(clean ? n * m->W : 0);
+	for (u64 i = 0; i < n && clean; i++) {
 		unsigned __int128 v = 0;
 		const char *s = strs + i * (u64)stride;
 		for (int j = 0; j < len; j++) {
@@ -965,14 +969,30 @@ extern "C" int kmx_query_ascii(kmx_model *m, const char *strs, int len, int stri
 			case 'C': c = 1; break;
 			case 'G': c = 2; break;
 			case 'T': c = 3; break;
-			default: return fail(KMX_E_ARG, "k-mer %llu holds a character outside ACGT", (unsigned long long)i);
+			default: c = 0; clean = false;
 			}
 			v = (v << 2) | c;
 		}
 		if (m->W == 1) pk[i] = (u64)v;
 		else { pk[2 * i] = (u64)(v >> 64); pk[2 * i + 1] = (u64)v; }
 	}
-	return kmx_query_packed(m, (const uint64_t *)pk.data(), n, out);
+	if (clean) return kmx_query_packed(m, (const uint64_t *)pk.data(), n, out);
+	HIPCHK(hipSetDevice(m->device));
+	unsigned char *ds = nullptr;
+	int *dout = nullptr;
+	const u64 bytes = (n - 1) * (u64)stride + (u64)len;
+	HIPCHK(hipMalloc((void **)&ds, bytes));
+	HIPCHK(hipMalloc((void **)&dout, n * 4));
+	int rc = KMX_OK;
+	if (hipMemcpyAsync(ds, strs, bytes, hipMemcpyHostToDevice, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
+	if (!rc) {
+		kmxk::query_ascii(m->md, len, ds, stride, n, dout, m->stream);
+		if (hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "D2H copy failed");
+	}
+	hipStreamSynchronize(m->stream);
+	if (!rc && hipGetLastError() != hipSuccess) rc = fail(KMX_E_NODEVICE, "query kernel failed");
+	hipFree(ds); hipFree(dout);
+	return rc;
 }
 
 // ------------------------------------------------------------------------------------------ persistence

@@ -223,3 +223,36 @@ def test_random_configurations_bit_exact(cfg, tmp_path):
     assert np.array_equal(m.kmer_to_occ_packed(q), o.query_packed(k, q))
     m2 = KModel.load(d2)                                      # files written by the oracle load and answer identically
     assert np.array_equal(m2.kmer_to_occ_packed(q), o.query_packed(k, q))
+
+
+@pytest.mark.parametrize("name", ["tiny_k31", "k55_nh9_nb6", "k21_nh6_nb3"])
+def test_strings_the_packed_form_cannot_hold(name):
+    """kmer_to_occ(vector<string>) on raw strings: 'N', lower case and other bytes are hashed as they are and count
+    as 'A' only in the 2-bit conversions (tools.hpp:63-76, rest.hpp:22-34); other lengths skip the rest table
+    (rest.hpp:224-226).  The byte-string kernel must agree with the oracle -- and with the packed kernel on clean input."""
+    _, k, ci, cs, nh, nb, n = CASE[name]
+    km, cnt = synth.make_stream(n, k, ci, cs)
+    m = KModel(ci, cs, nh, nb)
+    m.build_packed(k, km, cnt)
+    o = O.OracleModel(ci, cs, nh, nb)
+    o.build(k, km, cnt)
+    rng = np.random.default_rng(5)
+    base = synth.to_strings(np.concatenate([km[:3000], synth.revcomp(km[3000:6000], k), synth.random_kmers(1000, k, seed_k=0xABCDEF0123)]), k)
+    dirty = []
+    for i, s in enumerate(base):
+        if i % 3 == 0:
+            dirty.append(s)                                   # clean strings inside an unclean batch
+            continue
+        b = list(s)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(0, k))] = str(rng.choice(list("NnacgtX-")))
+        dirty.append("".join(b))
+    got = np.array(m.kmer_to_occ(dirty), dtype=np.int32)
+    assert np.array_equal(got, o.query_strings(dirty))
+    clean_idx = np.arange(0, len(base), 3)
+    assert np.array_equal(got[clean_idx], m.kmer_to_occ_packed(synth.from_strings([base[i] for i in clean_idx], k).reshape(-1)))
+    for L in (k - 1, k - 2, min(k + 3, 64), 2, 9):
+        if L < 2 or L > 64 or L == k:
+            continue
+        strs = [(s * 3)[:L] for s in base[:2000]]
+        assert np.array_equal(np.array(m.kmer_to_occ(strs), dtype=np.int32), o.query_strings(strs)), L
