@@ -16,6 +16,12 @@ CASES = [
     ("k55_multiblock", 55, 1, 4095, 9, 6, 2000000),          # 1 full block (6*2^18) + partial, two-word k-mers
     ("k32_nb4", 32, 1, 1023, 7, 4, 50000),                   # k == 32 boundary, pre_len 4
 ]
+# KMC2-layout databases (what KMC 3 emits): bin-major listing, not globally sorted -> the insert order differs
+# name, k, ci, cs, nh, nb, n_draws, n_bins
+KMC2_CASES = [
+    ("k31_kmc2_6bins", 31, 1, 1023, 7, 5, 1600000, 6),
+    ("k55_kmc2_3bins", 55, 2, 4095, 9, 6, 40000, 3),
+]
 CASE = {c[0]: c for c in CASES}
 SMALL = ["tiny_k31", "k31_ci2_200k", "k55_nh9_nb6", "k21_nh6_nb3", "k32_nb4"]
 LARGE = ["k31_multiblock_ci1", "k31_multiblock_ci2", "k55_multiblock"]

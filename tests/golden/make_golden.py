@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402
 from kmcex_amd import kmcdb, synth  # noqa: E402
 
-from common import CASES, query_set, sha_file  # noqa: E402
+from common import CASES, KMC2_CASES, query_set, sha_file  # noqa: E402
 
 
 def main():
@@ -79,6 +79,35 @@ def main():
             with open(os.path.join(d, "queries.txt"), "w") as f:
                 f.write("\n".join(qs) + "\n")
             np.savetxt(os.path.join(d, "occ.txt"), r_ref, fmt="%d")
+        m.close()
+    out["kmc2_cases"] = {}
+    for name, k, ci, cs, nh, nb, n, n_bins in KMC2_CASES:
+        km, cnt = synth.make_stream(n, k, ci, cs)
+        db = os.path.join(tmp, name)
+        order = kmcdb.write_kmc2(db, km, cnt, k, ci, cs, n_bins=n_bins)
+        O.ref_build(db, db + ".ref", ci, cs, nh, nb)
+        W = synth.words_for_k(k)
+        lkm = km.reshape(len(cnt), -1)[order]
+        lkm = lkm[:, 0] if W == 1 else lkm
+        m = O.OracleModel(ci, cs, nh, nb)
+        m.build(k, np.ascontiguousarray(lkm), np.ascontiguousarray(cnt[order]))       # the listing order of the database
+        m.save(db + ".ora")
+        files = {}
+        for f in ("header", "km.bin", "rest.bin"):
+            a, b = sha_file(f"{db}.ref/{f}"), sha_file(f"{db}.ora/{f}")
+            if a != b:
+                sys.exit(f"{name}: oracle {f} differs from the reference")
+            files[f] = a
+        q = query_set(km, k)
+        r_ref = O.ref_query(db + ".ref", synth.to_strings(q, k), db)
+        if not np.array_equal(r_ref, m.query_packed(k, q)):
+            sys.exit(f"{name}: oracle kmer_to_occ differs from the reference")
+        st = m.stats()
+        out["kmc2_cases"][name] = {"k": k, "ci": ci, "cs": cs, "nh": nh, "nb": nb, "n_draws": n, "n_bins": n_bins, "sha256": files,
+                                   "occ_sha256": hashlib.sha256(r_ref.astype("<i4").tobytes()).hexdigest(),
+                                   "order_sha256": hashlib.sha256(order.astype("<i8").tobytes()).hexdigest(),
+                                   "stats": {"attempts": st.attempts, "successes": st.successes, "rest_entries": st.rest_entries}}
+        print(name, "ok", out["kmc2_cases"][name]["stats"], flush=True)
         m.close()
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

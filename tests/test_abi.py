@@ -60,6 +60,19 @@ def test_kmc_reader_lists_what_the_writer_wrote(tmp_path):
         api.kmc_list(str(tmp_path / "missing"))
 
 
+def test_kmc2_layout_lists_bin_major(tmp_path):
+    """KMC2 prefix files (per-bin LUTs, kmc_file.cpp:188-235, :449): the listing walks bin after bin."""
+    for k, ci, cs, n, n_bins in ((31, 1, 1023, 20000, 5), (55, 1, 4095, 4000, 3), (21, 2, 255, 2500, 16)):
+        km, cnt = synth.make_stream(n, k, ci, cs)
+        db = str(tmp_path / f"k2_{k}")
+        order = kmcdb.write_kmc2(db, km, cnt, k, ci, cs, n_bins=n_bins)
+        k2, total, okm, ocnt = api.kmc_list(db)
+        exp = km.reshape(len(cnt), -1)[order]
+        assert (k2, total) == (k, len(cnt))
+        assert np.array_equal(okm.reshape(exp.shape), exp) and np.array_equal(ocnt, cnt[order])
+        assert not np.array_equal(order, np.arange(len(order)))          # really not the sorted order
+
+
 def test_tiny_golden_database_lists_in_order():
     k, total, km, cnt = api.kmc_list(os.path.join(ROOT, "tests", "golden", "tiny", "db"))
     assert k == 31 and total == len(cnt) == 20000

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from common import CASE, LARGE, SMALL, query_set, sha_file, sha_occ
+from common import CASE, KMC2_CASES, LARGE, SMALL, query_set, sha_file, sha_occ
 from kmcex_amd import KModel, api, kmcdb, synth
 
 pytestmark = pytest.mark.gpu
@@ -256,3 +256,24 @@ def test_strings_the_packed_form_cannot_hold(name):
             continue
         strs = [(s * 3)[:L] for s in base[:2000]]
         assert np.array_equal(np.array(m.kmer_to_occ(strs), dtype=np.int32), o.query_strings(strs)), L
+
+
+@pytest.mark.parametrize("case", KMC2_CASES, ids=lambda c: c[0])
+def test_init_from_kmc2_database_unsorted_listing(case, golden, tmp_path):
+    """A KMC2-layout database (what KMC 3 emits) lists bin-major, i.e. NOT in sorted order; the ordered insert must follow
+    that order.  init(db) -> the files the reference wrote from the same database."""
+    name, k, ci, cs, nh, nb, n, n_bins = case
+    g = golden["kmc2_cases"][name]
+    km, cnt = synth.make_stream(n, k, ci, cs)
+    db = str(tmp_path / "db")
+    kmcdb.write_kmc2(db, km, cnt, k, ci, cs, n_bins=n_bins)
+    m = KModel(ci, cs, nh, nb)
+    m.init(db)
+    out = str(tmp_path / "m")
+    os.makedirs(out)
+    m.save(out)
+    for f in ("header", "km.bin", "rest.bin"):
+        assert sha_file(os.path.join(out, f)) == g["sha256"][f], f
+    st = m.stats()
+    assert (st.attempts, st.successes, st.rest_entries) == (g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
+    assert sha_occ(m.kmer_to_occ_packed(query_set(km, k))) == g["occ_sha256"]
