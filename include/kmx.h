@@ -122,7 +122,8 @@ int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double
 int kmx_set_profile(kmx_model *m, int on);
 int kmx_get_kernel_times(kmx_model *m, double *seconds, uint64_t *launches, int reset);
 
-/* timing of the last build, seconds measured with HIP events on the model's stream */
+/* timing of the last build with HIP events on the model's stream: total_s = whole build call;
+ * insert_kernels_s = time inside the insert kernels (only collected while kmx_set_profile is on, else 0) */
 int kmx_last_build_seconds(kmx_model *m, double *insert_kernels_s, double *total_s);
 
 #ifdef __cplusplus

@@ -127,17 +127,16 @@ template <int NHM> __device__ __forceinline__ bool touches_conflict(const ModelD
 
 // kmodel.hpp:611-618 + :548-550: set tag (and value) bits, then the (k-2)-mer goes into km_back
 template <int W, int NHM>
-__device__ __forceinline__ void commit_touches(const ModelDev &md, const Touches<NHM> &t, u32 bin, int a, const Aligned<W> &al, int dbg = 0)
+__device__ __forceinline__ void commit_touches(const ModelDev &md, const Touches<NHM> &t, u32 bin, int a, const Aligned<W> &al)
 {
 	u64 *cells = md.cells[a];
 #pragma unroll
 	for (int j = 0; j < NHM; j++)
-		if (j < md.nh && !(dbg & 1)) {
+		if (j < md.nh) {
 			u32 b = bit_in_cell(t.pos[j]);
 			if (!((t.cell[j] >> (16 + b)) & 1ULL))          // already tagged => already carries this value
 				atomicOr(cells + (t.pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
 		}
-	if (dbg & 2) return;
 	Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
 	bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
 }
@@ -315,41 +314,46 @@ __global__ __launch_bounds__(256) void k_block_init(BlockDev bd, int nb, int pp,
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_claim(ModelDev md, BlockDev bd, int t, int pp)
 {
 	__shared__ int s_fail;
-	if (threadIdx.x == 0) s_fail = 0;
-	__syncthreads();
-	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	const int i = blockIdx.y;
 	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
-	bool failed = false;
-	if (x < n) {
-		if (x == 0) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
-		const u32 raw = bd.list[pp][row + x];
-		const u32 idx = (raw & LIST_HOLE) ? bd.mover[pp][row + (raw & ~LIST_HOLE)] : raw;
-		if (raw & LIST_HOLE) bd.list[pp][row + x] = idx;            // later kernels of the round read plain entries
-		u64 v[W];
-		load_kmer<W>(bd.kmers, row + idx, v);
-		const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
-		const int a = (i + t) % md.nb;                                  // kmodel.hpp:563
-		Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
-		Touches<NHM> tc;
-		gather_touches<W, NHM, false>(md, pm, a, tc);
-		failed = touches_conflict<NHM>(md, tc, bin);
-		bd.status[row + x] = failed ? SLOT_FAILED : SLOT_UNDECIDED;
-		if (!failed) {
-			u64 *cells = md.cells[a];
+	const int a = (i + t) % md.nb;                                  // kmodel.hpp:563
+	if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
+	// grid-stride over the list: later rounds are launched with fewer workgroups (lists shrink round by round)
+	for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+		if (threadIdx.x == 0) s_fail = 0;
+		__syncthreads();
+		const int x = base + threadIdx.x;
+		bool failed = false;
+		if (x < n) {
+			const u32 raw = bd.list[pp][row + x];
+			const u32 idx = (raw & LIST_HOLE) ? bd.mover[pp][row + (raw & ~LIST_HOLE)] : raw;
+			if (raw & LIST_HOLE) bd.list[pp][row + x] = idx;            // later kernels of the round read plain entries
+			u64 v[W];
+			load_kmer<W>(bd.kmers, row + idx, v);
+			const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
+			Touches<NHM> tc;
+			gather_touches<W, NHM, false>(md, pm, a, tc);
+			failed = touches_conflict<NHM>(md, tc, bin);
+			bd.status[row + x] = failed ? SLOT_FAILED : SLOT_UNDECIDED;
+			if (!failed) {
+				u64 *cells = md.cells[a];
 #pragma unroll
-			for (int j = 0; j < NHM; j++)
-				if (j < md.nh) {
-					u32 b = bit_in_cell(tc.pos[j]);
-					if (!((tc.cell[j] >> (16 + b)) & 1ULL)) atomicOr(cells + (tc.pos[j] >> 4), CELL_CLAIM((bin >> j) & 1u, b));
-				}
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh) {
+						u32 b = bit_in_cell(tc.pos[j]);
+						if (!((tc.cell[j] >> (16 + b)) & 1ULL)) atomicOr(cells + (tc.pos[j] >> 4), CELL_CLAIM((bin >> j) & 1u, b));
+					}
+			}
 		}
+		// survivors are counted per 1024-slot tile as they fail, so the reorder needs no counting pass
+		const u64 mask = __ballot(failed);
+		if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&s_fail, (int)__popcll(mask));
+		__syncthreads();
+		if (threadIdx.x == 0 && s_fail) atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (base >> 10), s_fail);
+		__syncthreads();
 	}
-	// survivors are counted per 1024-slot tile as they fail, so the reorder needs no counting pass
-	const u64 mask = __ballot(failed);
-	if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&s_fail, (int)__popcll(mask));
-	__syncthreads();
-	if (threadIdx.x == 0 && s_fail) atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (blockIdx.x >> 2), s_fail);
 }
 
 // ------------------------------------------------------------------------------------------ S: ordered slow path (helpers)
@@ -423,38 +427,43 @@ template <int W> __device__ __forceinline__ void rec_load(const u64 *rec, u64 sl
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_verify_commit(ModelDev md, BlockDev bd, int t, int pp, u64 epoch)
 {
 	__shared__ int s_cnt, s_base;
-	if (threadIdx.x == 0) s_cnt = 0;
-	__syncthreads();
-	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	const int i = blockIdx.y;
+	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
-	const bool active = x < bd.n[pp][i] && bd.status[row + x] == SLOT_UNDECIDED;
-	bool contended = false;
-	u64 v[W];
-	u32 bin = 0;
-	if (active) {
-		const u32 idx = bd.list[pp][row + x];
-		load_kmer<W>(bd.kmers, row + idx, v);
-		bin = md.bin_of_occ[bd.counts[row + idx]];
-		const int a = (i + t) % md.nb;
-		Aligned<W> al = left_align<W>(v, md.k);
-		Premixed<W> pm = premix_string<W>(al, md.gfull);
-		Touches<NHM> tc;
-		gather_touches<W, NHM, false>(md, pm, a, tc);
+	const int a = (i + t) % md.nb;
+	for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+		if (threadIdx.x == 0) s_cnt = 0;
+		__syncthreads();
+		const int x = base + threadIdx.x;
+		const bool active = x < n && bd.status[row + x] == SLOT_UNDECIDED;
+		bool contended = false;
+		u64 v[W];
+		u32 bin = 0;
+		if (active) {
+			const u32 idx = bd.list[pp][row + x];
+			load_kmer<W>(bd.kmers, row + idx, v);
+			bin = md.bin_of_occ[bd.counts[row + idx]];
+			Aligned<W> al = left_align<W>(v, md.k);
+			Premixed<W> pm = premix_string<W>(al, md.gfull);
+			Touches<NHM> tc;
+			gather_touches<W, NHM, false>(md, pm, a, tc);
 #pragma unroll
-		for (int j = 0; j < NHM; j++)
-			if (j < md.nh) {
-				u32 b = bit_in_cell(tc.pos[j]);
-				u32 want = (bin >> j) & 1u;
-				bool tagged = (tc.cell[j] >> (16 + b)) & 1ULL;
-				contended |= !tagged && ((tc.cell[j] >> (32 + 16 * (1 - want) + b)) & 1ULL);
-			}
-		if (!contended) {
-			commit_touches<W, NHM>(md, tc, bin, a, al, bd.debug_flags);
-			bd.status[row + x] = SLOT_INSERTED;
-		} else reserve_untagged<NHM>(md, bd, i, tc, resv_key(epoch, (u32)x));
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh) {
+					u32 b = bit_in_cell(tc.pos[j]);
+					u32 want = (bin >> j) & 1u;
+					bool tagged = (tc.cell[j] >> (16 + b)) & 1ULL;
+					contended |= !tagged && ((tc.cell[j] >> (32 + 16 * (1 - want) + b)) & 1ULL);
+				}
+			if (!contended) {
+				commit_touches<W, NHM>(md, tc, bin, a, al);
+				bd.status[row + x] = SLOT_INSERTED;
+			} else reserve_untagged<NHM>(md, bd, i, tc, resv_key(epoch, (u32)x));
+		}
+		const int p = block_append_slot(bd.Un + UN_IDX(0, i, md.nb), contended, &s_cnt, &s_base);
+		if (contended) rec_store<W>(bd.Urec[0], row + p, (u32)x, bin, v);
+		__syncthreads();
 	}
-	const int p = block_append_slot(bd.Un + UN_IDX(0, i, md.nb), contended, &s_cnt, &s_base);
-	if (contended) rec_store<W>(bd.Urec[0], row + p, (u32)x, bin, v);
 }
 
 // ------------------------------------------------------------------------------------------ S: ordered slow path
@@ -1212,7 +1221,9 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	const int nb = md.nb;
 	if (nsub < 0) nsub = 0;
 	if (nsub > KMX_MAX_NSUB) nsub = KMX_MAX_NSUB;
-	const dim3 grid(KMX_BUCKET / 256, nb), blk(256), sgrid(SLOW_BLOCKS, nb);
+	// lists shrink by roughly half per round; the kernels are grid-stride, so a smaller grid is only a speed choice
+	const int gx = (KMX_BUCKET / 256) >> (t < 4 ? t : 4);
+	const dim3 grid(gx, nb), blk(256), sgrid(SLOW_BLOCKS, nb);
 	KPROF_BEGIN(prof, KC_CHECK_CLAIM, st);
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_claim<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
 	KPROF_END(prof, st);

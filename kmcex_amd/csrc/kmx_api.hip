@@ -154,7 +154,6 @@ struct kmx_model {
 	void *d_block_scratch = nullptr;
 	u64 scratch_bytes = 0;
 	int scratch_nb = 0, scratch_W = 0;
-	int *h_groups = nullptr;                                   // pinned
 	u64 *d_rest_kmers = nullptr;
 	int *d_rest_counts = nullptr;
 	unsigned long long *d_rest_n = nullptr;
@@ -434,7 +433,6 @@ extern "C" int kmx_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n
 		bd.Un = (int *)(base + o_Un); bd.R = (u64 *)(base + o_R);
 		bd.tile_cnt[0] = (int *)(base + o_tc0); bd.tile_cnt[1] = (int *)(base + o_tc1);
 		bd.stats = m->d_stats;
-		bd.debug_flags = getenv("KMX_DEBUG_FLAGS") ? atoi(getenv("KMX_DEBUG_FLAGS")) : 0;
 		TRY(dalloc(&m->d_rest_n, 1, false, m->stream));
 		TRY(dalloc(&m->d_stale_kmers, (u64)nb * 2, false, m->stream));
 		TRY(dalloc(&m->d_stale_counts, (u64)nb, false, m->stream));
@@ -763,7 +761,13 @@ extern "C" int kmx_finish(kmx_model *m)
 		m->state = ST_EMPTY;
 		return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)m->h_stats[ST_BAD_COUNT], m->ci, m->cs);
 	}
-	if (m->prof.on) prof_collect(m);
+	if (m->prof.on) {
+		double before = 0, after = 0;
+		for (int c = 0; c < KC_QUERY; c++) before += m->kc_seconds[c];
+		prof_collect(m);
+		for (int c = 0; c < KC_QUERY; c++) after += m->kc_seconds[c];
+		m->t_insert_kernels = after - before;                   // HIP-event time inside the insert kernels of this build
+	}
 	TRY(build_rest(m, n_rest));
 	fill_model_dev(m);
 	m->state = ST_READY;

@@ -58,7 +58,6 @@ struct BlockDev {
 	int *Un;                 // [KMX_NSLOW*nb*KMX_CTR_STRIDE], use UN_IDX
 	u64 *R;                  // [nb*KMX_RSIZE] epoch-tagged reservations
 	u64 *stats;              // [ST_N]
-	int debug_flags;         // timing experiments only (results become wrong): 1 skip cell commits, 2 skip km_back inserts
 };
 
 #define LIST_HOLE 0x80000000u
