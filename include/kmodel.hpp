@@ -15,6 +15,7 @@
 #ifndef KMODEL_H
 #define KMODEL_H
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <iostream>
@@ -41,15 +42,21 @@ public:
 		const size_t n = kmer_v.size();
 		std::vector<int> occ_v(n);
 		if (!n) return occ_v;
-		const int len = (int)kmer_v[0].size();
-		std::string flat;
-		flat.reserve(n * (size_t)len);
-		for (size_t i = 0; i < n; i++) {
-			if ((int)kmer_v[i].size() != len) die("kmer_to_occ: all k-mers of a batch must have the same length");
-			flat += kmer_v[i];
-		}
 		static_assert(sizeof(int) == sizeof(int32_t), "int is 32 bits on every supported target");
-		check(kmx_query_ascii(h_, flat.data(), len, len, n, reinterpret_cast<int32_t *>(occ_v.data())));
+		// the reference answers every string on its own, whatever its length: batch the strings of equal length
+		std::vector<size_t> order(n);
+		for (size_t i = 0; i < n; i++) order[i] = i;
+		std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return kmer_v[a].size() < kmer_v[b].size(); });
+		for (size_t lo = 0; lo < n;) {
+			const size_t len = kmer_v[order[lo]].size();
+			size_t hi = lo;
+			std::string flat;
+			while (hi < n && kmer_v[order[hi]].size() == len) flat += kmer_v[order[hi++]];
+			std::vector<int32_t> part(hi - lo);
+			check(kmx_query_ascii(h_, flat.data(), (int)len, (int)len, hi - lo, part.data()));
+			for (size_t j = lo; j < hi; j++) occ_v[order[j]] = part[j - lo];
+			lo = hi;
+		}
 		return occ_v;
 	}
 
@@ -89,7 +96,8 @@ public:
 		std::cout << "   kmercount hash map                 :     " << st.rest_entries << std::endl;
 		std::cout << "   memory bloomfilter                 :     " << bf / mb << "MB" << std::endl;
 		std::cout << "   memory bit array                   :     " << km / mb << "MB" << std::endl;
-		std::cout << "   total memory (without rest map)    :     " << (bf + km + st.byte_km_back) / mb << "MB" << std::endl;
+		std::cout << "   memory rest map                    :     " << st.rest_bytes / mb << "MB" << std::endl;
+		std::cout << "   total memory                       :     " << (bf + km + st.rest_bytes + st.byte_km_back) / mb << "MB" << std::endl;
 		std::cout << "   build time cost                    :     " << total_s << std::endl;
 	}
 

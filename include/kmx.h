@@ -50,6 +50,7 @@ typedef struct kmx_stats {
 	uint64_t blocks, rounds;  /* nb*2^18 blocks and rounds executed                             */
 	int32_t  k, ci, cs, nh, nb, bf_num;
 	int32_t  device, reserved;
+	uint64_t rest_bytes;      /* KRestData::get_all_byte_size (rest.hpp:257-259)                */
 } kmx_stats;
 
 const char *kmx_last_error(void);

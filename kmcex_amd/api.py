@@ -30,7 +30,7 @@ class Stats(C.Structure):
                 ("fast_commits", C.c_uint64), ("contended", C.c_uint64), ("finisher_iters", C.c_uint64),
                 ("blocks", C.c_uint64), ("rounds", C.c_uint64),
                 ("k", C.c_int32), ("ci", C.c_int32), ("cs", C.c_int32), ("nh", C.c_int32), ("nb", C.c_int32),
-                ("bf_num", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
+                ("bf_num", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32), ("rest_bytes", C.c_uint64)]
 
 
 # every symbol include/kmx.h declares (tests check that the library exports all of them)
@@ -213,11 +213,14 @@ class KModel:
         strs = [kmers] if single else list(kmers)
         if not strs:
             return []
-        ln = len(strs[0])
-        if any(len(s) != ln for s in strs):
-            raise KmxError(-1, "all k-mers of a batch must have the model's k")
         out = np.zeros(len(strs), dtype=np.int32)
-        _chk(self.L.kmx_query_ascii(self.h, "".join(strs).encode(), ln, ln, len(strs), out.ctypes.data))
+        by_len = {}
+        for i, s in enumerate(strs):                           # the reference answers every string on its own
+            by_len.setdefault(len(s), []).append(i)
+        for ln, idx in by_len.items():
+            part = np.zeros(len(idx), dtype=np.int32)
+            _chk(self.L.kmx_query_ascii(self.h, "".join(strs[i] for i in idx).encode("latin-1"), ln, ln, len(idx), part.ctypes.data))
+            out[idx] = part
         return int(out[0]) if single else out.tolist()
 
     def kmer_to_occ_packed(self, kmers: np.ndarray) -> np.ndarray:

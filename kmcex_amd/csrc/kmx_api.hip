@@ -1171,6 +1171,7 @@ extern "C" int kmx_get_stats(kmx_model *m, kmx_stats *st)
 	st->fast_commits = m->h_stats[ST_SUCCESSES] - m->h_stats[ST_SLOW_SUCC]; st->contended = m->h_stats[ST_CONTENDED]; st->finisher_iters = m->h_stats[ST_FIN_ITERS];
 	st->rest_entries = m->rest.entries; st->km_byte_size = m->km_byte_size; st->byte_km_back = m->byte_km_back;
 	st->blocks = m->blocks; st->rounds = m->rounds;
+	st->rest_bytes = m->rest.suff_bin_size + 4 * m->rest.entries + 4 * (u64)m->rest.pre_buffer_size + 4 * (u64)m->rest.map_size;
 	st->k = m->k; st->ci = m->ci; st->cs = m->cs; st->nh = m->nh; st->nb = m->nb; st->bf_num = m->bf_num; st->device = m->device;
 	return KMX_OK;
 }

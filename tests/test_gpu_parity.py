@@ -251,6 +251,9 @@ def test_strings_the_packed_form_cannot_hold(name):
     assert np.array_equal(got, o.query_strings(dirty))
     clean_idx = np.arange(0, len(base), 3)
     assert np.array_equal(got[clean_idx], m.kmer_to_occ_packed(synth.from_strings([base[i] for i in clean_idx], k).reshape(-1)))
+    ragged = [dirty[0], dirty[1][:-1], dirty[2][:-2], dirty[3], (dirty[4] * 2)[:min(k + 5, 64)], "AC"]
+    exp = [int(o.query_strings([s])[0]) for s in ragged]
+    assert m.kmer_to_occ(ragged) == exp                       # one batch, several lengths
     for L in (k - 1, k - 2, min(k + 3, 64), 2, 9):
         if L < 2 or L > 64 or L == k:
             continue
