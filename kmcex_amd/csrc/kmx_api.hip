@@ -8,6 +8,8 @@
 #include "kmx_types.h"
 
 #include <algorithm>
+#include <exception>
+#include <new>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -58,7 +60,7 @@ static int fail(int code, const char *fmt, ...)
 
 extern "C" const char *kmx_last_error(void) { return g_err; }
 
-extern "C" int kmx_device_count(void)
+static int kmx_device_count_impl(void)
 {
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -100,7 +102,7 @@ static int occubin_tables(int cs, int nh, std::vector<u32> &bin_of_occ, std::vec
 	return 0;
 }
 
-extern "C" int kmx_occubin(int cs, int nh, uint32_t *bin_of_occ, uint32_t *mean_of_bin)
+static int kmx_occubin_impl(int cs, int nh, uint32_t *bin_of_occ, uint32_t *mean_of_bin)
 {
 	if (nh < 3 || nh > KMX_MAX_NH || cs < 1) return fail(KMX_E_ARG, "bad cs/nh");
 	std::vector<u32> b, m;
@@ -276,7 +278,7 @@ static void free_arrays(kmx_model *m)
 	free_rest_dev(m->rest);
 }
 
-extern "C" int kmx_create(int ci, int cs, int nh, int nb, kmx_model **out)
+static int kmx_create_impl(int ci, int cs, int nh, int nb, kmx_model **out)
 {
 	if (!out) return fail(KMX_E_ARG, "null out");
 	*out = nullptr;
@@ -310,7 +312,7 @@ extern "C" int kmx_create(int ci, int cs, int nh, int nb, kmx_model **out)
 	return KMX_OK;
 }
 
-extern "C" int kmx_destroy(kmx_model *m)
+static int kmx_destroy_impl(kmx_model *m)
 {
 	if (!m) return KMX_OK;
 	hipSetDevice(m->device);
@@ -332,7 +334,7 @@ extern "C" int kmx_destroy(kmx_model *m)
 	return KMX_OK;
 }
 
-extern "C" int kmx_set_stream(kmx_model *m, void *s)
+static int kmx_set_stream_impl(kmx_model *m, void *s)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	m->stream = (hipStream_t)s;
@@ -387,7 +389,7 @@ static int alloc_arrays(kmx_model *m)
 }
 
 // ------------------------------------------------------------------------------------------ streamed build
-extern "C" int kmx_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total)
+static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (k < 3 || k > 64) return fail(KMX_E_ARG, "k=%d out of range [3,64]", k);
@@ -553,7 +555,7 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 // ONE launch on a side stream, underneath the ordered coupled-array rounds of the earlier chunks, which leave the
 // memory system idle in their latency-bound tails.  The compaction into the staging stream and the rounds stay in
 // order on the model's stream.
-extern "C" int kmx_insert_batch_dev(kmx_model *m, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n)
+static int kmx_insert_batch_dev_impl(kmx_model *m, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (m->state != ST_BUILDING) return fail(KMX_E_STATE, "insert_batch before begin");
@@ -625,7 +627,7 @@ extern "C" int kmx_insert_batch_dev(kmx_model *m, const uint64_t *d_kmers, const
 	return KMX_OK;
 }
 
-extern "C" int kmx_insert_batch(kmx_model *m, const uint64_t *kmers, const uint32_t *counts, uint64_t n)
+static int kmx_insert_batch_impl(kmx_model *m, const uint64_t *kmers, const uint32_t *counts, uint64_t n)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (m->state != ST_BUILDING) return fail(KMX_E_STATE, "insert_batch before begin");
@@ -746,7 +748,7 @@ static int rest_to_device(kmx_model *m)
 	return rest_build_accel(m);
 }
 
-extern "C" int kmx_finish(kmx_model *m)
+static int kmx_finish_impl(kmx_model *m)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (m->state != ST_BUILDING) return fail(KMX_E_STATE, "finish before begin");
@@ -797,14 +799,14 @@ static int build_common(kmx_model *m, int k, const u64 *d_kmers, const u32 *d_co
 	return KMX_OK;
 }
 
-extern "C" int kmx_build_dev(kmx_model *m, int k, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n)
+static int kmx_build_dev_impl(kmx_model *m, int k, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (k < 3 || k > 64) return fail(KMX_E_ARG, "k=%d out of range [3,64]", k);
 	return build_common(m, k, (const u64 *)d_kmers, (const u32 *)d_counts, n, n);
 }
 
-extern "C" int kmx_build_host(kmx_model *m, int k, const uint64_t *kmers, const uint32_t *counts, uint64_t n)
+static int kmx_build_host_impl(kmx_model *m, int k, const uint64_t *kmers, const uint32_t *counts, uint64_t n)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (k < 3 || k > 64) return fail(KMX_E_ARG, "k=%d out of range [3,64]", k);
@@ -834,7 +836,7 @@ struct FeedSlot {
 };
 }   // namespace
 
-extern "C" int kmx_build_from_kmc(kmx_model *m, const char *db_prefix)
+static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 {
 	if (!m || !db_prefix) return fail(KMX_E_ARG, "null argument");
 	kmx::KmcListing db;
@@ -901,7 +903,7 @@ extern "C" int kmx_build_from_kmc(kmx_model *m, const char *db_prefix)
 }
 
 // ------------------------------------------------------------------------------------------ KMC listing (host only)
-extern "C" int kmx_kmc_info(const char *db_prefix, int *k, uint64_t *total_kmers)
+static int kmx_kmc_info_impl(const char *db_prefix, int *k, uint64_t *total_kmers)
 {
 	if (!db_prefix) return fail(KMX_E_ARG, "null argument");
 	kmx::KmcListing db;
@@ -911,7 +913,7 @@ extern "C" int kmx_kmc_info(const char *db_prefix, int *k, uint64_t *total_kmers
 	return KMX_OK;
 }
 
-extern "C" int kmx_kmc_read(const char *db_prefix, uint64_t *kmers, uint32_t *counts, uint64_t capacity, uint64_t *n_read)
+static int kmx_kmc_read_impl(const char *db_prefix, uint64_t *kmers, uint32_t *counts, uint64_t capacity, uint64_t *n_read)
 {
 	if (!db_prefix || !kmers || !counts || !n_read) return fail(KMX_E_ARG, "null argument");
 	kmx::KmcListing db;
@@ -924,7 +926,7 @@ extern "C" int kmx_kmc_read(const char *db_prefix, uint64_t *kmers, uint32_t *co
 }
 
 // ------------------------------------------------------------------------------------------ query
-extern "C" int kmx_query_packed_dev(kmx_model *m, const uint64_t *d_kmers, uint64_t n, int32_t *d_out)
+static int kmx_query_packed_dev_impl(kmx_model *m, const uint64_t *d_kmers, uint64_t n, int32_t *d_out)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (m->state != ST_READY) return fail(KMX_E_STATE, "query before the model is built or loaded");
@@ -934,7 +936,7 @@ extern "C" int kmx_query_packed_dev(kmx_model *m, const uint64_t *d_kmers, uint6
 	return KMX_OK;
 }
 
-extern "C" int kmx_query_packed(kmx_model *m, const uint64_t *kmers, uint64_t n, int32_t *out)
+static int kmx_query_packed_impl(kmx_model *m, const uint64_t *kmers, uint64_t n, int32_t *out)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (m->state != ST_READY) return fail(KMX_E_STATE, "query before the model is built or loaded");
@@ -955,7 +957,7 @@ extern "C" int kmx_query_packed(kmx_model *m, const uint64_t *kmers, uint64_t n,
 // vector<string> front door (kmodel.hpp:90-116).  Strings of the model's k that hold only ACGT are packed on the host
 // (2 bits/base) and take the packed kernel; anything else -- other characters, another length -- is answered by the
 // byte-string kernel, which hashes the bytes as they are, exactly like the reference does.
-extern "C" int kmx_query_ascii(kmx_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out)
+static int kmx_query_ascii_impl(kmx_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (m->state != ST_READY) return fail(KMX_E_STATE, "query before the model is built or loaded");
@@ -1025,7 +1027,7 @@ static int download_array(kmx_model *m, int which, int index, std::vector<unsign
 	return KMX_OK;
 }
 
-extern "C" int kmx_download(kmx_model *m, int which, int index, uint8_t *dst, uint64_t capacity, uint64_t *written)
+static int kmx_download_impl(kmx_model *m, int which, int index, uint8_t *dst, uint64_t capacity, uint64_t *written)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (m->state == ST_EMPTY) return fail(KMX_E_STATE, "no arrays yet");
@@ -1040,7 +1042,7 @@ extern "C" int kmx_download(kmx_model *m, int which, int index, uint8_t *dst, ui
 }
 
 // KModel::save (kmodel.hpp:173-206) + KRestData::save_file (rest.hpp:197-221); layouts: Appendix B.1/B.2
-extern "C" int kmx_save(kmx_model *m, const char *dir)
+static int kmx_save_impl(kmx_model *m, const char *dir)
 {
 	if (!m || !dir) return fail(KMX_E_ARG, "null argument");
 	if (m->state != ST_READY) return fail(KMX_E_STATE, "save before the model is built or loaded");
@@ -1083,7 +1085,7 @@ extern "C" int kmx_save(kmx_model *m, const char *dir)
 }
 
 // get_model(save_dir) (kmodel.hpp:680-696) + KModel::load (:209-235) + KRestData::from_file (rest.hpp:163-195)
-extern "C" int kmx_load(const char *dir, kmx_model **out)
+static int kmx_load_impl(const char *dir, kmx_model **out)
 {
 	if (!dir || !out) return fail(KMX_E_ARG, "null argument");
 	*out = nullptr;
@@ -1161,7 +1163,7 @@ extern "C" int kmx_load(const char *dir, kmx_model **out)
 	return KMX_OK;
 }
 
-extern "C" int kmx_get_stats(kmx_model *m, kmx_stats *st)
+static int kmx_get_stats_impl(kmx_model *m, kmx_stats *st)
 {
 	if (!m || !st) return fail(KMX_E_ARG, "null argument");
 	memset(st, 0, sizeof *st);
@@ -1176,7 +1178,7 @@ extern "C" int kmx_get_stats(kmx_model *m, kmx_stats *st)
 	return KMX_OK;
 }
 
-extern "C" int kmx_last_build_seconds(kmx_model *m, double *insert_kernels_s, double *total_s)
+static int kmx_last_build_seconds_impl(kmx_model *m, double *insert_kernels_s, double *total_s)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (insert_kernels_s) *insert_kernels_s = m->t_insert_kernels;
@@ -1185,7 +1187,7 @@ extern "C" int kmx_last_build_seconds(kmx_model *m, double *insert_kernels_s, do
 }
 
 // ------------------------------------------------------------------------------------------ KAT surface / microbench
-extern "C" int kmx_debug_hash(int k, const uint64_t *kmers, uint64_t n, const uint32_t *seeds, int n_seeds, int whole, uint64_t *hashes)
+static int kmx_debug_hash_impl(int k, const uint64_t *kmers, uint64_t n, const uint32_t *seeds, int n_seeds, int whole, uint64_t *hashes)
 {
 	if (k < 3 || k > 64 || n_seeds < 1) return fail(KMX_E_ARG, "bad arguments");
 	const int W = (k + 31) / 32;
@@ -1202,7 +1204,7 @@ extern "C" int kmx_debug_hash(int k, const uint64_t *kmers, uint64_t n, const ui
 	return KMX_OK;
 }
 
-extern "C" int kmx_debug_min_kmer(int k, const uint64_t *kmers, uint64_t n, uint64_t *out)
+static int kmx_debug_min_kmer_impl(int k, const uint64_t *kmers, uint64_t n, uint64_t *out)
 {
 	if (k < 3 || k > 64) return fail(KMX_E_ARG, "bad arguments");
 	const int W = (k + 31) / 32;
@@ -1216,7 +1218,7 @@ extern "C" int kmx_debug_min_kmer(int k, const uint64_t *kmers, uint64_t n, uint
 	return KMX_OK;
 }
 
-extern "C" int kmx_debug_mod(const uint64_t *h, uint64_t n, uint64_t d, uint64_t *out)
+static int kmx_debug_mod_impl(const uint64_t *h, uint64_t n, uint64_t d, uint64_t *out)
 {
 	if (!d || !n) return fail(KMX_E_ARG, "bad arguments");
 	u64 *dh = nullptr, *dout = nullptr;
@@ -1229,7 +1231,7 @@ extern "C" int kmx_debug_mod(const uint64_t *h, uint64_t n, uint64_t d, uint64_t
 	return KMX_OK;
 }
 
-extern "C" int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds)
+static int kmx_microbench_impl(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds)
 {
 	if (bytes < 4096 || touches < 8 || iters < 1 || !seconds) return fail(KMX_E_ARG, "bad arguments");
 	u64 *buf = nullptr, *sink = nullptr;
@@ -1254,14 +1256,14 @@ extern "C" int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int it
 }
 
 // ------------------------------------------------------------------------------------------ kernel-class timing
-extern "C" int kmx_set_profile(kmx_model *m, int on)
+static int kmx_set_profile_impl(kmx_model *m, int on)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	m->prof.on = on != 0;
 	return KMX_OK;
 }
 
-extern "C" int kmx_get_kernel_times(kmx_model *m, double *seconds, uint64_t *launches, int reset)
+static int kmx_get_kernel_times_impl(kmx_model *m, double *seconds, uint64_t *launches, int reset)
 {
 	if (!m || !seconds || !launches) return fail(KMX_E_ARG, "null argument");
 	HIPCHK(hipSetDevice(m->device));
@@ -1271,3 +1273,42 @@ extern "C" int kmx_get_kernel_times(kmx_model *m, double *seconds, uint64_t *lau
 	if (reset) for (int c = 0; c < KC_N; c++) { m->kc_seconds[c] = 0; m->kc_launches[c] = 0; }
 	return KMX_OK;
 }
+
+// ------------------------------------------------------------------------------------------ exception firewall
+// Nothing may unwind through the C ABI: every entry point runs its implementation inside this guard.
+template <typename F> static int guarded(F f)
+{
+	try { return f(); }
+	catch (const std::bad_alloc &) { return fail(KMX_E_NOMEM, "out of host memory"); }
+	catch (const std::exception &e) { return fail(KMX_E_ARG, "internal error: %s", e.what()); }
+	catch (...) { return fail(KMX_E_ARG, "internal error"); }
+}
+
+extern "C" int kmx_device_count(void) { return guarded([&] { return kmx_device_count_impl(); }); }
+extern "C" int kmx_occubin(int cs, int nh, uint32_t *bin_of_occ, uint32_t *mean_of_bin) { return guarded([&] { return kmx_occubin_impl(cs, nh, bin_of_occ, mean_of_bin); }); }
+extern "C" int kmx_create(int ci, int cs, int nh, int nb, kmx_model **out) { return guarded([&] { return kmx_create_impl(ci, cs, nh, nb, out); }); }
+extern "C" int kmx_destroy(kmx_model *m) { return guarded([&] { return kmx_destroy_impl(m); }); }
+extern "C" int kmx_set_stream(kmx_model *m, void *s) { return guarded([&] { return kmx_set_stream_impl(m, s); }); }
+extern "C" int kmx_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total) { return guarded([&] { return kmx_begin_impl(m, k, n_bf, n_total); }); }
+extern "C" int kmx_insert_batch_dev(kmx_model *m, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n) { return guarded([&] { return kmx_insert_batch_dev_impl(m, d_kmers, d_counts, n); }); }
+extern "C" int kmx_insert_batch(kmx_model *m, const uint64_t *kmers, const uint32_t *counts, uint64_t n) { return guarded([&] { return kmx_insert_batch_impl(m, kmers, counts, n); }); }
+extern "C" int kmx_finish(kmx_model *m) { return guarded([&] { return kmx_finish_impl(m); }); }
+extern "C" int kmx_build_dev(kmx_model *m, int k, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n) { return guarded([&] { return kmx_build_dev_impl(m, k, d_kmers, d_counts, n); }); }
+extern "C" int kmx_build_host(kmx_model *m, int k, const uint64_t *kmers, const uint32_t *counts, uint64_t n) { return guarded([&] { return kmx_build_host_impl(m, k, kmers, counts, n); }); }
+extern "C" int kmx_build_from_kmc(kmx_model *m, const char *db_prefix) { return guarded([&] { return kmx_build_from_kmc_impl(m, db_prefix); }); }
+extern "C" int kmx_kmc_info(const char *db_prefix, int *k, uint64_t *total_kmers) { return guarded([&] { return kmx_kmc_info_impl(db_prefix, k, total_kmers); }); }
+extern "C" int kmx_kmc_read(const char *db_prefix, uint64_t *kmers, uint32_t *counts, uint64_t capacity, uint64_t *n_read) { return guarded([&] { return kmx_kmc_read_impl(db_prefix, kmers, counts, capacity, n_read); }); }
+extern "C" int kmx_query_packed_dev(kmx_model *m, const uint64_t *d_kmers, uint64_t n, int32_t *d_out) { return guarded([&] { return kmx_query_packed_dev_impl(m, d_kmers, n, d_out); }); }
+extern "C" int kmx_query_packed(kmx_model *m, const uint64_t *kmers, uint64_t n, int32_t *out) { return guarded([&] { return kmx_query_packed_impl(m, kmers, n, out); }); }
+extern "C" int kmx_query_ascii(kmx_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out) { return guarded([&] { return kmx_query_ascii_impl(m, strs, len, stride, n, out); }); }
+extern "C" int kmx_download(kmx_model *m, int which, int index, uint8_t *dst, uint64_t capacity, uint64_t *written) { return guarded([&] { return kmx_download_impl(m, which, index, dst, capacity, written); }); }
+extern "C" int kmx_save(kmx_model *m, const char *dir) { return guarded([&] { return kmx_save_impl(m, dir); }); }
+extern "C" int kmx_load(const char *dir, kmx_model **out) { return guarded([&] { return kmx_load_impl(dir, out); }); }
+extern "C" int kmx_get_stats(kmx_model *m, kmx_stats *st) { return guarded([&] { return kmx_get_stats_impl(m, st); }); }
+extern "C" int kmx_last_build_seconds(kmx_model *m, double *insert_kernels_s, double *total_s) { return guarded([&] { return kmx_last_build_seconds_impl(m, insert_kernels_s, total_s); }); }
+extern "C" int kmx_debug_hash(int k, const uint64_t *kmers, uint64_t n, const uint32_t *seeds, int n_seeds, int whole, uint64_t *hashes) { return guarded([&] { return kmx_debug_hash_impl(k, kmers, n, seeds, n_seeds, whole, hashes); }); }
+extern "C" int kmx_debug_min_kmer(int k, const uint64_t *kmers, uint64_t n, uint64_t *out) { return guarded([&] { return kmx_debug_min_kmer_impl(k, kmers, n, out); }); }
+extern "C" int kmx_debug_mod(const uint64_t *h, uint64_t n, uint64_t d, uint64_t *out) { return guarded([&] { return kmx_debug_mod_impl(h, n, d, out); }); }
+extern "C" int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds) { return guarded([&] { return kmx_microbench_impl(mode, bytes, touches, iters, seconds); }); }
+extern "C" int kmx_set_profile(kmx_model *m, int on) { return guarded([&] { return kmx_set_profile_impl(m, on); }); }
+extern "C" int kmx_get_kernel_times(kmx_model *m, double *seconds, uint64_t *launches, int reset) { return guarded([&] { return kmx_get_kernel_times_impl(m, seconds, launches, reset); }); }
