@@ -163,3 +163,21 @@ def from_strings(strs, k: int) -> np.ndarray:
         w = W - 1 - bit // 64
         out[:, w] |= code[arr[:, pos]] << np.uint64(bit % 64)
     return out[:, 0] if W == 1 else out
+
+
+def genome_stream(n_bases: int, k: int, ci: int, cs: int, seed: int = 11, seed_c: int = 2):
+    """Genome-like stream: all overlapping k-mers of a random sequence, canonicalised, distinct, in listing order.
+
+    Unlike independent draws these k-mers have their de Bruijn neighbours in the set, which is what the query's
+    neighbour-based disambiguation (kmodel.hpp:286-359) feeds on."""
+    assert k <= 32
+    rng = np.random.default_rng(seed)
+    bases = rng.integers(0, 4, size=n_bases, dtype=np.uint64)
+    n = n_bases - k + 1
+    v = np.zeros(n, dtype=np.uint64)
+    for j in range(k):
+        v = (v << np.uint64(2)) | bases[j:j + n]
+    if k < 32:
+        v &= np.uint64((1 << (2 * k)) - 1)
+    km = sort_unique(canonical(v, k))
+    return km, d1_counts(len(km), ci, cs, seed_c)

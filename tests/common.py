@@ -22,6 +22,11 @@ KMC2_CASES = [
     ("k31_kmc2_6bins", 31, 1, 1023, 7, 5, 1600000, 6),
     ("k55_kmc2_3bins", 55, 2, 4095, 9, 6, 40000, 3),
 ]
+# genome-like streams (overlapping k-mers of a random sequence): name, k, ci, cs, nh, nb, n_bases
+GENOME_CASES = [
+    ("genome_k31_ci1", 31, 1, 1023, 7, 5, 400000),
+    ("genome_k27_ci2", 27, 2, 1023, 7, 4, 250000),
+]
 CASE = {c[0]: c for c in CASES}
 SMALL = ["tiny_k31", "k31_ci2_200k", "k55_nh9_nb6", "k21_nh6_nb3", "k32_nb4"]
 LARGE = ["k31_multiblock_ci1", "k31_multiblock_ci2", "k55_multiblock"]
@@ -40,6 +45,16 @@ def query_set(km, k, seed=7, max_present=MAX_PRESENT):
     q[:h] = synth.revcomp(q[:h], k)
     absent = synth.random_kmers(max(len(q) // 10, 10), k, seed_k=ABSENT_SEED)
     return np.concatenate([q, absent])
+
+
+def genome_query_set(km, k):
+    """every stored k-mer (half reverse-complemented) + all 8 de Bruijn neighbours of a sample (mostly absent)"""
+    q = km.copy()
+    q[::2] = synth.revcomp(q[::2], k)
+    s = km[::5]
+    mask = np.uint64((1 << (2 * k)) - 1) if k < 32 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    nb = [((s << np.uint64(2)) | np.uint64(x)) & mask for x in range(4)] + [(s >> np.uint64(2)) | (np.uint64(x) << np.uint64(2 * (k - 1))) for x in range(4)]
+    return np.concatenate([q] + nb)
 
 
 def sha_file(p):

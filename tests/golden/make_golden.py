@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402
 from kmcex_amd import kmcdb, synth  # noqa: E402
 
-from common import CASES, KMC2_CASES, query_set, sha_file  # noqa: E402
+from common import CASES, GENOME_CASES, KMC2_CASES, genome_query_set, query_set, sha_file  # noqa: E402
 
 
 def main():
@@ -108,6 +108,31 @@ def main():
                                    "order_sha256": hashlib.sha256(order.astype("<i8").tobytes()).hexdigest(),
                                    "stats": {"attempts": st.attempts, "successes": st.successes, "rest_entries": st.rest_entries}}
         print(name, "ok", out["kmc2_cases"][name]["stats"], flush=True)
+        m.close()
+    out["genome_cases"] = {}
+    for name, k, ci, cs, nh, nb, n_bases in GENOME_CASES:
+        km, cnt = synth.genome_stream(n_bases, k, ci, cs)
+        db = os.path.join(tmp, name)
+        kmcdb.write_kmc1(db, km, cnt, k, ci, cs)
+        O.ref_build(db, db + ".ref", ci, cs, nh, nb)
+        m = O.OracleModel(ci, cs, nh, nb)
+        m.build(k, km, cnt)
+        m.save(db + ".ora")
+        files = {}
+        for f in ("header", "km.bin", "rest.bin"):
+            a, b = sha_file(f"{db}.ref/{f}"), sha_file(f"{db}.ora/{f}")
+            if a != b:
+                sys.exit(f"{name}: oracle {f} differs from the reference")
+            files[f] = a
+        q = genome_query_set(km, k)
+        r_ref = O.ref_query(db + ".ref", synth.to_strings(q, k), db)
+        if not np.array_equal(r_ref, m.query_packed(k, q)):
+            sys.exit(f"{name}: oracle kmer_to_occ differs from the reference")
+        out["genome_cases"][name] = {"k": k, "ci": ci, "cs": cs, "nh": nh, "nb": nb, "n_bases": n_bases, "n_kmers": int(len(cnt)),
+                                     "sha256": files, "n_queries": int(len(q)),
+                                     "occ_sha256": hashlib.sha256(r_ref.astype("<i4").tobytes()).hexdigest(),
+                                     "occ_nonzero": int((r_ref != 0).sum())}
+        print(name, "ok", len(cnt), "k-mers,", len(q), "queries,", out["genome_cases"][name]["occ_nonzero"], "non-zero", flush=True)
         m.close()
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

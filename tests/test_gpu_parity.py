@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from common import CASE, KMC2_CASES, LARGE, SMALL, query_set, sha_file, sha_occ
+from common import CASE, GENOME_CASES, KMC2_CASES, LARGE, SMALL, genome_query_set, query_set, sha_file, sha_occ
 from kmcex_amd import KModel, api, kmcdb, synth
 
 pytestmark = pytest.mark.gpu
@@ -280,3 +280,29 @@ def test_init_from_kmc2_database_unsorted_listing(case, golden, tmp_path):
     st = m.stats()
     assert (st.attempts, st.successes, st.rest_entries) == (g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
     assert sha_occ(m.kmer_to_occ_packed(query_set(km, k))) == g["occ_sha256"]
+
+
+@pytest.mark.parametrize("case", GENOME_CASES, ids=lambda c: c[0])
+def test_genome_like_stream_neighbour_path(case, golden, tmp_path):
+    """Overlapping k-mers of a sequence: the de Bruijn neighbours of a stored k-mer are stored too, so the query's
+    neighbour-based disambiguation (kmodel.hpp:286-359) is exercised for real.  Files and answers = the reference's."""
+    name, k, ci, cs, nh, nb, n_bases = case
+    g = golden["genome_cases"][name]
+    km, cnt = synth.genome_stream(n_bases, k, ci, cs)
+    assert len(cnt) == g["n_kmers"]
+    m = KModel(ci, cs, nh, nb)
+    m.build_packed(k, km, cnt)
+    out = str(tmp_path / "m")
+    os.makedirs(out)
+    m.save(out)
+    for f in ("header", "km.bin", "rest.bin"):
+        assert sha_file(os.path.join(out, f)) == g["sha256"][f], f
+    q = genome_query_set(km, k)
+    occ = m.kmer_to_occ_packed(q)
+    assert sha_occ(occ) == g["occ_sha256"]
+    o = O.OracleModel(ci, cs, nh, nb)
+    o.build(k, km, cnt)
+    assert np.array_equal(occ, o.query_packed(k, q))
+    strs = synth.to_strings(q[:20000], k)                       # the raw-string kernel takes the same neighbour path
+    dirty = [s if i % 2 else s[:7] + "N" + s[8:] for i, s in enumerate(strs)]
+    assert np.array_equal(np.array(m.kmer_to_occ(dirty), dtype=np.int32), o.query_strings(dirty))
