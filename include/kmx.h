@@ -112,8 +112,10 @@ int kmx_debug_mod(const uint64_t *h, uint64_t n, uint64_t d, uint64_t *out);
 /* OccuBin tables (occu_bin.hpp:27-83): bin_of_occ[cs+1], mean_of_bin[2^nh]                         */
 int kmx_occubin(int cs, int nh, uint32_t *bin_of_occ, uint32_t *mean_of_bin);
 
-/* Random-access ceiling of the memory system for this access pattern: `touches` random
- * 8-byte loads (mode 0) or 64-bit atomic ORs (mode 1) over `bytes` of device memory; seconds out.  */
+/* Random-access ceiling of the memory system for this access pattern: `touches` random touches over
+ * `bytes` of device memory, 8 per lane like one k-mer on one array; seconds per launch out.  mode: 0 8-byte loads,
+ * 1 64-bit atomic OR (agent scope, what the insert uses), 2 byte stores, 3 byte loads, 4 8-byte stores,
+ * 5 32-bit atomic OR, 6 64-bit atomic OR at workgroup scope, 7 64-bit atomic OR returning the old word.       */
 int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds);
 
 /* Per-kernel-class timing with HIP events recorded on the model's stream around each launch (off by default).

@@ -1159,6 +1159,29 @@ __global__ __launch_bounds__(256) void k_micro_atomic_or32(u32 *buf, u64 nword, 
 	}
 }
 
+__global__ __launch_bounds__(256) void k_micro_atomic_or_wg(u64 *buf, u64 ncell, u64 n_lanes, u64 salt)
+{
+	u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_lanes) return;
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		u64 r = splitmix(i * 8 + j + salt);
+		__hip_atomic_fetch_or(buf + r % ncell, 1ULL << (r >> 58), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+}
+__global__ __launch_bounds__(256) void k_micro_atomic_or_ret(u64 *buf, u64 ncell, u64 n_lanes, u64 salt, u64 *sink)
+{
+	u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_lanes) return;
+	u64 acc = 0;
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		u64 r = splitmix(i * 8 + j + salt);
+		acc ^= atomicOr(buf + r % ncell, 1ULL << (r >> 58));
+	}
+	if (acc == 0x123456789ULL) *sink = acc;
+}
+
 // ------------------------------------------------------------------------------------------ launchers
 namespace kmxk {
 
@@ -1301,7 +1324,9 @@ void micro(int mode, u64 *buf, u64 ncell, u64 n_lanes, u64 salt, u64 *sink, hipS
 	else if (mode == 2) hipLaunchKernelGGL(k_micro_byte_store, grid, dim3(256), 0, st, (unsigned char *)buf, ncell * 8, n_lanes, salt);
 	else if (mode == 3) hipLaunchKernelGGL(k_micro_byte_gather, grid, dim3(256), 0, st, (const unsigned char *)buf, ncell * 8, n_lanes, salt, sink);
 	else if (mode == 4) hipLaunchKernelGGL(k_micro_store8, grid, dim3(256), 0, st, buf, ncell, n_lanes, salt);
-	else hipLaunchKernelGGL(k_micro_atomic_or32, grid, dim3(256), 0, st, (u32 *)buf, ncell * 2, n_lanes, salt);
+	else if (mode == 5) hipLaunchKernelGGL(k_micro_atomic_or32, grid, dim3(256), 0, st, (u32 *)buf, ncell * 2, n_lanes, salt);
+	else if (mode == 6) hipLaunchKernelGGL(k_micro_atomic_or_wg, grid, dim3(256), 0, st, buf, ncell, n_lanes, salt);
+	else hipLaunchKernelGGL(k_micro_atomic_or_ret, grid, dim3(256), 0, st, buf, ncell, n_lanes, salt, sink);
 }
 
 }   // namespace kmxk
