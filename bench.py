@@ -203,6 +203,8 @@ def main():
         foot = max(int(st.km_byte_size) * 4 * a.nb, 1 << 26)
         tg = api.microbench(0, foot, 1 << 27, 3)
         ta = api.microbench(1, foot, 1 << 27, 3)
+        roof["random_access_ceiling_GBps_at_32B"] = (1 << 27) * G / tg / 1e9     # measured 8-byte gather rate, priced at G per touch
+        roof["frac_of_random_access_ceiling"] = ach / roof["random_access_ceiling_GBps_at_32B"]
         extra = {"kernel_classes": classes,
                  "insert_alg_bytes_per_kmer": total_insert_alg / n,
                  "insert_alg_GBps_whole_step": total_insert_alg / (t_ins / a.steps) / 1e9,
