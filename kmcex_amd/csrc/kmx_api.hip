@@ -965,22 +965,37 @@ static int kmx_query_ascii_impl(kmx_model *m, const char *strs, int len, int str
 	if (!n) return KMX_OK;
 	bool clean = len == m->k;
 	std::vector<u64> pk(clean ? n * m->W : 0);
-	for (u64 i = 0; i < n && clean; i++) {
-		unsigned __int128 v = 0;
-		const char *s = strs + i * (u64)stride;
-		for (int j = 0; j < len; j++) {
-			unsigned c;
-			switch (s[j]) {
-			case 'A': c = 0; break;
-			case 'C': c = 1; break;
-			case 'G': c = 2; break;
-			case 'T': c = 3; break;
-			default: c = 0; clean = false;
+	if (clean) {                                              // pack on up to 16 host threads
+		const unsigned hw = std::thread::hardware_concurrency();
+		const int T = (int)std::max<u64>(1, std::min<u64>(std::min<unsigned>(hw ? hw : 1, 16), n / 65536 + 1));
+		std::vector<char> ok(T, 1);
+		auto work = [&](int t) {
+			const u64 per = (n + T - 1) / T, lo = (u64)t * per, hi = std::min<u64>(n, lo + per);
+			for (u64 i = lo; i < hi; i++) {
+				unsigned __int128 v = 0;
+				const char *s = strs + i * (u64)stride;
+				for (int j = 0; j < len; j++) {
+					unsigned c;
+					switch (s[j]) {
+					case 'A': c = 0; break;
+					case 'C': c = 1; break;
+					case 'G': c = 2; break;
+					case 'T': c = 3; break;
+					default: ok[t] = 0; return;
+					}
+					v = (v << 2) | c;
+				}
+				if (m->W == 1) pk[i] = (u64)v;
+				else { pk[2 * i] = (u64)(v >> 64); pk[2 * i + 1] = (u64)v; }
 			}
-			v = (v << 2) | c;
+		};
+		if (T == 1) work(0);
+		else {
+			std::vector<std::thread> th;
+			for (int t = 0; t < T; t++) th.emplace_back(work, t);
+			for (auto &x : th) x.join();
 		}
-		if (m->W == 1) pk[i] = (u64)v;
-		else { pk[2 * i] = (u64)(v >> 64); pk[2 * i + 1] = (u64)v; }
+		for (int t = 0; t < T; t++) clean = clean && ok[t];
 	}
 	if (clean) return kmx_query_packed(m, (const uint64_t *)pk.data(), n, out);
 	HIPCHK(hipSetDevice(m->device));

@@ -306,3 +306,61 @@ def test_genome_like_stream_neighbour_path(case, golden, tmp_path):
     strs = synth.to_strings(q[:20000], k)                       # the raw-string kernel takes the same neighbour path
     dirty = [s if i % 2 else s[:7] + "N" + s[8:] for i, s in enumerate(strs)]
     assert np.array_equal(np.array(m.kmer_to_occ(dirty), dtype=np.int32), o.query_strings(dirty))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 15, 16, 17, 33, 100])
+def test_degenerate_sizes(n, tmp_path):
+    """Empty and tiny listings: zero-length filters (N_km < 16, N_bf < 8) follow the documented divergence D2 --
+    nothing is stored in an empty filter, every probe of it misses -- identically in the oracle and on the GPU."""
+    k, ci, cs, nh, nb = 31, 1, 1023, 7, 5
+    km, cnt = synth.make_stream(max(n, 1), k, ci, cs, seed_k=99)
+    km, cnt = km[:n], cnt[:n]
+    m = KModel(ci, cs, nh, nb)
+    m.build_packed(k, km, cnt)
+    o = O.OracleModel(ci, cs, nh, nb)
+    o.build(k, km, cnt)
+    st, so = m.stats(), o.stats()
+    assert (st.n_total, st.n_km, st.km_byte_size, st.rest_entries) == (so.n_total, so.n_km, so.km_byte_size, so.rest_entries)
+    _check_arrays(m, o, nb, st.bf_num)
+    d1, d2 = str(tmp_path / "g"), str(tmp_path / "o")
+    os.makedirs(d1)
+    m.save(d1)
+    o.save(d2)
+    for f in ("header", "km.bin", "rest.bin"):
+        assert sha_file(os.path.join(d1, f)) == sha_file(os.path.join(d2, f)), f
+    q = np.concatenate([km, synth.random_kmers(50, k, seed_k=0xABCDEF0123)])
+    assert np.array_equal(m.kmer_to_occ_packed(q), o.query_packed(k, q))
+    assert np.array_equal(KModel.load(d1).kmer_to_occ_packed(q), o.query_packed(k, q))
+
+
+def test_api_state_machine():
+    """Calls out of order or with unusable arguments return an error code; nothing crashes, nothing falls back."""
+    k, ci, cs, nh, nb = 31, 1, 1023, 7, 5
+    km, cnt = synth.make_stream(5000, k, ci, cs)
+    m = KModel(ci, cs, nh, nb)
+    with pytest.raises(api.KmxError):
+        m.finish()                                            # finish before begin
+    with pytest.raises(api.KmxError):
+        m.insert_batch(km, cnt)                               # insert before begin
+    with pytest.raises(api.KmxError):
+        m.save("/tmp")                                        # save before build
+    m.begin(k, [int((cnt == 1).sum())], len(cnt))
+    m.insert_batch(km[:0], cnt[:0])                           # empty batch is fine
+    with pytest.raises(api.KmxError):
+        m.kmer_to_occ_packed(km)                              # query while building
+    m.insert_batch(km, cnt)
+    m.finish()
+    with pytest.raises(api.KmxError):
+        m.save("/nonexistent/dir/x")                          # the reference needs an existing directory too (main.cpp:148)
+    with pytest.raises(api.KmxError):
+        m.kmer_to_occ(["A"])                                  # shorter than 2 characters
+    with pytest.raises(api.KmxError):
+        api.KModel(1, 1023, 2, 5)                             # nh out of range
+    with pytest.raises(api.KmxError):
+        api.KModel(1, 100, 7, 5)                              # cs too small for nh=7 (occu_bin.hpp:38-44 overruns)
+    m.build_packed(k, km, cnt)                                # a handle can be rebuilt
+    o = O.OracleModel(ci, cs, nh, nb)
+    o.build(k, km, cnt)
+    assert np.array_equal(m.kmer_to_occ_packed(km), o.query_packed(k, km))
+    m.close()
+    m.close()                                                 # idempotent
