@@ -241,6 +241,7 @@ def main():
         line.update(extra)
         print(json.dumps(line), flush=True)
     if distributed:
+        dist.barrier()                      # rank 0 may still have been in its roofline leg: leave together
         dist.destroy_process_group()
 
 
