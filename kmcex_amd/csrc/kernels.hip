@@ -534,28 +534,201 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve(
 	if (threadIdx.x == 0 && s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)s_succ);
 }
 
-// Finisher: ONE workgroup per list iterates reserve/resolve over level s until nothing is undecided.  Every
-// iteration decides at least the smallest undecided index, so the loop ends after at most |U| iterations.
-// s == 0 (no grid-wide pass ran): the first iteration resolves verify_commit's reservations (epoch_b) and drops the
-// claim bits; afterwards it reserves for itself with epochs epoch0, epoch0+1, ...
-template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch_b, u64 epoch0)
+// Finisher: ONE workgroup per list decides whatever is still undecided at level s, in list order.
+// s == 0 (no grid-wide pass ran): the records still carry their claim bits, which are dropped here.
+//
+// finish_lds -- the normal case, at most KMX_FIN_RPT*1024 records: every thread keeps its records (cell indices and
+// bit numbers of their positions) in registers and the reservations live in LDS, so an iteration costs one round of
+// coherent gathers and one round of commits instead of nine dependent trips to memory.  Per iteration: gather the
+// tag/value halves of the cells; a record that conflicts with what is committed has failed; the others reserve their
+// untagged positions with atomicMax((priority << 14) | tag) -- priority = smaller list index, tag = 14 position bits
+// above the slot index -- in table 1; a position whose table-1 slot went to ANOTHER position (different tag: all
+// reservers of the position see the same winner) is reserved again in table 2 under a second hash.  A record that
+// holds every untagged position has no earlier undecided record on any of them, so its outcome is final and it
+// commits; the smallest undecided index always holds everything, so the loop ends.  Sharing a slot with a foreign
+// position only delays a record.  The (k-2)-mers of the winners go into km_back after the loop (nobody reads it here).
+#define KMX_FIN_T 16384
+__device__ __forceinline__ u32 fin_key(u32 x, u64 q) { return ((0x3FFFFu - x) << 14) | ((u32)(q >> 14) & 0x3FFFu); }
+__device__ __forceinline__ u32 fin_slot1(u64 q) { return (u32)q & (KMX_FIN_T - 1); }
+__device__ __forceinline__ u32 fin_slot2(u64 q) { return ((u32)(q >> 5) * 0x9E3779B1u) >> 18; }
+
+template <int W, int NHM, int RPT>
+__device__ __forceinline__ void finish_lds(const ModelDev &md, const BlockDev &bd, int pp, int i, int a, int lv, int n, bool drop_claims,
+                                            u32 *s_t1, u32 *s_t2, int *s_pending, int *s_succ)
 {
-	__shared__ int s_pending, s_succ;
-	const int i = blockIdx.x, lv = s & 1;
-	const int n = bd.Un[UN_IDX(lv, i, md.nb)];
-	if (n == 0) return;
 	const u64 row = (u64)i * KMX_BUCKET;
-	const int a = (i + t) % md.nb;
-	if (threadIdx.x == 0) {
-		s_succ = 0;
-		atomicMax(bd.stats + ST_MAX_UFIN, (u64)n);
-		if (s == 0) { atomicAdd(bd.stats + ST_CONTENDED, (u64)n); atomicMax(bd.stats + ST_MAX_U0, (u64)n); }
+	u64 *cells = md.cells[a];
+	const int sbase = a * md.nh;
+	for (int q = threadIdx.x; q < KMX_FIN_T; q += 1024) { s_t1[q] = 0; s_t2[q] = 0; }
+	u32 x[RPT], bin[RPT], cidx[RPT][NHM];
+	u64 bits[RPT];                                                   // bit_in_cell of position j in nibble j
+	bool live[RPT], won[RPT];
+#pragma unroll
+	for (int r = 0; r < RPT; r++) {
+		const int u = threadIdx.x + r * 1024;
+		live[r] = u < n;
+		won[r] = false;
+		x[r] = bin[r] = 0;
+		bits[r] = 0;
+		if (live[r]) {
+			u64 v[W];
+			rec_load<W>(bd.Urec[lv], row + u, x[r], bin[r], v);          // every record of the finisher's level is undecided
+			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh) {
+					const u64 pos = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(sbase + j) & 127]), md.km_mod);
+					cidx[r][j] = (u32)(pos >> 4);
+					bits[r] |= (u64)bit_in_cell(pos) << (4 * j);
+				}
+		}
+		__builtin_amdgcn_sched_barrier(0);                           // one record's hashes at a time
 	}
-	u64 epoch = epoch0;
-	bool first = s == 0;
+#define FIN_BIT(r, j) ((u32)(bits[r] >> (4 * (j))) & 15u)
+#define FIN_Q(r, j) (((u64)cidx[r][j] << 4) | FIN_BIT(r, j))
+	int succ = 0;
 	u64 iters = 0;
 	for (;; iters++) {
-		if (threadIdx.x == 0) s_pending = 0;
+		const int par = (int)(iters % 3), par_next = (int)((iters + 1) % 3);
+		// keep only the cell indices alive across iterations: slots, keys and addresses are recomputed (a few ALU ops)
+		// instead of being hoisted into ~10 registers per position
+#pragma unroll
+		for (int r = 0; r < RPT; r++) {
+#pragma unroll
+			for (int j = 0; j < NHM; j++) asm volatile("" : "+v"(cidx[r][j]));
+			asm volatile("" : "+v"(bits[r]), "+v"(x[r]), "+v"(bin[r]));
+		}
+		u32 untagged[RPT];                                           // positions this record reserves in this iteration
+#pragma unroll
+		for (int r = 0; r < RPT; r++) untagged[r] = 0;
+		// two records per thread at a time (one round of gathers for n <= 2048): bounds the registers in flight
+		constexpr int G = RPT < 2 ? RPT : 2;
+#pragma unroll
+		for (int g0 = 0; g0 < RPT; g0 += G) {
+			if (g0 * 1024 >= n) break;                                 // uniform
+			u32 w[G][NHM];                                             // value16 | tag16 halves of the cells
+#pragma unroll
+			for (int g = 0; g < G; g++)
+				if (live[g0 + g]) {
+#pragma unroll
+					for (int j = 0; j < NHM; j++)
+						if (j < md.nh) w[g][j] = __hip_atomic_load((const u32 *)(cells + cidx[g0 + g][j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+#pragma unroll
+			for (int g = 0; g < G; g++) {
+				const int r = g0 + g;
+				if (!live[r]) continue;
+				bool conflict = false;
+#pragma unroll
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh) {
+						const u32 b = FIN_BIT(r, j), want = (bin[r] >> j) & 1u;
+						const u32 tag = (w[g][j] >> (16 + b)) & 1u, val = (w[g][j] >> b) & 1u;
+						conflict |= tag && val != want;
+						if (!tag) {
+							untagged[r] |= 1u << j;
+							// the claim was set in check_claim iff the position was untagged then, and it still is
+							if (drop_claims && iters == 0) atomicAnd(cells + cidx[r][j], ~CELL_CLAIM(want, b));
+						}
+					}
+				if (conflict) { mark_failed(bd, pp, i, row, x[r]); live[r] = false; untagged[r] = 0; continue; }
+#pragma unroll
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh && ((untagged[r] >> j) & 1u)) atomicMax(s_t1 + fin_slot1(FIN_Q(r, j)), fin_key(x[r], FIN_Q(r, j)));
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		if (threadIdx.x == 0) s_pending[par_next] = 0;               // last read two iterations ago
+		__syncthreads();
+		u32 second[RPT];                                             // positions that moved to table 2
+#pragma unroll
+		for (int r = 0; r < RPT; r++) {
+			second[r] = 0;
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((untagged[r] >> j) & 1u)) {
+					const u64 q = FIN_Q(r, j);
+					const u32 key = fin_key(x[r], q);
+					if ((s_t1[fin_slot1(q)] ^ key) & 0x3FFFu) {
+						second[r] |= 1u << j;
+						atomicMax(s_t2 + fin_slot2(q), key);
+					}
+				}
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < RPT; r++) {
+			if (!live[r]) continue;
+			bool mine = true;
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((untagged[r] >> j) & 1u)) {
+					const u64 q = FIN_Q(r, j);
+					const u32 held = ((second[r] >> j) & 1u) ? s_t2[fin_slot2(q)] : s_t1[fin_slot1(q)];
+					mine &= held == fin_key(x[r], q);
+				}
+			if (mine) {
+#pragma unroll
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh && ((untagged[r] >> j) & 1u)) {
+						const u32 b = FIN_BIT(r, j);
+						atomicOr(cells + cidx[r][j], CELL_TAG(b) | (((bin[r] >> j) & 1u) ? CELL_VAL(b) : 0ULL));
+					}
+				bd.status[row + x[r]] = SLOT_INSERTED;
+				live[r] = false;
+				won[r] = true;
+				succ++;
+			} else s_pending[par] = 1;
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		__syncthreads();
+		// leave the tables empty for the next iteration
+#pragma unroll
+		for (int r = 0; r < RPT; r++)
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((untagged[r] >> j) & 1u)) {
+					const u64 q = FIN_Q(r, j);
+					s_t1[fin_slot1(q)] = 0;
+					if ((second[r] >> j) & 1u) s_t2[fin_slot2(q)] = 0;
+				}
+		drain_vmem();                                                // the commits are performed before anyone gathers again
+		__syncthreads();
+		if (!s_pending[par]) break;
+	}
+#undef FIN_BIT
+#undef FIN_Q
+	// kmodel.hpp:548-550 for the winners
+#pragma unroll
+	for (int r = 0; r < RPT; r++)
+		if (won[r]) {
+			u32 x_, bin_;
+			u64 v[W];
+			rec_load<W>(bd.Urec[lv], row + threadIdx.x + r * 1024, x_, bin_, v);
+			Premixed<W> pb = premix_string<W>(drop_first_base<W>(left_align<W>(v, md.k)), md.gback);
+			bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+		}
+	if (succ) atomicAdd(s_succ, succ);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		atomicAdd(bd.stats + ST_FIN_ITERS, iters + 1);
+		if (*s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)*s_succ);
+	}
+}
+
+// finish_global -- more records than finish_lds holds (the host adds grid-wide passes when it sees that happen): the
+// same iteration through the records and the epoch-tagged reservation table in global memory.  The first iteration
+// of s == 0 resolves verify_commit's reservations (epoch_b); afterwards it reserves for itself with epoch0, epoch0+1, ...
+template <int W, int NHM>
+__device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev &bd, int pp, int i, int a, int lv, int n, bool first, u64 epoch_b, u64 epoch0,
+                                               int *s_pending, int *s_succ)
+{
+	const u64 row = (u64)i * KMX_BUCKET;
+	u64 epoch = epoch0;
+	u64 iters = 0;
+	for (;; iters++) {
+		if (threadIdx.x == 0) *s_pending = 0;
 		__syncthreads();
 		if (!first) {
 			for (int u = threadIdx.x; u < n; u += 1024) {
@@ -568,11 +741,11 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 				gather_touches<W, NHM, true>(md, pm, a, tc);
 				if (touches_conflict<NHM>(md, tc, bin)) { mark_failed(bd, pp, i, row, x); continue; }
 				reserve_untagged<NHM>(md, bd, i, tc, resv_key(epoch, x));
-				s_pending = 1;
+				*s_pending = 1;
 			}
 			drain_vmem();                                      // our atomics are performed; readers use sc1 loads
 			__syncthreads();
-			const int pending = s_pending;
+			const int pending = *s_pending;
 			__syncthreads();
 			if (!pending) break;
 		}
@@ -593,7 +766,7 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 				succ++;
 			}
 		}
-		if (succ) atomicAdd(&s_succ, succ);
+		if (succ) atomicAdd(s_succ, succ);
 		drain_vmem();
 		__syncthreads();
 		if (!first) epoch++;
@@ -601,8 +774,28 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 	}
 	if (threadIdx.x == 0) {
 		atomicAdd(bd.stats + ST_FIN_ITERS, iters);
-		if (s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)s_succ);
+		if (*s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)*s_succ);
 	}
+}
+
+template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch_b, u64 epoch0, int force_global)
+{
+	__shared__ u32 s_t1[KMX_FIN_T], s_t2[KMX_FIN_T];
+	__shared__ int s_pending[3], s_succ;
+	const int i = blockIdx.x, lv = s & 1;
+	const int n = bd.Un[UN_IDX(lv, i, md.nb)];
+	if (n == 0) return;
+	const int a = (i + t) % md.nb;
+	if (threadIdx.x == 0) {
+		s_succ = 0;
+		s_pending[0] = 0;
+		atomicMax(bd.stats + ST_MAX_UFIN, (u64)n);
+		if (s == 0) { atomicAdd(bd.stats + ST_CONTENDED, (u64)n); atomicMax(bd.stats + ST_MAX_U0, (u64)n); }
+	}
+	__syncthreads();
+	constexpr int RPT = KMX_FIN_RPT(NHM);
+	if (n <= RPT * 1024 && !force_global && md.km_mod.d < (1ULL << 36)) finish_lds<W, NHM, RPT>(md, bd, pp, i, a, lv, n, s == 0, s_t1, s_t2, s_pending, &s_succ);
+	else finish_global<W, NHM>(md, bd, pp, i, a, lv, n, s == 0, epoch_b, epoch0, s_pending, &s_succ);
 }
 
 // ------------------------------------------------------------------------------------------ R: reorder
@@ -1263,9 +1456,11 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 		}
 		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_resolve<W, NHM>), sgrid, blk, 0, st, md, bd, t, pp, s, e));
 	}
+	const char *fg = getenv("KMX_FIN_GLOBAL");                   // test hook: the finisher's global-memory path for every set
+	const int force_global = fg ? atoi(fg) : 0;
 	const u64 e0 = *epoch;
 	*epoch += (1ULL << 19);                                    // the finisher may use up to |U| <= 2^18 epochs
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb), dim3(1024), 0, st, md, bd, t, pp, nsub, eb, e0));
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb), dim3(1024), 0, st, md, bd, t, pp, nsub, eb, e0, force_global));
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_REORDER, st);
 	hipLaunchKernelGGL(k_reorder, dim3(KMX_NTILES, nb), dim3(256), 0, st, bd, pp, nb);

@@ -463,7 +463,8 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 		const double L = (double)m->km_byte_size * 8.0;
 		const double p = L > 0 ? std::min(1.0, (double)m->nh * m->nh * 131072.0 / L) : 1.0;
 		const double u0 = 157000.0 * p;
-		m->nsub = u0 <= 4096 ? 0 : (u0 <= 16384 ? 2 : (u0 <= 49152 ? 5 : 8));
+		const double fin = 1024.0 * KMX_FIN_RPT(m->nh <= 8 ? 8 : 16);       // what the LDS finisher holds per list
+		m->nsub = u0 <= 0.75 * fin ? 0 : (u0 <= 4 * fin ? 1 : (u0 <= 10 * fin ? 3 : (u0 <= 24 * fin ? 5 : 8)));
 	}
 	m->t_insert_kernels = 0; m->t_total = 0;
 	memset(m->h_stats, 0, sizeof m->h_stats);
@@ -523,9 +524,10 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 	static const int force1 = getenv("KMX_NSUB1") ? atoi(getenv("KMX_NSUB1")) : -1;
 	const u64 u0 = ((volatile u64 *)m->h_feedback)[0], ufin = ((volatile u64 *)m->h_feedback)[1];
 	if (u0 != ~0ULL) {
-		if (ufin > 2048) m->nsub = std::min(m->nsub + 2, KMX_MAX_NSUB);
-		else if (ufin < 256 && m->nsub > 0 && u0 <= 4096) m->nsub--;
-		else if (m->nsub == 0 && u0 > 4096) m->nsub = 1;
+		const u64 fin = 1024ull * KMX_FIN_RPT(m->nh <= 8 ? 8 : 16);
+		if (ufin > fin) m->nsub = std::min(m->nsub + (ufin > 4 * fin ? 2 : 1), KMX_MAX_NSUB);
+		else if (m->nsub > 0 && u0 <= fin * 3 / 4) m->nsub--;               // the finisher could have taken all of it
+		else if (m->nsub > 1 && ufin < fin / 8) m->nsub--;
 	}
 	for (int t = 0; t < nb; t++) {
 		int nsub = t == 0 ? m->nsub : m->nsub / 2;

@@ -167,6 +167,27 @@ def test_heavy_collision_tiny_arrays():
         assert np.array_equal(m.kmer_to_occ_packed(q), o.query_packed(k, q))
 
 
+@pytest.mark.parametrize("cfg", [(31, 2, 1023, 7, 5, 400000), (40, 1, 4095, 11, 4, 250000), (27, 1, 1023, 8, 4, 120000)],
+                         ids=lambda c: "k%d_nh%d_nb%d_n%d" % (c[0], c[3], c[4], c[5]))
+def test_both_finisher_paths_bit_exact(cfg, monkeypatch):
+    """The single-workgroup finisher has an LDS path (sets up to 2048 / 1024 records) and a global-memory path (larger
+    sets).  Both must give the oracle's arrays on the same input: KMX_FIN_GLOBAL=1 sends every set through the second."""
+    k, ci, cs, nh, nb, n = cfg
+    km, cnt = synth.make_stream(n, k, ci, cs, seed_k=4242, seed_c=4243)
+    o = O.OracleModel(ci, cs, nh, nb)
+    o.build(k, km, cnt)
+    so = o.stats()
+    for force_global in (0, 1):
+        monkeypatch.setenv("KMX_FIN_GLOBAL", str(force_global))
+        m = KModel(ci, cs, nh, nb)
+        m.build_packed(k, km, cnt)
+        st = m.stats()
+        _check_arrays(m, o, nb, st.bf_num)
+        assert (st.attempts, st.successes, st.rest_entries) == (so.attempts, so.successes, so.rest_entries)
+        assert st.contended > 0
+    monkeypatch.delenv("KMX_FIN_GLOBAL")
+
+
 def test_error_behaviour():
     m = KModel(1, 1023, 7, 5)
     with pytest.raises(api.KmxError):

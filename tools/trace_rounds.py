@@ -1,0 +1,18 @@
+"""Per-round (t = 0..nb-1) average duration of each insert kernel from a rocprofv3 kernel trace of a one-stream build."""
+import csv, glob, sys
+from collections import defaultdict
+nb = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+f = (glob.glob(sys.argv[1] + "/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"))[0]
+rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(("void k_", "k_"))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+acc = defaultdict(lambda: [0, 0.0, 0.0])
+t = -1
+for r in rows:
+    nm = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+    if nm == "k_block_init": t = -1
+    if nm == "k_round_check_claim": t += 1
+    if nm.startswith(("k_round", "k_slow", "k_reorder")) and t >= 0:
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        a = acc[(t % nb, nm)]; a[0] += 1; a[1] += d; a[2] = max(a[2], d)
+for (t, nm), (n, d, mx) in sorted(acc.items()):
+    print("round %d %-24s n %5d avg %7.1f us max %7.1f total %7.2f ms" % (t, nm, n, d / n, mx, d / 1e3))
