@@ -403,21 +403,23 @@ __device__ __forceinline__ bool owns_outcome(const ModelDev &md, const BlockDev 
 	return mine;
 }
 
-template <int W> __device__ __forceinline__ void rec_store(u64 *rec, u64 slot, u32 x, u32 bin, const u64 *v)
+// record of a contended k-mer: list index | bin << 32 | (positions that were untagged when verify_commit looked) << 48
+template <int W> __device__ __forceinline__ void rec_store(u64 *rec, u64 slot, u32 x, u32 bin, const u64 *v, u32 untagged = 0)
 {
 	u64 *r = rec + slot * (1 + W);
-	r[0] = (u64)x | ((u64)bin << 32);
+	r[0] = (u64)x | ((u64)bin << 32) | ((u64)untagged << 48);
 #pragma unroll
 	for (int w = 0; w < W; w++) r[1 + w] = v[w];
 }
-template <int W> __device__ __forceinline__ void rec_load(const u64 *rec, u64 slot, u32 &x, u32 &bin, u64 *v)
+template <int W> __device__ __forceinline__ u32 rec_load(const u64 *rec, u64 slot, u32 &x, u32 &bin, u64 *v)
 {
 	const u64 *r = rec + slot * (1 + W);
 	const u64 h = r[0];
 	x = (u32)h;
-	bin = (u32)(h >> 32);
+	bin = (u32)(h >> 32) & 0xFFFFu;
 #pragma unroll
 	for (int w = 0; w < W; w++) v[w] = r[1 + w];
+	return (u32)(h >> 48);
 }
 
 // ------------------------------------------------------------------------------------------ B: verify + commit
@@ -438,7 +440,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_verify_
 		const bool active = x < n && bd.status[row + x] == SLOT_UNDECIDED;
 		bool contended = false;
 		u64 v[W];
-		u32 bin = 0;
+		u32 bin = 0, um = 0;
 		if (active) {
 			const u32 idx = bd.list[pp][row + x];
 			load_kmer<W>(bd.kmers, row + idx, v);
@@ -454,6 +456,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_verify_
 					u32 want = (bin >> j) & 1u;
 					bool tagged = (tc.cell[j] >> (16 + b)) & 1ULL;
 					contended |= !tagged && ((tc.cell[j] >> (32 + 16 * (1 - want) + b)) & 1ULL);
+					um |= tagged ? 0u : 1u << j;
 				}
 			if (!contended) {
 				commit_touches<W, NHM>(md, tc, bin, a, al);
@@ -461,7 +464,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_verify_
 			} else reserve_untagged<NHM>(md, bd, i, tc, resv_key(epoch, (u32)x));
 		}
 		const int p = block_append_slot(bd.Un + UN_IDX(0, i, md.nb), contended, &s_cnt, &s_base);
-		if (contended) rec_store<W>(bd.Urec[0], row + p, (u32)x, bin, v);
+		if (contended) rec_store<W>(bd.Urec[0], row + p, (u32)x, bin, v, um);
 		__syncthreads();
 	}
 }
@@ -534,6 +537,69 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve(
 	if (threadIdx.x == 0 && s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)s_succ);
 }
 
+// resolve pass of level 0 without a gather: the untagged mask verify_commit left in the record is still right for
+// this purpose (see finish_lds), so a k-mer that holds the reservation of every position in it commits, and one that
+// does not is deferred -- also when the position was tagged meanwhile by a winner of this very pass, which held it.
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0(ModelDev md, BlockDev bd, int t, int pp, u64 epoch)
+{
+	__shared__ int s_cnt, s_base, s_succ;
+	const int i = blockIdx.y;
+	const int cnt = bd.Un[UN_IDX(0, i, md.nb)];
+	const u64 row = (u64)i * KMX_BUCKET;
+	const int a = (i + t) % md.nb;
+	u64 *cells = md.cells[a];
+	const int sbase = a * md.nh;
+	if (threadIdx.x == 0) {
+		s_succ = 0;
+		if (blockIdx.x == 0 && cnt) { atomicAdd(bd.stats + ST_CONTENDED, (u64)cnt); atomicMax(bd.stats + ST_MAX_U0, (u64)cnt); }
+	}
+	for (int base = blockIdx.x * 256; base < cnt; base += SLOW_BLOCKS * 256) {      // uniform trip count per workgroup
+		if (threadIdx.x == 0) s_cnt = 0;
+		__syncthreads();
+		const int u = base + threadIdx.x;
+		bool mine = false, defer = false;
+		u32 x = 0, bin = 0;
+		u64 v[W];
+		if (u < cnt) {
+			const u32 um = rec_load<W>(bd.Urec[0], row + u, x, bin, v);
+			Aligned<W> al = left_align<W>(v, md.k);
+			Premixed<W> pm = premix_string<W>(al, md.gfull);
+			const u64 key = resv_key(epoch, x);
+			u64 pos[NHM], held[NHM];
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((um >> j) & 1u)) {
+					pos[j] = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(sbase + j) & 127]), md.km_mod);
+					held[j] = *resv_slot(bd, i, pos[j]);
+					atomicAnd(cells + (pos[j] >> 4), ~CELL_CLAIM((bin >> j) & 1u, bit_in_cell(pos[j])));
+				}
+			mine = true;
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((um >> j) & 1u)) mine &= held[j] == key;
+			if (mine) {
+#pragma unroll
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh && ((um >> j) & 1u)) {
+						const u32 b = bit_in_cell(pos[j]);
+						atomicOr(cells + (pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
+					}
+				Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
+				bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+				bd.status[row + x] = SLOT_INSERTED;
+			}
+			defer = !mine;
+		}
+		const int p = block_append_slot(bd.Un + UN_IDX(1, i, md.nb), defer, &s_cnt, &s_base);
+		if (defer) rec_store<W>(bd.Urec[1], row + p, x, bin, v);
+		const u64 mk = __ballot(mine);
+		if ((threadIdx.x & 63) == 0 && mk) atomicAdd(&s_succ, (int)__popcll(mk));
+		__syncthreads();
+	}
+	__syncthreads();
+	if (threadIdx.x == 0 && s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)s_succ);
+}
+
 // Finisher: ONE workgroup per list decides whatever is still undecided at level s, in list order.
 // s == 0 (no grid-wide pass ran): the records still carry their claim bits, which are dropped here.
 //
@@ -553,26 +619,31 @@ __device__ __forceinline__ u32 fin_slot1(u64 q) { return (u32)q & (KMX_FIN_T - 1
 __device__ __forceinline__ u32 fin_slot2(u64 q) { return ((u32)(q >> 5) * 0x9E3779B1u) >> 18; }
 
 template <int W, int NHM, int RPT>
-__device__ __forceinline__ void finish_lds(const ModelDev &md, const BlockDev &bd, int pp, int i, int a, int lv, int n, bool drop_claims,
-                                            u32 *s_t1, u32 *s_t2, int *s_pending, int *s_succ)
+__device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd, int pp, int i, int a, int lv, int n, const u32 *s_list, bool snapshot,
+                                           u32 *s_t1, u32 *s_t2, int *s_pending, int *s_succ)
 {
+	// the n records are Urec[lv][s_list[0..n)], or Urec[lv][0..n) when s_list is null; the tables are empty on entry and on exit.
+	// snapshot: nothing was committed on this array's contended positions since verify_commit looked at them (a fast
+	// commit on one of them carries the value this record wants too, or the committer would have been contended), so
+	// the untagged mask in the record stands in for the first round of gathers.
 	const u64 row = (u64)i * KMX_BUCKET;
 	u64 *cells = md.cells[a];
 	const int sbase = a * md.nh;
-	for (int q = threadIdx.x; q < KMX_FIN_T; q += 1024) { s_t1[q] = 0; s_t2[q] = 0; }
-	u32 x[RPT], bin[RPT], cidx[RPT][NHM];
+	u32 x[RPT], bin[RPT], rec[RPT], um0[RPT], cidx[RPT][NHM];
 	u64 bits[RPT];                                                   // bit_in_cell of position j in nibble j
 	bool live[RPT], won[RPT];
 #pragma unroll
 	for (int r = 0; r < RPT; r++) {
-		const int u = threadIdx.x + r * 1024;
-		live[r] = u < n;
+		const int slot = threadIdx.x + r * 1024;
+		live[r] = slot < n;
 		won[r] = false;
 		x[r] = bin[r] = 0;
 		bits[r] = 0;
+		rec[r] = um0[r] = 0;
 		if (live[r]) {
+			rec[r] = s_list ? s_list[slot] : (u32)slot;
 			u64 v[W];
-			rec_load<W>(bd.Urec[lv], row + u, x[r], bin[r], v);          // every record of the finisher's level is undecided
+			um0[r] = rec_load<W>(bd.Urec[lv], row + rec[r], x[r], bin[r], v);   // every record of the finisher's level is undecided
 			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
@@ -601,42 +672,49 @@ __device__ __forceinline__ void finish_lds(const ModelDev &md, const BlockDev &b
 		u32 untagged[RPT];                                           // positions this record reserves in this iteration
 #pragma unroll
 		for (int r = 0; r < RPT; r++) untagged[r] = 0;
-		// two records per thread at a time (one round of gathers for n <= 2048): bounds the registers in flight
-		constexpr int G = RPT < 2 ? RPT : 2;
+		if (snapshot && iters == 0) {
 #pragma unroll
-		for (int g0 = 0; g0 < RPT; g0 += G) {
-			if (g0 * 1024 >= n) break;                                 // uniform
-			u32 w[G][NHM];                                             // value16 | tag16 halves of the cells
-#pragma unroll
-			for (int g = 0; g < G; g++)
-				if (live[g0 + g]) {
-#pragma unroll
-					for (int j = 0; j < NHM; j++)
-						if (j < md.nh) w[g][j] = __hip_atomic_load((const u32 *)(cells + cidx[g0 + g][j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-#pragma unroll
-			for (int g = 0; g < G; g++) {
-				const int r = g0 + g;
+			for (int r = 0; r < RPT; r++) {
 				if (!live[r]) continue;
-				bool conflict = false;
-#pragma unroll
-				for (int j = 0; j < NHM; j++)
-					if (j < md.nh) {
-						const u32 b = FIN_BIT(r, j), want = (bin[r] >> j) & 1u;
-						const u32 tag = (w[g][j] >> (16 + b)) & 1u, val = (w[g][j] >> b) & 1u;
-						conflict |= tag && val != want;
-						if (!tag) {
-							untagged[r] |= 1u << j;
-							// the claim was set in check_claim iff the position was untagged then, and it still is
-							if (drop_claims && iters == 0) atomicAnd(cells + cidx[r][j], ~CELL_CLAIM(want, b));
-						}
-					}
-				if (conflict) { mark_failed(bd, pp, i, row, x[r]); live[r] = false; untagged[r] = 0; continue; }
+				untagged[r] = um0[r];
 #pragma unroll
 				for (int j = 0; j < NHM; j++)
 					if (j < md.nh && ((untagged[r] >> j) & 1u)) atomicMax(s_t1 + fin_slot1(FIN_Q(r, j)), fin_key(x[r], FIN_Q(r, j)));
 			}
-			__builtin_amdgcn_sched_barrier(0);
+		} else {
+			// two records per thread at a time (one round of gathers for n <= 2048): bounds the registers in flight
+			constexpr int G = RPT < 2 ? RPT : 2;
+#pragma unroll
+			for (int g0 = 0; g0 < RPT; g0 += G) {
+				if (g0 * 1024 >= n) break;                                 // uniform
+				u32 w[G][NHM];                                             // value16 | tag16 halves of the cells
+#pragma unroll
+				for (int g = 0; g < G; g++)
+					if (live[g0 + g]) {
+#pragma unroll
+						for (int j = 0; j < NHM; j++)
+							if (j < md.nh) w[g][j] = __hip_atomic_load((const u32 *)(cells + cidx[g0 + g][j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+#pragma unroll
+				for (int g = 0; g < G; g++) {
+					const int r = g0 + g;
+					if (!live[r]) continue;
+					bool conflict = false;
+#pragma unroll
+					for (int j = 0; j < NHM; j++)
+						if (j < md.nh) {
+							const u32 b = FIN_BIT(r, j), want = (bin[r] >> j) & 1u;
+							const u32 tag = (w[g][j] >> (16 + b)) & 1u, val = (w[g][j] >> b) & 1u;
+							conflict |= tag && val != want;
+							untagged[r] |= tag ? 0u : 1u << j;
+						}
+					if (conflict) { mark_failed(bd, pp, i, row, x[r]); live[r] = false; untagged[r] = 0; continue; }
+#pragma unroll
+					for (int j = 0; j < NHM; j++)
+						if (j < md.nh && ((untagged[r] >> j) & 1u)) atomicMax(s_t1 + fin_slot1(FIN_Q(r, j)), fin_key(x[r], FIN_Q(r, j)));
+				}
+				__builtin_amdgcn_sched_barrier(0);
+			}
 		}
 		if (threadIdx.x == 0) s_pending[par_next] = 0;               // last read two iterations ago
 		__syncthreads();
@@ -705,14 +783,62 @@ __device__ __forceinline__ void finish_lds(const ModelDev &md, const BlockDev &b
 		if (won[r]) {
 			u32 x_, bin_;
 			u64 v[W];
-			rec_load<W>(bd.Urec[lv], row + threadIdx.x + r * 1024, x_, bin_, v);
+			rec_load<W>(bd.Urec[lv], row + rec[r], x_, bin_, v);
 			Premixed<W> pb = premix_string<W>(drop_first_base<W>(left_align<W>(v, md.k)), md.gback);
 			bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
 		}
 	if (succ) atomicAdd(s_succ, succ);
+	return iters + 1;
+}
+
+// More records than the registers hold: the list order lets the finisher take them in index ranges, one range to
+// completion before the next (a record only ever waits for smaller indices).  The ranges are cut by index so that about
+// 7/8 of the capacity falls into each; a range that turns out too full is halved.
+template <int W, int NHM, int RPT>
+__device__ __forceinline__ void finish_lds_ranges(const ModelDev &md, const BlockDev &bd, int pp, int i, int a, int lv, int n, bool snapshot,
+                                                   u32 *s_t1, u32 *s_t2, u32 *s_list, int *s_count, int *s_pending, int *s_succ)
+{
+	constexpr int CAP = RPT * 1024;
+	const u64 row = (u64)i * KMX_BUCKET;
+	for (int q = threadIdx.x; q < KMX_FIN_T; q += 1024) { s_t1[q] = 0; s_t2[q] = 0; }
+	u64 iters = 0;
+	if (n <= CAP) {
+		__syncthreads();
+		iters = finish_lds<W, NHM, RPT>(md, bd, pp, i, a, lv, n, nullptr, snapshot, s_t1, s_t2, s_pending, s_succ);
+	} else {
+		const int n_list = bd.n[pp][i];
+		int lo = 0, remaining = n;
+		while (remaining > 0) {
+			int hi = n_list;
+			if (remaining > CAP) hi = lo + max(1, (int)((long long)(n_list - lo) * (CAP * 7 / 8) / remaining));
+			int cnt;
+			for (;;) {
+				if (threadIdx.x == 0) *s_count = 0;
+				__syncthreads();
+				for (int u = threadIdx.x; u < n; u += 1024) {
+					const int x = (int)(u32)bd.Urec[lv][(row + u) * (1 + W)];
+					if (x >= lo && x < hi) {
+						const int slot = atomicAdd(s_count, 1);
+						if (slot < CAP) s_list[slot] = (u32)u;
+					}
+				}
+				__syncthreads();
+				cnt = *s_count;
+				__syncthreads();
+				if (cnt <= CAP) break;
+				hi = lo + max(1, (hi - lo) / 2);
+			}
+			iters += finish_lds<W, NHM, RPT>(md, bd, pp, i, a, lv, cnt, s_list, snapshot && lo == 0, s_t1, s_t2, s_pending, s_succ);
+			__syncthreads();
+			if (threadIdx.x == 0) s_pending[0] = 0;                  // finish_lds starts with s_pending[0] clear
+			remaining -= cnt;
+			lo = hi;
+			if (lo >= n_list) break;
+		}
+	}
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		atomicAdd(bd.stats + ST_FIN_ITERS, iters + 1);
+		atomicAdd(bd.stats + ST_FIN_ITERS, iters);
 		if (*s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)*s_succ);
 	}
 }
@@ -778,14 +904,38 @@ __device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev
 	}
 }
 
+// Workgroups (i, 0) are the finishers.  Workgroups (i, 1..KMX_FIN_HELPERS) only drop the claim bits of list i's contended
+// k-mers (s == 0: nobody has yet) -- independent random atomics that one CU would take tens of microseconds to issue and
+// that nothing in the finisher reads.
 template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch_b, u64 epoch0, int force_global)
 {
-	__shared__ u32 s_t1[KMX_FIN_T], s_t2[KMX_FIN_T];
-	__shared__ int s_pending[3], s_succ;
+	__shared__ u32 s_t1[KMX_FIN_T], s_t2[KMX_FIN_T], s_list[KMX_FIN_RPT(NHM) * 1024];
+	__shared__ int s_pending[3], s_succ, s_count;
 	const int i = blockIdx.x, lv = s & 1;
 	const int n = bd.Un[UN_IDX(lv, i, md.nb)];
 	if (n == 0) return;
 	const int a = (i + t) % md.nb;
+	constexpr int RPT = KMX_FIN_RPT(NHM);
+	const bool lds_path = n <= KMX_FIN_RANGES * RPT * 1024 && !force_global && md.km_mod.d < (1ULL << 36);
+	if (blockIdx.y > 0) {
+		if (s != 0 || !lds_path) return;                             // finish_global drops the claims itself
+		const u64 row = (u64)i * KMX_BUCKET;
+		u64 *cells = md.cells[a];
+		const int sbase = a * md.nh;
+		for (int u = (blockIdx.y - 1) * 1024 + threadIdx.x; u < n; u += KMX_FIN_HELPERS * 1024) {
+			u32 x, bin;
+			u64 v[W];
+			const u32 um = rec_load<W>(bd.Urec[0], row + u, x, bin, v);
+			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((um >> j) & 1u)) {                     // claimed in check_claim iff untagged, and it still was in verify_commit
+					const u64 pos = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(sbase + j) & 127]), md.km_mod);
+					atomicAnd(cells + (pos >> 4), ~CELL_CLAIM((bin >> j) & 1u, bit_in_cell(pos)));
+				}
+		}
+		return;
+	}
 	if (threadIdx.x == 0) {
 		s_succ = 0;
 		s_pending[0] = 0;
@@ -793,8 +943,7 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 		if (s == 0) { atomicAdd(bd.stats + ST_CONTENDED, (u64)n); atomicMax(bd.stats + ST_MAX_U0, (u64)n); }
 	}
 	__syncthreads();
-	constexpr int RPT = KMX_FIN_RPT(NHM);
-	if (n <= RPT * 1024 && !force_global && md.km_mod.d < (1ULL << 36)) finish_lds<W, NHM, RPT>(md, bd, pp, i, a, lv, n, s == 0, s_t1, s_t2, s_pending, &s_succ);
+	if (lds_path) finish_lds_ranges<W, NHM, RPT>(md, bd, pp, i, a, lv, n, s == 0, s_t1, s_t2, s_list, &s_count, s_pending, &s_succ);
 	else finish_global<W, NHM>(md, bd, pp, i, a, lv, n, s == 0, epoch_b, epoch0, s_pending, &s_succ);
 }
 
@@ -1448,19 +1597,22 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_verify_commit<W, NHM>), grid, blk, 0, st, md, bd, t, pp, eb));
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_SLOW, st);
+	const char *lg = getenv("KMX_RESOLVE_GATHER");               // test hook: the gathering resolve kernel for level 0 too
+	const bool legacy0 = lg && atoi(lg);
 	for (int s = 0; s < nsub; s++) {
 		u64 e = eb;
 		if (s > 0) {
 			e = (*epoch)++;
 			DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_reserve<W, NHM>), sgrid, blk, 0, st, md, bd, t, pp, s, e));
 		}
-		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_resolve<W, NHM>), sgrid, blk, 0, st, md, bd, t, pp, s, e));
+		if (s == 0 && !legacy0) DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_resolve0<W, NHM>), sgrid, blk, 0, st, md, bd, t, pp, e));
+		else DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_resolve<W, NHM>), sgrid, blk, 0, st, md, bd, t, pp, s, e));
 	}
 	const char *fg = getenv("KMX_FIN_GLOBAL");                   // test hook: the finisher's global-memory path for every set
 	const int force_global = fg ? atoi(fg) : 0;
 	const u64 e0 = *epoch;
 	*epoch += (1ULL << 19);                                    // the finisher may use up to |U| <= 2^18 epochs
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb), dim3(1024), 0, st, md, bd, t, pp, nsub, eb, e0, force_global));
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb, 1 + KMX_FIN_HELPERS), dim3(1024), 0, st, md, bd, t, pp, nsub, eb, e0, force_global));
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_REORDER, st);
 	hipLaunchKernelGGL(k_reorder, dim3(KMX_NTILES, nb), dim3(256), 0, st, bd, pp, nb);

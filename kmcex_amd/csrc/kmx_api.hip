@@ -464,7 +464,9 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 		const double p = L > 0 ? std::min(1.0, (double)m->nh * m->nh * 131072.0 / L) : 1.0;
 		const double u0 = 157000.0 * p;
 		const double fin = 1024.0 * KMX_FIN_RPT(m->nh <= 8 ? 8 : 16);       // what the LDS finisher holds per list
-		m->nsub = u0 <= 0.75 * fin ? 0 : (u0 <= 4 * fin ? 1 : (u0 <= 10 * fin ? 3 : (u0 <= 24 * fin ? 5 : 8)));
+		// measured at 10^8 k-mers: one load of the finisher 50-60 us; two loads (index ranges) 115 us; one grid-wide pass
+		// (37 us) decides half of the set and leaves one load (40 us)
+		m->nsub = u0 <= fin ? 0 : (u0 <= 6 * fin ? 1 : (u0 <= 16 * fin ? 3 : (u0 <= 40 * fin ? 5 : 8)));
 	}
 	m->t_insert_kernels = 0; m->t_total = 0;
 	memset(m->h_stats, 0, sizeof m->h_stats);
@@ -526,9 +528,10 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 	if (u0 != ~0ULL) {
 		const u64 fin = 1024ull * KMX_FIN_RPT(m->nh <= 8 ? 8 : 16);
 		if (ufin > fin) m->nsub = std::min(m->nsub + (ufin > 4 * fin ? 2 : 1), KMX_MAX_NSUB);
-		else if (m->nsub > 0 && u0 <= fin * 3 / 4) m->nsub--;               // the finisher could have taken all of it
-		else if (m->nsub > 1 && ufin < fin / 8) m->nsub--;
+		else if (m->nsub > 0 && u0 <= fin * 7 / 8) m->nsub--;               // the finisher could have taken all of it in one load
+		else if (m->nsub > 1 && ufin < fin / 4) m->nsub--;
 	}
+	if (getenv("KMX_CTRL_DEBUG")) fprintf(stderr, "[kmx] block %llu feedback u0=%lld ufin=%lld -> nsub=%d\n", (unsigned long long)m->blocks, (long long)u0, (long long)ufin, m->nsub);
 	for (int t = 0; t < nb; t++) {
 		int nsub = t == 0 ? m->nsub : m->nsub / 2;
 		if (t == 0 && force0 >= 0) nsub = force0;
