@@ -318,7 +318,10 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_c
 	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;                                  // kmodel.hpp:563
-	if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		if (n) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
+		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, md.nb)] = 0;   // verify_commit files this round's records
+	}
 	// grid-stride over the list: later rounds are launched with fewer workgroups (lists shrink round by round)
 	for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
 		if (threadIdx.x == 0) s_fail = 0;
@@ -403,7 +406,8 @@ __device__ __forceinline__ bool owns_outcome(const ModelDev &md, const BlockDev 
 	return mine;
 }
 
-// record of a contended k-mer: list index | bin << 32 | (positions that were untagged when verify_commit looked) << 48
+// record of a contended k-mer: list index | REC_WON | bin << 32 | (positions that were untagged when verify_commit looked) << 48
+#define REC_WON (1ULL << 31)       // set by the finisher: decided to fit, k_reorder applies it
 template <int W> __device__ __forceinline__ void rec_store(u64 *rec, u64 slot, u32 x, u32 bin, const u64 *v, u32 untagged = 0)
 {
 	u64 *r = rec + slot * (1 + W);
@@ -415,7 +419,7 @@ template <int W> __device__ __forceinline__ u32 rec_load(const u64 *rec, u64 slo
 {
 	const u64 *r = rec + slot * (1 + W);
 	const u64 h = r[0];
-	x = (u32)h;
+	x = (u32)h & (KMX_BUCKET - 1);
 	bin = (u32)(h >> 32) & 0xFFFFu;
 #pragma unroll
 	for (int w = 0; w < W; w++) v[w] = r[1 + w];
@@ -601,35 +605,46 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0
 }
 
 // Finisher: ONE workgroup per list decides whatever is still undecided at level s, in list order.
-// s == 0 (no grid-wide pass ran): the records still carry their claim bits, which are dropped here.
 //
-// finish_lds -- the normal case, at most KMX_FIN_RPT*1024 records: every thread keeps its records (cell indices and
-// bit numbers of their positions) in registers and the reservations live in LDS, so an iteration costs one round of
-// coherent gathers and one round of commits instead of nine dependent trips to memory.  Per iteration: gather the
-// tag/value halves of the cells; a record that conflicts with what is committed has failed; the others reserve their
-// untagged positions with atomicMax((priority << 14) | tag) -- priority = smaller list index, tag = 14 position bits
-// above the slot index -- in table 1; a position whose table-1 slot went to ANOTHER position (different tag: all
-// reservers of the position see the same winner) is reserved again in table 2 under a second hash.  A record that
-// holds every untagged position has no earlier undecided record on any of them, so its outcome is final and it
-// commits; the smallest undecided index always holds everything, so the loop ends.  Sharing a slot with a foreign
-// position only delays a record.  The (k-2)-mers of the winners go into km_back after the loop (nobody reads it here).
+// finish_lds -- at most KMX_FIN_RPT*1024 records at a time.  Every thread keeps its records (cell indices and bit
+// numbers of their positions, mask of the positions still untagged) in registers; the reservations live in LDS.
+// The state of the array is read ONCE -- the untagged mask verify_commit left in the record when nothing was committed
+// on contended positions since (snapshot), one round of coherent gathers otherwise -- and afterwards only this
+// workgroup changes it, so everything else is learnt through LDS:
+//   1. every undecided record reserves its untagged positions with atomicMax(priority << 13 | tag) in table 1
+//      (priority: smaller list index first; tag: 13 position bits above the slot index);
+//   2. a position whose table-1 slot went to ANOTHER position (tag mismatch -- all reservers of a position see the same
+//      winner) is reserved again in table 2 under a second hash, which removes nearly all false sharing;
+//   3. a record that holds every untagged position has no earlier undecided record on any of them: its outcome is the
+//      sequential one.  It wins, and replaces each slot it holds by a MARK word carrying the full position identity
+//      (tag + 9 more bits; the slot index gives the rest) and the value it commits there;
+//   4. a record that lost a slot to a MARK of exactly its position now knows the position is tagged: with the other
+//      value it has failed for good, with its own value the position leaves its untagged mask.  (Every undecided
+//      record interested in a position reserves it in every iteration and takes the same route to table 1 or 2, so
+//      nobody misses the iteration in which the position is won.)
+//   5. the slots are cleared, and the loop ends when nothing is undecided; the smallest undecided index always wins.
+// Sharing a slot with a foreign position only delays a record.  `defer`: the winners do not touch the array at all;
+// they set REC_WON in their record and k_reorder -- 256 workgroups per list instead of one -- applies tag/value bits
+// and the km_back insert.  One CU issues a random access every ~2.8 ns, which is what bounded this kernel before.
 #define KMX_FIN_T 16384
-__device__ __forceinline__ u32 fin_key(u32 x, u64 q) { return ((0x3FFFFu - x) << 14) | ((u32)(q >> 14) & 0x3FFFu); }
+#define FIN_MARK 0x80000000u
+// workgroup barrier for LDS-only hand-offs: __syncthreads() would also wait for every outstanding global store and
+// atomic of the wave (status bytes, failure counters), 2-4 us each time
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ u32 fin_ident(u64 q) { return (u32)(q >> 14) & 0x3FFFFFu; }                  // tag13 | hi9 << 13
+__device__ __forceinline__ u32 fin_key(u32 x, u64 q) { return ((0x3FFFFu - x) << 13) | ((u32)(q >> 14) & 0x1FFFu); }
 __device__ __forceinline__ u32 fin_slot1(u64 q) { return (u32)q & (KMX_FIN_T - 1); }
-__device__ __forceinline__ u32 fin_slot2(u64 q) { return ((u32)(q >> 5) * 0x9E3779B1u) >> 18; }
+__device__ __forceinline__ u32 fin_slot2(u64 q) { return ((u32)q ^ ((fin_ident(q) * 0x9E3779B1u) >> 18)) & (KMX_FIN_T - 1); }
 
 template <int W, int NHM, int RPT>
-__device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd, int pp, int i, int a, int lv, int n, const u32 *s_list, bool snapshot,
+__device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd, int pp, int i, int a, int lv, int n, const u32 *s_list, bool snapshot, bool defer,
                                            u32 *s_t1, u32 *s_t2, int *s_pending, int *s_succ)
 {
-	// the n records are Urec[lv][s_list[0..n)], or Urec[lv][0..n) when s_list is null; the tables are empty on entry and on exit.
-	// snapshot: nothing was committed on this array's contended positions since verify_commit looked at them (a fast
-	// commit on one of them carries the value this record wants too, or the committer would have been contended), so
-	// the untagged mask in the record stands in for the first round of gathers.
+	// the n records are Urec[lv][s_list[0..n)], or Urec[lv][0..n) when s_list is null; the tables are empty on entry and on exit
 	const u64 row = (u64)i * KMX_BUCKET;
 	u64 *cells = md.cells[a];
 	const int sbase = a * md.nh;
-	u32 x[RPT], bin[RPT], rec[RPT], um0[RPT], cidx[RPT][NHM];
+	u32 x[RPT], bin[RPT], rec[RPT], um[RPT], cidx[RPT][NHM];
 	u64 bits[RPT];                                                   // bit_in_cell of position j in nibble j
 	bool live[RPT], won[RPT];
 #pragma unroll
@@ -639,11 +654,11 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 		won[r] = false;
 		x[r] = bin[r] = 0;
 		bits[r] = 0;
-		rec[r] = um0[r] = 0;
+		rec[r] = um[r] = 0;
 		if (live[r]) {
 			rec[r] = s_list ? s_list[slot] : (u32)slot;
 			u64 v[W];
-			um0[r] = rec_load<W>(bd.Urec[lv], row + rec[r], x[r], bin[r], v);   // every record of the finisher's level is undecided
+			um[r] = rec_load<W>(bd.Urec[lv], row + rec[r], x[r], bin[r], v);    // every record of the finisher's level is undecided
 			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
@@ -657,6 +672,39 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 	}
 #define FIN_BIT(r, j) ((u32)(bits[r] >> (4 * (j))) & 15u)
 #define FIN_Q(r, j) (((u64)cidx[r][j] << 4) | FIN_BIT(r, j))
+	if (!snapshot) {
+		// the state of the array now (two records per thread at a time: bounds the registers in flight)
+		constexpr int G = RPT < 2 ? RPT : 2;
+#pragma unroll
+		for (int g0 = 0; g0 < RPT; g0 += G) {
+			if (g0 * 1024 >= n) break;                                 // uniform
+			u32 w[G][NHM];                                             // value16 | tag16 halves of the cells
+#pragma unroll
+			for (int g = 0; g < G; g++)
+				if (live[g0 + g]) {
+#pragma unroll
+					for (int j = 0; j < NHM; j++)
+						if (j < md.nh) w[g][j] = __hip_atomic_load((const u32 *)(cells + cidx[g0 + g][j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+#pragma unroll
+			for (int g = 0; g < G; g++) {
+				const int r = g0 + g;
+				if (!live[r]) continue;
+				bool conflict = false;
+				um[r] = 0;
+#pragma unroll
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh) {
+						const u32 b = FIN_BIT(r, j), want = (bin[r] >> j) & 1u;
+						const u32 tag = (w[g][j] >> (16 + b)) & 1u, val = (w[g][j] >> b) & 1u;
+						conflict |= tag && val != want;
+						um[r] |= tag ? 0u : 1u << j;
+					}
+				if (conflict) { mark_failed(bd, pp, i, row, x[r]); live[r] = false; um[r] = 0; }
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
 	int succ = 0;
 	u64 iters = 0;
 	for (;; iters++) {
@@ -667,126 +715,132 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 		for (int r = 0; r < RPT; r++) {
 #pragma unroll
 			for (int j = 0; j < NHM; j++) asm volatile("" : "+v"(cidx[r][j]));
-			asm volatile("" : "+v"(bits[r]), "+v"(x[r]), "+v"(bin[r]));
+			asm volatile("" : "+v"(bits[r]), "+v"(x[r]), "+v"(bin[r]), "+v"(um[r]));
 		}
-		u32 untagged[RPT];                                           // positions this record reserves in this iteration
+		u32 resv[RPT], second[RPT];                                  // positions reserved in this iteration / moved to table 2
+		bool mine[RPT];
+		// 1
 #pragma unroll
-		for (int r = 0; r < RPT; r++) untagged[r] = 0;
-		if (snapshot && iters == 0) {
+		for (int r = 0; r < RPT; r++) {
+			resv[r] = live[r] ? um[r] : 0u;
 #pragma unroll
-			for (int r = 0; r < RPT; r++) {
-				if (!live[r]) continue;
-				untagged[r] = um0[r];
-#pragma unroll
-				for (int j = 0; j < NHM; j++)
-					if (j < md.nh && ((untagged[r] >> j) & 1u)) atomicMax(s_t1 + fin_slot1(FIN_Q(r, j)), fin_key(x[r], FIN_Q(r, j)));
-			}
-		} else {
-			// two records per thread at a time (one round of gathers for n <= 2048): bounds the registers in flight
-			constexpr int G = RPT < 2 ? RPT : 2;
-#pragma unroll
-			for (int g0 = 0; g0 < RPT; g0 += G) {
-				if (g0 * 1024 >= n) break;                                 // uniform
-				u32 w[G][NHM];                                             // value16 | tag16 halves of the cells
-#pragma unroll
-				for (int g = 0; g < G; g++)
-					if (live[g0 + g]) {
-#pragma unroll
-						for (int j = 0; j < NHM; j++)
-							if (j < md.nh) w[g][j] = __hip_atomic_load((const u32 *)(cells + cidx[g0 + g][j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					}
-#pragma unroll
-				for (int g = 0; g < G; g++) {
-					const int r = g0 + g;
-					if (!live[r]) continue;
-					bool conflict = false;
-#pragma unroll
-					for (int j = 0; j < NHM; j++)
-						if (j < md.nh) {
-							const u32 b = FIN_BIT(r, j), want = (bin[r] >> j) & 1u;
-							const u32 tag = (w[g][j] >> (16 + b)) & 1u, val = (w[g][j] >> b) & 1u;
-							conflict |= tag && val != want;
-							untagged[r] |= tag ? 0u : 1u << j;
-						}
-					if (conflict) { mark_failed(bd, pp, i, row, x[r]); live[r] = false; untagged[r] = 0; continue; }
-#pragma unroll
-					for (int j = 0; j < NHM; j++)
-						if (j < md.nh && ((untagged[r] >> j) & 1u)) atomicMax(s_t1 + fin_slot1(FIN_Q(r, j)), fin_key(x[r], FIN_Q(r, j)));
-				}
-				__builtin_amdgcn_sched_barrier(0);
-			}
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((resv[r] >> j) & 1u)) atomicMax(s_t1 + fin_slot1(FIN_Q(r, j)), fin_key(x[r], FIN_Q(r, j)));
 		}
 		if (threadIdx.x == 0) s_pending[par_next] = 0;               // last read two iterations ago
-		__syncthreads();
-		u32 second[RPT];                                             // positions that moved to table 2
+		lds_barrier();
+		// 2
 #pragma unroll
 		for (int r = 0; r < RPT; r++) {
 			second[r] = 0;
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
-				if (j < md.nh && ((untagged[r] >> j) & 1u)) {
+				if (j < md.nh && ((resv[r] >> j) & 1u)) {
 					const u64 q = FIN_Q(r, j);
 					const u32 key = fin_key(x[r], q);
-					if ((s_t1[fin_slot1(q)] ^ key) & 0x3FFFu) {
+					if ((s_t1[fin_slot1(q)] ^ key) & 0x1FFFu) {
 						second[r] |= 1u << j;
 						atomicMax(s_t2 + fin_slot2(q), key);
 					}
 				}
 			__builtin_amdgcn_sched_barrier(0);
 		}
-		__syncthreads();
+		lds_barrier();
+		// 3 (reads only)
 #pragma unroll
 		for (int r = 0; r < RPT; r++) {
-			if (!live[r]) continue;
-			bool mine = true;
+			mine[r] = live[r];
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
-				if (j < md.nh && ((untagged[r] >> j) & 1u)) {
+				if (j < md.nh && ((resv[r] >> j) & 1u)) {
 					const u64 q = FIN_Q(r, j);
 					const u32 held = ((second[r] >> j) & 1u) ? s_t2[fin_slot2(q)] : s_t1[fin_slot1(q)];
-					mine &= held == fin_key(x[r], q);
+					mine[r] &= held == fin_key(x[r], q);
 				}
-			if (mine) {
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		lds_barrier();
+		// 3 (the winners publish what they commit; duplicates of a position inside one k-mer OR their values, as the
+		// reference's set loop does, kmodel.hpp:611-618)
+#pragma unroll
+		for (int r = 0; r < RPT; r++) {
+			if (!mine[r]) continue;
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((resv[r] >> j) & 1u)) {
+					const u64 q = FIN_Q(r, j);
+					*(((second[r] >> j) & 1u) ? s_t2 + fin_slot2(q) : s_t1 + fin_slot1(q)) = FIN_MARK | fin_ident(q);
+				}
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((resv[r] >> j) & 1u) && ((bin[r] >> j) & 1u)) {
+					const u64 q = FIN_Q(r, j);
+					atomicOr(((second[r] >> j) & 1u) ? s_t2 + fin_slot2(q) : s_t1 + fin_slot1(q), 0x40000000u);
+				}
+			if (!defer) {
 #pragma unroll
 				for (int j = 0; j < NHM; j++)
-					if (j < md.nh && ((untagged[r] >> j) & 1u)) {
+					if (j < md.nh && ((resv[r] >> j) & 1u)) {
 						const u32 b = FIN_BIT(r, j);
 						atomicOr(cells + cidx[r][j], CELL_TAG(b) | (((bin[r] >> j) & 1u) ? CELL_VAL(b) : 0ULL));
 					}
-				bd.status[row + x[r]] = SLOT_INSERTED;
-				live[r] = false;
-				won[r] = true;
-				succ++;
-			} else s_pending[par] = 1;
+			}
+			bd.status[row + x[r]] = SLOT_INSERTED;
+			live[r] = false;
+			won[r] = true;
+			succ++;
 			__builtin_amdgcn_sched_barrier(0);
 		}
-		__syncthreads();
-		// leave the tables empty for the next iteration
+		lds_barrier();
+		// 4
+#pragma unroll
+		for (int r = 0; r < RPT; r++) {
+			if (!live[r]) continue;
+			bool conflict = false;
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((resv[r] >> j) & 1u)) {
+					const u64 q = FIN_Q(r, j);
+					const u32 m = ((second[r] >> j) & 1u) ? s_t2[fin_slot2(q)] : s_t1[fin_slot1(q)];
+					if ((m & FIN_MARK) && (m & 0x3FFFFFu) == fin_ident(q)) {
+						conflict |= ((m >> 30) & 1u) != ((bin[r] >> j) & 1u);
+						um[r] &= ~(1u << j);
+					}
+				}
+			if (conflict) { mark_failed(bd, pp, i, row, x[r]); live[r] = false; }
+			else s_pending[par] = 1;
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		lds_barrier();
+		// 5
 #pragma unroll
 		for (int r = 0; r < RPT; r++)
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
-				if (j < md.nh && ((untagged[r] >> j) & 1u)) {
+				if (j < md.nh && ((resv[r] >> j) & 1u)) {
 					const u64 q = FIN_Q(r, j);
 					s_t1[fin_slot1(q)] = 0;
 					if ((second[r] >> j) & 1u) s_t2[fin_slot2(q)] = 0;
 				}
-		drain_vmem();                                                // the commits are performed before anyone gathers again
-		__syncthreads();
+		lds_barrier();
 		if (!s_pending[par]) break;
 	}
 #undef FIN_BIT
 #undef FIN_Q
-	// kmodel.hpp:548-550 for the winners
 #pragma unroll
 	for (int r = 0; r < RPT; r++)
 		if (won[r]) {
-			u32 x_, bin_;
-			u64 v[W];
-			rec_load<W>(bd.Urec[lv], row + rec[r], x_, bin_, v);
-			Premixed<W> pb = premix_string<W>(drop_first_base<W>(left_align<W>(v, md.k)), md.gback);
-			bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+			u64 *hdr = bd.Urec[lv] + (row + rec[r]) * (1 + W);
+			if (defer) *hdr |= REC_WON;                                // k_reorder applies it
+			else {                                                     // kmodel.hpp:548-550
+				u32 x_, bin_;
+				u64 v[W];
+				rec_load<W>(bd.Urec[lv], row + rec[r], x_, bin_, v);
+				Premixed<W> pb = premix_string<W>(drop_first_base<W>(left_align<W>(v, md.k)), md.gback);
+				bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+			}
 		}
+	if (!defer) drain_vmem();                                        // the next range gathers what this one committed
 	if (succ) atomicAdd(s_succ, succ);
 	return iters + 1;
 }
@@ -804,7 +858,7 @@ __device__ __forceinline__ void finish_lds_ranges(const ModelDev &md, const Bloc
 	u64 iters = 0;
 	if (n <= CAP) {
 		__syncthreads();
-		iters = finish_lds<W, NHM, RPT>(md, bd, pp, i, a, lv, n, nullptr, snapshot, s_t1, s_t2, s_pending, s_succ);
+		iters = finish_lds<W, NHM, RPT>(md, bd, pp, i, a, lv, n, nullptr, snapshot, true, s_t1, s_t2, s_pending, s_succ);
 	} else {
 		const int n_list = bd.n[pp][i];
 		int lo = 0, remaining = n;
@@ -816,7 +870,7 @@ __device__ __forceinline__ void finish_lds_ranges(const ModelDev &md, const Bloc
 				if (threadIdx.x == 0) *s_count = 0;
 				__syncthreads();
 				for (int u = threadIdx.x; u < n; u += 1024) {
-					const int x = (int)(u32)bd.Urec[lv][(row + u) * (1 + W)];
+					const int x = (int)((u32)bd.Urec[lv][(row + u) * (1 + W)] & (KMX_BUCKET - 1));
 					if (x >= lo && x < hi) {
 						const int slot = atomicAdd(s_count, 1);
 						if (slot < CAP) s_list[slot] = (u32)u;
@@ -828,7 +882,7 @@ __device__ __forceinline__ void finish_lds_ranges(const ModelDev &md, const Bloc
 				if (cnt <= CAP) break;
 				hi = lo + max(1, (hi - lo) / 2);
 			}
-			iters += finish_lds<W, NHM, RPT>(md, bd, pp, i, a, lv, cnt, s_list, snapshot && lo == 0, s_t1, s_t2, s_pending, s_succ);
+			iters += finish_lds<W, NHM, RPT>(md, bd, pp, i, a, lv, cnt, s_list, snapshot && lo == 0, false, s_t1, s_t2, s_pending, s_succ);
 			__syncthreads();
 			if (threadIdx.x == 0) s_pending[0] = 0;                  // finish_lds starts with s_pending[0] clear
 			remaining -= cnt;
@@ -953,13 +1007,41 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 // accumulated while the slots failed; holes are written as (LIST_HOLE | rank) and filled lazily from mover[] by the
 // next round's check_claim (or by rest_append after the last round), so no grid-wide fill pass is needed.
 // Also closes the round's books: successes = n - m, contended = |U0|; resets the counters of the next round.
-__global__ __launch_bounds__(256) void k_reorder(BlockDev bd, int pp, int nb)
+// Before that, it applies what the finisher decided but left undone (REC_WON records of level lv): tag/value bits
+// (kmodel.hpp:611-618, every position: an already tagged one carries the same value) and the km_back insert (:548-550).
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(ModelDev md, BlockDev bd, int t, int pp, int lv)
 {
 	__shared__ int s_tmp[4];
 	__shared__ int s_m, s_off;
+	const int nb = md.nb;
 	const int i = blockIdx.y, tile = blockIdx.x;
 	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
+	if (tile >= (int)KMX_NTILES) {                                   // the extra workgroups only apply; the others only reorder
+		const int nrec = bd.Un[UN_IDX(lv, i, nb)];
+		for (int u = (tile - (int)KMX_NTILES) * 256 + threadIdx.x; u < nrec; u += KMX_APPLY_WGS * 256) {
+			const u64 *rec = bd.Urec[lv] + (row + u) * (1 + W);
+			if (rec[0] & REC_WON) {
+				const int a = (i + t) % nb;
+				u32 x, bin;
+				u64 v[W];
+				rec_load<W>(bd.Urec[lv], row + u, x, bin, v);
+				Aligned<W> al = left_align<W>(v, md.k);
+				Premixed<W> pm = premix_string<W>(al, md.gfull);
+				u64 *cells = md.cells[a];
+#pragma unroll
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh) {
+						const u64 pos = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(a * md.nh + j) & 127]), md.km_mod);
+						const u32 b = bit_in_cell(pos);
+						atomicOr(cells + (pos >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
+					}
+				Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
+				bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+			}
+		}
+		return;
+	}
 	{   // every workgroup scans the 256 tile counts of its list
 		int c = bd.tile_cnt[pp][i * KMX_NTILES + threadIdx.x];
 		int tot;
@@ -992,8 +1074,7 @@ __global__ __launch_bounds__(256) void k_reorder(BlockDev bd, int pp, int nb)
 	bd.tile_cnt[pp ^ 1][i * KMX_NTILES + tile] = 0;                 // next round counts into the other buffer
 	if (tile == 0 && threadIdx.x == 0) {
 		if (n > m) atomicAdd(bd.stats + ST_SUCCESSES, (u64)(n - m));
-		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, nb)] = 0;
-		bd.n[pp ^ 1][i] = m;
+		bd.n[pp ^ 1][i] = m;                                       // (the record counters are reset by the next check_claim)
 	}
 }
 
@@ -1615,7 +1696,7 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb, 1 + KMX_FIN_HELPERS), dim3(1024), 0, st, md, bd, t, pp, nsub, eb, e0, force_global));
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_REORDER, st);
-	hipLaunchKernelGGL(k_reorder, dim3(KMX_NTILES, nb), dim3(256), 0, st, bd, pp, nb);
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, nb), dim3(256), 0, st, md, bd, t, pp, nsub & 1));
 	KPROF_END(prof, st);
 }
 

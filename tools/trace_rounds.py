@@ -16,3 +16,14 @@ for r in rows:
         a = acc[(t % nb, nm)]; a[0] += 1; a[1] += d; a[2] = max(a[2], d)
 for (t, nm), (n, d, mx) in sorted(acc.items()):
     print("round %d %-24s n %5d avg %7.1f us max %7.1f total %7.2f ms" % (t, nm, n, d / n, mx, d / 1e3))
+if len(sys.argv) > 3:   # sequence of one kernel's durations in round 0, last build
+    want = sys.argv[3]
+    seq = []
+    t = -1
+    for r in rows:
+        nm = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        if nm == "k_block_init": t = -1
+        if nm == "k_round_check_claim": t += 1
+        if nm == want and t == 0: seq.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    per = len(seq) // 3 if len(seq) >= 3 else len(seq)
+    print(want, "round 0, last build:", " ".join("%.0f" % v for v in seq[-per:]))
