@@ -1662,7 +1662,7 @@ void block_init(const BlockDev &bd, int nb, int pp, int n_in_block, hipStream_t 
 // one round t of one block: A, B, `nsub` grid-wide ordered sub-rounds, finisher, reorder.  `epoch` advances.
 // The single-workgroup finisher decides whatever the sub-rounds leave (everything when nsub == 0), so nsub only
 // trades launches for finisher iterations; the host picks it from the contention it has observed so far.
-void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 *epoch, hipStream_t st, KernelProf *prof)
+void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 *epoch, int flags, hipStream_t st, KernelProf *prof)
 {
 	const int nb = md.nb;
 	if (nsub < 0) nsub = 0;
@@ -1678,8 +1678,7 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_verify_commit<W, NHM>), grid, blk, 0, st, md, bd, t, pp, eb));
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_SLOW, st);
-	const char *lg = getenv("KMX_RESOLVE_GATHER");               // test hook: the gathering resolve kernel for level 0 too
-	const bool legacy0 = lg && atoi(lg);
+	const bool legacy0 = flags & KMX_ROUND_RESOLVE_GATHER;      // test hook: the gathering resolve kernel for level 0 too
 	for (int s = 0; s < nsub; s++) {
 		u64 e = eb;
 		if (s > 0) {
@@ -1689,8 +1688,7 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 		if (s == 0 && !legacy0) DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_resolve0<W, NHM>), sgrid, blk, 0, st, md, bd, t, pp, e));
 		else DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_resolve<W, NHM>), sgrid, blk, 0, st, md, bd, t, pp, s, e));
 	}
-	const char *fg = getenv("KMX_FIN_GLOBAL");                   // test hook: the finisher's global-memory path for every set
-	const int force_global = fg ? atoi(fg) : 0;
+	const int force_global = (flags & KMX_ROUND_FIN_GLOBAL) ? 1 : 0;   // test hook: the finisher's global-memory path for every set
 	const u64 e0 = *epoch;
 	*epoch += (1ULL << 19);                                    // the finisher may use up to |U| <= 2^18 epochs
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb, 1 + KMX_FIN_HELPERS), dim3(1024), 0, st, md, bd, t, pp, nsub, eb, e0, force_global));

@@ -26,7 +26,7 @@ int classify_tiles(u64 n);
 void classify_count(const ModelDev &, const u64 *, const u32 *, u64, u64, int *, int *, int *, u64 *, hipStream_t, KernelProf *);
 void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int *, u64 *, u32 *, u64, hipStream_t);
 void block_init(const BlockDev &, int, int, int, hipStream_t);
-void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, hipStream_t, KernelProf *);
+void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *);
 void rest_append(const ModelDev &, const BlockDev &, int, u64 *, int *, unsigned long long *, u64 *, int *, hipStream_t);
 void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *);
 void query_ascii(const ModelDev &, int, const unsigned char *, int, u64, int *, hipStream_t);
@@ -173,6 +173,10 @@ struct kmx_model {
 	u64 *h_feedback = nullptr;                                 // pinned: ST_MAX_U0 as of some earlier block (heuristic input)
 	u64 epoch = 1, blocks = 0, rounds = 0;
 	int nsub = 1;                                              // grid-wide ordered passes in round 0 (see process_block)
+	// test hooks, read from the environment by kmx_begin: forced pass counts, forced older code
+	// paths (KMX_ROUND_* flags of kmx_types.h), a trace of the pass-count controller
+	int dbg_nsub0 = -1, dbg_nsub1 = -1, dbg_flags = 0;
+	bool dbg_ctrl = false;
 	u64 h_stats[ST_N] = {0};
 	double t_insert_kernels = 0, t_total = 0;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -302,6 +306,13 @@ static int kmx_create_impl(int ci, int cs, int nh, int nb, kmx_model **out)
 	HIPCHK(hipHostMalloc((void **)&m->h_total, 64));
 	HIPCHK(hipHostMalloc((void **)&m->h_feedback, 64));
 	m->h_feedback[0] = ~0ULL; m->h_feedback[1] = 0;
+	{
+		auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+		m->dbg_nsub0 = env_int("KMX_NSUB0", -1);
+		m->dbg_nsub1 = env_int("KMX_NSUB1", -1);
+		m->dbg_flags = (env_int("KMX_FIN_GLOBAL", 0) ? KMX_ROUND_FIN_GLOBAL : 0) | (env_int("KMX_RESOLVE_GATHER", 0) ? KMX_ROUND_RESOLVE_GATHER : 0);
+		m->dbg_ctrl = env_int("KMX_CTRL_DEBUG", 0) != 0;
+	}
 	HIPCHK(hipEventCreate(&m->ev0));
 	HIPCHK(hipEventCreate(&m->ev1));
 	HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
@@ -522,8 +533,7 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 	// launch-count heuristic only, never the result): the largest contended set per list, and the largest set that
 	// reached the single-workgroup finisher.  Small sets are decided by the finisher alone; when too much reaches it,
 	// grid-wide ordered passes are added in front of it.
-	static const int force0 = getenv("KMX_NSUB0") ? atoi(getenv("KMX_NSUB0")) : -1;
-	static const int force1 = getenv("KMX_NSUB1") ? atoi(getenv("KMX_NSUB1")) : -1;
+	const int force0 = m->dbg_nsub0, force1 = m->dbg_nsub1;
 	const u64 u0 = ((volatile u64 *)m->h_feedback)[0], ufin = ((volatile u64 *)m->h_feedback)[1];
 	if (u0 != ~0ULL) {
 		const u64 fin = 1024ull * KMX_FIN_RPT(m->nh <= 8 ? 8 : 16);
@@ -531,12 +541,12 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 		else if (m->nsub > 0 && u0 <= fin * 7 / 8) m->nsub--;               // the finisher could have taken all of it in one load
 		else if (m->nsub > 1 && ufin < fin / 4) m->nsub--;
 	}
-	if (getenv("KMX_CTRL_DEBUG")) fprintf(stderr, "[kmx] block %llu feedback u0=%lld ufin=%lld -> nsub=%d\n", (unsigned long long)m->blocks, (long long)u0, (long long)ufin, m->nsub);
+	if (m->dbg_ctrl) fprintf(stderr, "[kmx] block %llu feedback u0=%lld ufin=%lld -> nsub=%d\n", (unsigned long long)m->blocks, (long long)u0, (long long)ufin, m->nsub);
 	for (int t = 0; t < nb; t++) {
 		int nsub = t == 0 ? m->nsub : m->nsub / 2;
 		if (t == 0 && force0 >= 0) nsub = force0;
 		if (t > 0 && force1 >= 0) nsub = force1;
-		kmxk::round(m->md, m->bd, t, pp, nsub, &m->epoch, m->stream, &m->prof);
+		kmxk::round(m->md, m->bd, t, pp, nsub, &m->epoch, m->dbg_flags, m->stream, &m->prof);
 		pp ^= 1;
 		m->rounds++;
 	}

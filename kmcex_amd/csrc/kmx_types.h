@@ -37,6 +37,7 @@ enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, 
 #define KMX_FIN_RANGES 8                        // the finisher takes up to this many register loads, in index ranges
 #define KMX_FIN_HELPERS 3                       // extra workgroups per list that drop the claim bits beside the finisher
 #define KMX_APPLY_WGS 8                         // extra workgroups per list in k_reorder that apply the finisher's decisions
+enum { KMX_ROUND_FIN_GLOBAL = 1, KMX_ROUND_RESOLVE_GATHER = 2 };   // test hooks of kmxk::round (older code paths)
 #define KMX_NSLOW 2                            // contended-record levels, ping-pong: pass s reads level s&1, defers to (s+1)&1
 #define KMX_MAX_NSUB 16                        // most grid-wide ordered passes per round
 #define KMX_CTR_STRIDE 32                      // ints between per-list counters: one 128-byte line each (same-line atomics serialise)

@@ -171,21 +171,28 @@ def test_heavy_collision_tiny_arrays():
                          ids=lambda c: "k%d_nh%d_nb%d_n%d" % (c[0], c[3], c[4], c[5]))
 def test_both_finisher_paths_bit_exact(cfg, monkeypatch):
     """The single-workgroup finisher has an LDS path (sets up to 2048 / 1024 records) and a global-memory path (larger
-    sets).  Both must give the oracle's arrays on the same input: KMX_FIN_GLOBAL=1 sends every set through the second."""
+    sets).  Both must give the oracle's arrays on the same input: KMX_FIN_GLOBAL=1 sends every set through the second;
+    KMX_NSUB0/1 force the number of grid-wide passes in front of it (0: the finisher alone, from verify_commit's
+    snapshot; 2: resolve + reserve/resolve first) and KMX_RESOLVE_GATHER=1 the gathering form of the first pass.  The
+    hooks are read by kmx_begin, once per build."""
     k, ci, cs, nh, nb, n = cfg
     km, cnt = synth.make_stream(n, k, ci, cs, seed_k=4242, seed_c=4243)
     o = O.OracleModel(ci, cs, nh, nb)
     o.build(k, km, cnt)
     so = o.stats()
-    for force_global in (0, 1):
+    for force_global, nsub0, gather in ((0, -1, 0), (1, -1, 0), (0, 0, 0), (0, 2, 0), (0, 2, 1), (1, 1, 1)):
         monkeypatch.setenv("KMX_FIN_GLOBAL", str(force_global))
+        monkeypatch.setenv("KMX_NSUB0", str(nsub0))
+        monkeypatch.setenv("KMX_NSUB1", str(nsub0))
+        monkeypatch.setenv("KMX_RESOLVE_GATHER", str(gather))
         m = KModel(ci, cs, nh, nb)
         m.build_packed(k, km, cnt)
         st = m.stats()
         _check_arrays(m, o, nb, st.bf_num)
         assert (st.attempts, st.successes, st.rest_entries) == (so.attempts, so.successes, so.rest_entries)
         assert st.contended > 0
-    monkeypatch.delenv("KMX_FIN_GLOBAL")
+    for v in ("KMX_FIN_GLOBAL", "KMX_NSUB0", "KMX_NSUB1", "KMX_RESOLVE_GATHER"):
+        monkeypatch.delenv(v)
 
 
 def test_error_behaviour():
