@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -851,6 +852,9 @@ struct FeedSlot {
 };
 }   // namespace
 
+// KModel::init(db_file) (kmodel.hpp:57-87).  Pass 1 counts the classes on the host (parallel, counts only).  Pass 2 is a
+// three-stage pipeline: a producer thread decodes the listing into two pinned slots; a copy stream moves a slot into
+// one of two device buffers while the model's stream is still inserting the previous batch; the insert itself.
 static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 {
 	if (!m || !db_prefix) return fail(KMX_E_ARG, "null argument");
@@ -862,22 +866,44 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 	const size_t B = size_t(1) << 22;
 	HIPCHK(hipSetDevice(m->device));
 	FeedSlot slot[2];
-	u64 *dk = nullptr;
-	u32 *dc = nullptr;
+	u64 *dk[2] = {nullptr, nullptr};
+	u32 *dc[2] = {nullptr, nullptr};
+	hipStream_t copy = nullptr;
+	hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
 	auto cleanup = [&] {
-		for (auto &sl : slot) { if (sl.km) hipHostFree(sl.km); if (sl.cnt) hipHostFree(sl.cnt); }
-		hipFree(dk); hipFree(dc);
+		if (copy) { hipStreamSynchronize(copy); hipStreamDestroy(copy); }
+		hipStreamSynchronize(m->stream);
+		for (int s = 0; s < 2; s++) {
+			if (slot[s].km) hipHostFree(slot[s].km);
+			if (slot[s].cnt) hipHostFree(slot[s].cnt);
+			hipFree(dk[s]); hipFree(dc[s]);
+			if (ev_copied[s]) hipEventDestroy(ev_copied[s]);
+			if (ev_free[s]) hipEventDestroy(ev_free[s]);
+		}
 	};
-	for (auto &sl : slot)
-		if (hipHostMalloc((void **)&sl.km, B * W * 8) != hipSuccess || hipHostMalloc((void **)&sl.cnt, B * 4) != hipSuccess) { cleanup(); return fail(KMX_E_NOMEM, "pinned allocation failed"); }
-	if (hipMalloc((void **)&dk, B * W * 8) != hipSuccess || hipMalloc((void **)&dc, B * 4) != hipSuccess) { cleanup(); return fail(KMX_E_NOMEM, "device allocation failed"); }
 	hipEventRecord(m->ev0, m->stream);
+	// the buffers of pass 2 are allocated beside pass 1 (pinned allocations take ~10 ms)
+	bool ok = false;
+	std::thread allocator([&] {
+		if (hipSetDevice(m->device) != hipSuccess) return;
+		bool good = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) == hipSuccess;
+		for (int s = 0; s < 2 && good; s++)
+			good = hipHostMalloc((void **)&slot[s].km, B * W * 8) == hipSuccess && hipHostMalloc((void **)&slot[s].cnt, B * 4) == hipSuccess &&
+			       hipMalloc((void **)&dk[s], B * W * 8) == hipSuccess && hipMalloc((void **)&dc[s], B * 4) == hipSuccess &&
+			       hipEventCreateWithFlags(&ev_copied[s], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev_free[s], hipEventDisableTiming) == hipSuccess;
+		ok = good;
+	});
 	uint64_t nbf[3] = {0, 0, 0};
 	int rc = KMX_OK;
 	uint64_t bad = 0;
+	const auto t_p1 = std::chrono::steady_clock::now();
 	db.count_classes((u32)m->ci, (u32)m->cs, m->bf_num, nbf, &bad);          // pass 1 (kmodel.hpp:423-428), parallel, counts only
+	const double s_p1 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_p1).count();
+	allocator.join();
+	if (!ok) { cleanup(); return fail(KMX_E_NOMEM, "pinned / device buffers for the listing feed could not be allocated"); }
 	if (bad) rc = fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)bad, m->ci, m->cs);
 	if (!rc) rc = kmx_begin(m, k, nbf, db.kmer_count());
+	double s_wait = 0;
 	if (!rc) {
 		db.restart();                                                          // kmodel.hpp:430
 		std::mutex mu;
@@ -891,18 +917,44 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 				if (!got) break;
 			}
 		});
-		for (int s = 0;; s ^= 1) {                                              // pass 2 (kmodel.hpp:68-74)
-			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return slot[s].full; }); }
-			if (slot[s].last) break;
-			if (!rc) {
-				const size_t n = slot[s].n;
-				if (hipMemcpyAsync(dk, slot[s].km, n * W * 8, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
-				    hipMemcpyAsync(dc, slot[s].cnt, n * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
-				else rc = kmx_insert_batch_dev(m, (const uint64_t *)dk, dc, n);  // synchronises the stream, so the slot is free again
-			}
+		// pass 2 (kmodel.hpp:68-74).  Batch b travels through slot b%2 and device buffer b%2; its copy is enqueued one
+		// batch ahead of its insert, so it runs under the rounds of batch b-1.
+		auto enqueue_copy = [&](int s) -> bool {                               // slot s is full
+			if (hipStreamWaitEvent(copy, ev_free[s], 0) != hipSuccess) return false;      // the insert that read dk[s] two batches ago
+			if (hipMemcpyAsync(dk[s], slot[s].km, slot[s].n * W * 8, hipMemcpyHostToDevice, copy) != hipSuccess) return false;
+			if (hipMemcpyAsync(dc[s], slot[s].cnt, slot[s].n * 4, hipMemcpyHostToDevice, copy) != hipSuccess) return false;
+			return hipEventRecord(ev_copied[s], copy) == hipSuccess;
+		};
+		auto wait_full = [&](int s) {
+			const auto t0 = std::chrono::steady_clock::now();
+			std::unique_lock<std::mutex> lk(mu);
+			cv.wait(lk, [&] { return slot[s].full; });
+			s_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		};
+		auto release = [&](int s) {
 			{ std::lock_guard<std::mutex> lk(mu); slot[s].full = false; }
 			cv.notify_all();
+		};
+		hipEventRecord(ev_free[0], m->stream);
+		hipEventRecord(ev_free[1], m->stream);
+		wait_full(0);
+		bool copied = !slot[0].last && enqueue_copy(0);
+		if (!slot[0].last && !copied) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
+		for (int s = 0; !slot[s].last; s ^= 1) {
+			const size_t n = slot[s].n;
+			// the next batch: decoded meanwhile by the producer, copied under this batch's rounds
+			wait_full(s ^ 1);
+			if (!rc && !slot[s ^ 1].last && !enqueue_copy(s ^ 1)) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
+			if (!rc) {
+				if (hipStreamWaitEvent(m->stream, ev_copied[s], 0) != hipSuccess) rc = fail(KMX_E_NODEVICE, "stream wait failed");
+				else rc = kmx_insert_batch_dev(m, (const uint64_t *)dk[s], dc[s], n);
+				hipEventRecord(ev_free[s], m->stream);                       // everything that reads dk[s] is enqueued by now
+			}
+			hipEventSynchronize(ev_copied[s]);                               // the pinned slot has been read
+			release(s);
 		}
+		// let the producer run to its end on every path
+		for (int s = 0; s < 2; s++) release(s);
 		producer.join();
 	}
 	if (!rc) rc = kmx_finish(m);
@@ -912,6 +964,7 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 		float ms = 0;
 		hipEventElapsedTime(&ms, m->ev0, m->ev1);
 		m->t_total = ms * 1e-3;
+		if (m->dbg_ctrl) fprintf(stderr, "[kmx] init(db): pass 1 %.1f ms, waited %.1f ms for the listing in pass 2, total %.1f ms\n", s_p1 * 1e3, s_wait * 1e3, (double)ms);
 	}
 	cleanup();
 	return rc;
