@@ -13,7 +13,7 @@ TOUCHES = 1 << 28
 
 
 def agg(tag, c):
-    fs = glob.glob(f"{root}/{tag}{c}/*/*counter_collection.csv")
+    fs = glob.glob(f"{root}/{tag}{c}/*/*counter_collection.csv") + glob.glob(f"{root}/{tag}{c}/*counter_collection.csv")
     a = collections.defaultdict(lambda: [0, 0.0])
     if fs:
         for r in csv.DictReader(open(fs[0])):
