@@ -14,11 +14,13 @@
 //   B  verify_commit a candidate that sees no OPPOSITE claim on its untagged positions cannot interact
 //                    with any other candidate of the list, so it commits (atomic OR) in parallel;
 //                    the others form the contended set U;
-//   S  slow path     U is resolved in list order by epoch-tagged min-index reservations: a k-mer that
-//                    holds the smallest index on all its slots has no earlier undecided k-mer touching
-//                    them, so its outcome is the sequential one.  Two grid-wide sub-rounds, then a
-//                    single-workgroup finisher that iterates until the set is empty.
-//   R  reorder       the reference's unstable compaction (kmodel.hpp:529-540) as count/scatter/fill.
+//   S  slow path     U is resolved in list order by priority reservations: a k-mer that holds the smallest
+//                    index on all its slots has no earlier undecided k-mer touching them, so its outcome is
+//                    the sequential one.  A single-workgroup finisher per list decides in LDS (k_slow_finish);
+//                    grid-wide passes (k_slow_resolve0 / k_slow_reserve / k_slow_resolve) run first when U is
+//                    larger than what its registers hold.
+//   R  reorder       applies what the finisher decided, then the reference's unstable compaction
+//                    (kmodel.hpp:529-540) in one launch with lazily filled holes.
 #include "kmx_types.h"
 #include <cstdlib>
 
@@ -1006,7 +1008,7 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 // (below m) receives the i-th survivor from the right (at or above m).  ONE launch: the tile survivor counts were
 // accumulated while the slots failed; holes are written as (LIST_HOLE | rank) and filled lazily from mover[] by the
 // next round's check_claim (or by rest_append after the last round), so no grid-wide fill pass is needed.
-// Also closes the round's books: successes = n - m, contended = |U0|; resets the counters of the next round.
+// Also closes the round's books: successes = n - m.
 // Before that, it applies what the finisher decided but left undone (REC_WON records of level lv): tag/value bits
 // (kmodel.hpp:611-618, every position: an already tagged one carries the same value) and the km_back insert (:548-550).
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(ModelDev md, BlockDev bd, int t, int pp, int lv)
