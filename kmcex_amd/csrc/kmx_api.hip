@@ -20,6 +20,10 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace kmxk {
 void histogram(const u32 *, u64, int, int, int, u64 *, u64 *, hipStream_t);
@@ -41,6 +45,7 @@ hipError_t rest_sort(const u64 *, const int *, u64, int, int, u64 *, int *, hipS
 hipError_t rest_index(const u64 *, u64, int, int, int, int *, int *, u64 *, int *, hipStream_t);
 void rest_expand(const int *, const int *, const u64 *, int, int, int, int, u64 *, hipStream_t);
 void rest_accel(const u64 *, u64, int, int, int, const int *, const int *, const u64 *, int, u32 *, u64 *, hipStream_t);
+void rest_suffix_bytes(const u64 *, u64, int, int, unsigned char *, hipStream_t);
 }   // namespace kmxk
 
 // ------------------------------------------------------------------------------------------ errors
@@ -718,20 +723,19 @@ static int rest_materialize_host(kmx_model *m)
 	RestTable &r = m->rest;
 	if (r.host_valid) return KMX_OK;
 	const u64 n = r.entries;
-	const int W = m->W;
-	std::vector<u64> km(n * W + 1);
 	r.hash2index.resize(r.map_size); r.pre_buffer.resize(r.pre_buffer_size); r.count_bin.resize(n);
+	r.suffix_bin.assign(r.suff_bin_size, 0);
 	HIPCHK(hipMemcpy(r.hash2index.data(), r.d_h2i, (u64)r.map_size * 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(r.pre_buffer.data(), r.d_pre, (u64)r.pre_buffer_size * 4, hipMemcpyDeviceToHost));
 	if (n) {
-		HIPCHK(hipMemcpy(km.data(), r.d_sorted, n * W * 8, hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(r.count_bin.data(), r.d_cnt, n * 4, hipMemcpyDeviceToHost));
-	}
-	r.suffix_bin.assign(r.suff_bin_size, 0);
-	for (u64 e = 0; e < n; e++) {
-		unsigned __int128 val = W == 2 ? (((unsigned __int128)km[2 * e] << 64) | km[2 * e + 1]) : (unsigned __int128)km[e];
-		for (int g = 0; g < r.suff_group; g++)
-			r.suffix_bin[e * (u64)r.suff_group + g] = (unsigned char)(val >> (8 * (r.suff_group - 1 - g)));
+		unsigned char *d_bytes = nullptr;                           // the byte rows are cut on the device
+		HIPCHK(hipMalloc((void **)&d_bytes, r.suff_bin_size));
+		kmxk::rest_suffix_bytes(r.d_sorted, n, m->W, r.suff_group, d_bytes, m->stream);
+		hipError_t e = hipMemcpyAsync(r.suffix_bin.data(), d_bytes, r.suff_bin_size, hipMemcpyDeviceToHost, m->stream);
+		if (e == hipSuccess) e = hipMemcpyAsync(r.count_bin.data(), r.d_cnt, n * 4, hipMemcpyDeviceToHost, m->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+		hipFree(d_bytes);
+		if (e != hipSuccess) return fail(KMX_E_NODEVICE, "rest table download failed");
 	}
 	r.host_valid = true;
 	return KMX_OK;
@@ -1124,6 +1128,99 @@ static int kmx_download_impl(kmx_model *m, int which, int index, uint8_t *dst, u
 	return KMX_OK;
 }
 
+// km.bin (Appendix B.1): u64 n_km, u64 n_bf[bf_num], then bf / bf_back per filter, km_back, and bit_array_1 (value) /
+// bit_array_2 (tag) per coupled array.  Streamed: the model's stream de-interleaves one array at a time and copies it
+// into a ring of pinned chunks; writer threads pwrite the chunks at their final offsets, so the copy, the page-cache
+// writes and the next array's kernel overlap.
+namespace {
+struct SaveChunk {
+	unsigned char *buf = nullptr;
+	hipEvent_t ready = nullptr;
+	u64 len = 0, off = 0;
+	int state = 0;                                              // 0 free, 1 filled (copy enqueued), 2 being written
+};
+}
+
+static int save_km_bin(kmx_model *m, const std::string &path)
+{
+	const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+	if (fd < 0) return fail(KMX_E_IO, "cannot write %s", path.c_str());
+	u64 head[4] = {m->n_km, 0, 0, 0};
+	for (int i = 0; i < m->bf_num; i++) head[1 + i] = m->n_bf[i];
+	const u64 head_bytes = 8 * (1 + (u64)m->bf_num);
+	bool io_ok = pwrite(fd, head, head_bytes, 0) == (ssize_t)head_bytes;
+	constexpr int R = 6, T = 4;
+	constexpr u64 CH = 16ull << 20;
+	SaveChunk ring[R];
+	unsigned char *tmp = nullptr;
+	int rc = KMX_OK;
+	for (auto &c : ring)
+		if (hipHostMalloc((void **)&c.buf, CH) != hipSuccess || hipEventCreateWithFlags(&c.ready, hipEventDisableTiming) != hipSuccess) rc = fail(KMX_E_NOMEM, "pinned buffers for save could not be allocated");
+	if (!rc && m->km_byte_size && hipMalloc((void **)&tmp, m->ncells * 2) != hipSuccess) rc = fail(KMX_E_NOMEM, "device buffer for save could not be allocated");
+	std::mutex mu;
+	std::condition_variable cv;
+	bool done = false;
+	std::vector<std::thread> writers;
+	if (!rc)
+		for (int t = 0; t < T; t++)
+			writers.emplace_back([&] {
+				for (;;) {
+					SaveChunk *c = nullptr;
+					{
+						std::unique_lock<std::mutex> lk(mu);
+						cv.wait(lk, [&] {
+							for (auto &x : ring) if (x.state == 1) { c = &x; return true; }
+							return done;
+						});
+						if (!c) return;
+						c->state = 2;
+					}
+					bool ok = hipEventSynchronize(c->ready) == hipSuccess;
+					for (u64 w = 0; ok && w < c->len;) {
+						const ssize_t k = pwrite(fd, c->buf + w, c->len - w, (off_t)(c->off + w));
+						if (k <= 0) ok = false; else w += (u64)k;
+					}
+					{ std::lock_guard<std::mutex> lk(mu); c->state = 0; if (!ok) io_ok = false; }
+					cv.notify_all();
+				}
+			});
+	u64 off = head_bytes;
+	auto emit = [&](const unsigned char *dsrc, u64 nbytes) {                 // device bytes -> file at `off`
+		for (u64 pos = 0; pos < nbytes && !rc; pos += CH) {
+			const u64 len = std::min<u64>(CH, nbytes - pos);
+			SaveChunk *c = nullptr;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&] { for (auto &x : ring) if (x.state == 0) { c = &x; return true; } return false; });
+			}
+			if (hipMemcpyAsync(c->buf, dsrc + pos, len, hipMemcpyDeviceToHost, m->stream) != hipSuccess || hipEventRecord(c->ready, m->stream) != hipSuccess) { rc = fail(KMX_E_NODEVICE, "D2H copy failed"); break; }
+			c->len = len; c->off = off + pos;
+			{ std::lock_guard<std::mutex> lk(mu); c->state = 1; }
+			cv.notify_all();
+		}
+		off += nbytes;
+	};
+	if (!rc) {
+		for (int i = 0; i < m->bf_num; i++) { emit((const unsigned char *)m->d_bf[i], m->byte_bf[i]); emit((const unsigned char *)m->d_bf_back[i], m->byte_bf_back[i]); }
+		emit((const unsigned char *)m->d_km_back, m->byte_km_back);
+		for (int a = 0; a < m->nb && !rc && m->km_byte_size; a++)
+			for (int which = 0; which < 2; which++) {                          // bit_array_1 (value), bit_array_2 (tag)
+				kmxk::cells_to_disk(m->d_cells[a], m->ncells, m->km_byte_size, which, tmp, m->stream);   // waits, in stream order, for the copies out of tmp
+				emit(tmp, m->km_byte_size);
+			}
+	}
+	{ std::lock_guard<std::mutex> lk(mu); done = true; }
+	cv.notify_all();
+	// the writers drain what is filled before they see `done` with nothing left
+	for (auto &w : writers) w.join();
+	hipStreamSynchronize(m->stream);
+	for (auto &c : ring) { if (c.buf) hipHostFree(c.buf); if (c.ready) hipEventDestroy(c.ready); }
+	hipFree(tmp);
+	if (close(fd) != 0) io_ok = false;
+	if (!rc && !io_ok) rc = fail(KMX_E_IO, "short write to %s", path.c_str());
+	return rc;
+}
+
 // KModel::save (kmodel.hpp:173-206) + KRestData::save_file (rest.hpp:197-221); layouts: Appendix B.1/B.2
 static int kmx_save_impl(kmx_model *m, const char *dir)
 {
@@ -1136,23 +1233,11 @@ static int kmx_save_impl(kmx_model *m, const char *dir)
 	if (!f) return fail(KMX_E_IO, "cannot write %s/header", dir);
 	fprintf(f, "number_hash %d\nnumber_bit %d\nci %d\ncs %d\n", m->nh, m->nb, m->ci, m->cs);
 	fclose(f);
-	if (!(f = fopen((d + "/km.bin").c_str(), "wb"))) return fail(KMX_E_IO, "cannot write %s/km.bin", dir);
-	fwrite(&m->n_km, 8, 1, f);
-	for (int i = 0; i < m->bf_num; i++) fwrite(&m->n_bf[i], 8, 1, f);
-	std::vector<unsigned char> v;
-	int rc = KMX_OK;
-	for (int i = 0; i < m->bf_num && !rc; i++) {
-		if (!(rc = download_array(m, 0, i, v))) fwrite(v.data(), 1, v.size(), f);
-		if (!rc && !(rc = download_array(m, 1, i, v))) fwrite(v.data(), 1, v.size(), f);
-	}
-	if (!rc && !(rc = download_array(m, 2, 0, v))) fwrite(v.data(), 1, v.size(), f);
-	for (int a = 0; a < m->nb && !rc; a++) {
-		if (!(rc = download_array(m, 3, a, v))) fwrite(v.data(), 1, v.size(), f);             // bit_array_1 (value)
-		if (!rc && !(rc = download_array(m, 4, a, v))) fwrite(v.data(), 1, v.size(), f);      // bit_array_2 (tag)
-	}
-	fclose(f);
-	if (rc) return rc;
+	const auto t0 = std::chrono::steady_clock::now();
+	TRY(save_km_bin(m, d + "/km.bin"));
+	const auto t1 = std::chrono::steady_clock::now();
 	TRY(rest_materialize_host(m));
+	const auto t2 = std::chrono::steady_clock::now();
 	const RestTable &r = m->rest;
 	if (!(f = fopen((d + "/rest.bin").c_str(), "wb"))) return fail(KMX_E_IO, "cannot write %s/rest.bin", dir);
 	int h[4] = {r.k, r.pre_len, r.map_size, r.pre_buffer_size};
@@ -1164,6 +1249,11 @@ static int kmx_save_impl(kmx_model *m, const char *dir)
 	fwrite(r.suffix_bin.data(), 1, r.suffix_bin.size(), f);
 	fwrite(r.count_bin.data(), 4, r.count_bin.size(), f);
 	fclose(f);
+	if (m->dbg_ctrl) {
+		const auto t3 = std::chrono::steady_clock::now();
+		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count() * 1e3; };
+		fprintf(stderr, "[kmx] save: km.bin %.1f ms, rest table to host form %.1f ms, rest.bin %.1f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3));
+	}
 	return KMX_OK;
 }
 
@@ -1207,20 +1297,35 @@ static int kmx_load_impl(const char *dir, kmx_model **out)
 	fclose(f);
 	if (!ok) return bail(fail(KMX_E_IO, "malformed %s/rest.bin", dir));
 	m->k = r.k; m->W = (r.k + 31) / 32;
-	if (!(f = fopen((d + "/km.bin").c_str(), "rb"))) return bail(fail(KMX_E_IO, "cannot open %s/km.bin", dir));
-	ok = fread(&m->n_km, 8, 1, f) == 1;
+	// km.bin is mapped and copied to the device section by section, without a staging read
+	const int fd = open((d + "/km.bin").c_str(), O_RDONLY);
+	if (fd < 0) return bail(fail(KMX_E_IO, "cannot open %s/km.bin", dir));
+	struct stat sb;
+	const unsigned char *map = nullptr;
+	if (fstat(fd, &sb) == 0 && sb.st_size >= 16) map = (const unsigned char *)mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+	close(fd);
+	if (!map || map == (const unsigned char *)MAP_FAILED) return bail(fail(KMX_E_IO, "malformed %s/km.bin", dir));
+	const u64 fsize = (u64)sb.st_size;
+	auto unmap = [&] { munmap((void *)map, (size_t)fsize); };
+	u64 off = 0;
+	memcpy(&m->n_km, map, 8); off = 8;
 	u64 nbf = 0;
-	for (int i = 0; i < m->bf_num && ok; i++) { ok = fread(&m->n_bf[i], 8, 1, f) == 1; nbf += m->n_bf[i]; }
-	if (!ok) { fclose(f); return bail(fail(KMX_E_IO, "malformed %s/km.bin", dir)); }
+	ok = fsize >= 8 * (1 + (u64)m->bf_num);
+	for (int i = 0; i < m->bf_num && ok; i++) { memcpy(&m->n_bf[i], map + off, 8); off += 8; nbf += m->n_bf[i]; }
+	if (!ok) { unmap(); return bail(fail(KMX_E_IO, "malformed %s/km.bin", dir)); }
 	m->n_total = m->n_km + nbf;
 	compute_sizes(m);
+	{
+		u64 need = off + m->byte_km_back + 2 * m->km_byte_size * (u64)m->nb;
+		for (int i = 0; i < m->bf_num; i++) need += m->byte_bf[i] + m->byte_bf_back[i];
+		if (fsize < need) { unmap(); return bail(fail(KMX_E_IO, "short or unreadable %s/km.bin", dir)); }
+	}
 	int rc = alloc_arrays(m);
-	if (rc) { fclose(f); return bail(rc); }
-	std::vector<unsigned char> buf, buf2;
-	auto upload = [&](u32 *dst, u64 nbytes) -> bool {
-		buf.resize(nbytes);
-		if (nbytes && fread(buf.data(), 1, nbytes, f) != nbytes) return false;
-		return !nbytes || hipMemcpy(dst, buf.data(), nbytes, hipMemcpyHostToDevice) == hipSuccess;
+	if (rc) { unmap(); return bail(rc); }
+	auto upload = [&](void *dst, u64 nbytes) -> bool {
+		const bool good = !nbytes || hipMemcpyAsync(dst, map + off, nbytes, hipMemcpyHostToDevice, m->stream) == hipSuccess;
+		off += nbytes;
+		return good;
 	};
 	for (int i = 0; i < m->bf_num && ok; i++) ok = upload(m->d_bf[i], m->byte_bf[i]) && upload(m->d_bf_back[i], m->byte_bf_back[i]);
 	ok = ok && upload(m->d_km_back, m->byte_km_back);
@@ -1228,15 +1333,14 @@ static int kmx_load_impl(const char *dir, kmx_model **out)
 	if (ok && m->km_byte_size) {
 		ok = hipMalloc((void **)&dv, m->ncells * 2) == hipSuccess && hipMalloc((void **)&dt, m->ncells * 2) == hipSuccess;
 		for (int a = 0; a < m->nb && ok; a++) {
-			buf.resize(m->km_byte_size); buf2.resize(m->km_byte_size);
-			ok = fread(buf.data(), 1, m->km_byte_size, f) == m->km_byte_size && fread(buf2.data(), 1, m->km_byte_size, f) == m->km_byte_size;
-			ok = ok && hipMemcpy(dv, buf.data(), m->km_byte_size, hipMemcpyHostToDevice) == hipSuccess &&
-			     hipMemcpy(dt, buf2.data(), m->km_byte_size, hipMemcpyHostToDevice) == hipSuccess;
-			if (ok) { kmxk::cells_from_disk(dv, dt, m->km_byte_size, m->d_cells[a], m->ncells, m->stream); ok = hipStreamSynchronize(m->stream) == hipSuccess; }
+			ok = upload(dv, m->km_byte_size) && upload(dt, m->km_byte_size);
+			if (ok) kmxk::cells_from_disk(dv, dt, m->km_byte_size, m->d_cells[a], m->ncells, m->stream);
 		}
+		ok = ok && hipStreamSynchronize(m->stream) == hipSuccess;
 		hipFree(dv); hipFree(dt);
 	}
-	fclose(f);
+	ok = ok && hipStreamSynchronize(m->stream) == hipSuccess;
+	unmap();
 	if (!ok) return bail(fail(KMX_E_IO, "short or unreadable %s/km.bin", dir));
 	rc = rest_to_device(m);
 	if (rc) return bail(rc);

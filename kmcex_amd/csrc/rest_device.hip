@@ -117,6 +117,18 @@ inline unsigned nblk(u64 n) { return (unsigned)((n + 255) / 256); }
 
 }   // namespace
 
+// rest.bin's suffix_bin (Appendix B.2): the low suff_group bytes of every sorted k-mer, most significant byte first
+__global__ __launch_bounds__(256) void k_rest_suffix_bytes(const u64 *km, u64 n, int W, int suff_group, unsigned char *out)
+{
+	const u64 e = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (e >= n) return;
+	const u64 lo = km[e * W + (W - 1)], hi = W == 2 ? km[e * W] : 0;
+	for (int g = 0; g < suff_group; g++) {
+		const int sh = 8 * (suff_group - 1 - g);
+		out[e * (u64)suff_group + g] = (unsigned char)(sh >= 64 ? hi >> (sh - 64) : lo >> sh);
+	}
+}
+
 namespace kmxk {
 
 #define RCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
@@ -193,6 +205,11 @@ void rest_accel(const u64 *km_sorted, u64 n, int W, int k, int F, const int *h2i
 	const u64 nbuckets = 1ULL << F;
 	hipLaunchKernelGGL(k_fine_index, dim3(nblk(nbuckets + 1)), dim3(256), 0, st, km_sorted, n, W, 2 * k - F, nbuckets, fine);
 	hipLaunchKernelGGL(k_next_first, dim3(nblk(map_size)), dim3(256), 0, st, h2i, pre, suf, n, map_size, W, q);
+}
+
+void rest_suffix_bytes(const u64 *km_sorted, u64 n, int W, int suff_group, unsigned char *out, hipStream_t st)
+{
+	if (n) hipLaunchKernelGGL(k_rest_suffix_bytes, dim3(nblk(n)), dim3(256), 0, st, km_sorted, n, W, suff_group, out);
 }
 
 }   // namespace kmxk
