@@ -16,6 +16,7 @@
 #include <cstring>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1036,30 +1037,31 @@ static int kmx_query_ascii_impl(kmx_model *m, const char *strs, int len, int str
 	if (len < 2 || len > 64 || stride < len) return fail(KMX_E_ARG, "k-mer strings must hold 2..64 characters (got %d, stride %d)", len, stride);
 	if (!n) return KMX_OK;
 	bool clean = len == m->k;
-	std::vector<u64> pk(clean ? n * m->W : 0);
+	std::unique_ptr<u64[]> pk_mem(clean ? new u64[n * m->W] : nullptr);   // not zero-filled: every word is written below
+	u64 *pk = pk_mem.get();
 	if (clean) {                                              // pack on up to 16 host threads
 		const unsigned hw = std::thread::hardware_concurrency();
 		const int T = (int)std::max<u64>(1, std::min<u64>(std::min<unsigned>(hw ? hw : 1, 16), n / 65536 + 1));
 		std::vector<char> ok(T, 1);
+		static const struct Lut { unsigned char c[256]; Lut() { memset(c, 0x80, sizeof c); c['A'] = 0; c['C'] = 1; c['G'] = 2; c['T'] = 3; } } lut;
 		auto work = [&](int t) {
 			const u64 per = (n + T - 1) / T, lo = (u64)t * per, hi = std::min<u64>(n, lo + per);
+			unsigned bad = 0;
 			for (u64 i = lo; i < hi; i++) {
-				unsigned __int128 v = 0;
-				const char *s = strs + i * (u64)stride;
-				for (int j = 0; j < len; j++) {
-					unsigned c;
-					switch (s[j]) {
-					case 'A': c = 0; break;
-					case 'C': c = 1; break;
-					case 'G': c = 2; break;
-					case 'T': c = 3; break;
-					default: ok[t] = 0; return;
-					}
-					v = (v << 2) | c;
+				const unsigned char *s = (const unsigned char *)strs + i * (u64)stride;
+				if (m->W == 1) {
+					u64 v = 0;
+					for (int j = 0; j < len; j++) { const unsigned c = lut.c[s[j]]; bad |= c; v = (v << 2) | (c & 3); }
+					pk[i] = v;
+				} else {
+					u64 hi64 = 0, lo64 = 0;                                  // len > 32: the first len-32 characters fill the high word
+					int j = 0;
+					for (; j < len - 32; j++) { const unsigned c = lut.c[s[j]]; bad |= c; hi64 = (hi64 << 2) | (c & 3); }
+					for (; j < len; j++) { const unsigned c = lut.c[s[j]]; bad |= c; lo64 = (lo64 << 2) | (c & 3); }
+					pk[2 * i] = hi64; pk[2 * i + 1] = lo64;
 				}
-				if (m->W == 1) pk[i] = (u64)v;
-				else { pk[2 * i] = (u64)(v >> 64); pk[2 * i + 1] = (u64)v; }
 			}
+			if (bad & 0x80) ok[t] = 0;
 		};
 		if (T == 1) work(0);
 		else {
@@ -1069,7 +1071,7 @@ static int kmx_query_ascii_impl(kmx_model *m, const char *strs, int len, int str
 		}
 		for (int t = 0; t < T; t++) clean = clean && ok[t];
 	}
-	if (clean) return kmx_query_packed(m, (const uint64_t *)pk.data(), n, out);
+	if (clean) return kmx_query_packed(m, (const uint64_t *)pk, n, out);
 	HIPCHK(hipSetDevice(m->device));
 	unsigned char *ds = nullptr;
 	int *dout = nullptr;
