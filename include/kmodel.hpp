@@ -50,10 +50,10 @@ public:
 		for (size_t lo = 0; lo < n;) {
 			const size_t len = kmer_v[order[lo]].size();
 			size_t hi = lo;
-			std::string flat;
-			while (hi < n && kmer_v[order[hi]].size() == len) flat += kmer_v[order[hi++]];
+			std::vector<const char *> ptrs;
+			while (hi < n && kmer_v[order[hi]].size() == len) ptrs.push_back(kmer_v[order[hi++]].data());
 			std::vector<int32_t> part(hi - lo);
-			check(kmx_query_ascii(h_, flat.data(), (int)len, (int)len, hi - lo, part.data()));
+			check(kmx_query_strings(h_, ptrs.data(), (int)len, hi - lo, part.data()));
 			for (size_t j = lo; j < hi; j++) occ_v[order[j]] = part[j - lo];
 			lo = hi;
 		}

@@ -90,6 +90,9 @@ int kmx_query_packed_dev(kmx_model *m, const uint64_t *d_kmers, uint64_t n, int3
 /* n records of `stride` bytes holding `len` characters each (not NUL-terminated), 2 <= len <= 64.  Strings of
  * the model's k over ACGT take the packed kernel; anything else is hashed byte for byte like the reference does. */
 int kmx_query_ascii(kmx_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out);
+/* the same for n separate strings of `len` characters each (strs[i] need not be NUL-terminated): what a
+ * vector<string> holds, without concatenating it first */
+int kmx_query_strings(kmx_model *m, const char *const *strs, int len, uint64_t n, int32_t *out);
 
 /* KModel::save(dir) -> header, km.bin, rest.bin (dir must exist)           kmodel.hpp:173-206 */
 int kmx_save(kmx_model *m, const char *dir);

@@ -37,7 +37,7 @@ class Stats(C.Structure):
 ABI_SYMBOLS = [
     "kmx_last_error", "kmx_device_count", "kmx_create", "kmx_destroy", "kmx_set_stream", "kmx_build_from_kmc",
     "kmx_begin", "kmx_insert_batch", "kmx_insert_batch_dev", "kmx_finish", "kmx_build_dev", "kmx_build_host",
-    "kmx_query_packed", "kmx_query_packed_dev", "kmx_query_ascii", "kmx_save", "kmx_load", "kmx_get_stats",
+    "kmx_query_packed", "kmx_query_packed_dev", "kmx_query_ascii", "kmx_query_strings", "kmx_save", "kmx_load", "kmx_get_stats",
     "kmx_download", "kmx_debug_hash", "kmx_debug_min_kmer", "kmx_occubin", "kmx_microbench", "kmx_last_build_seconds",
     "kmx_set_profile", "kmx_get_kernel_times", "kmx_kmc_info", "kmx_kmc_read", "kmx_debug_mod",
 ]
@@ -84,6 +84,7 @@ def load_library():
     L.kmx_query_packed.argtypes = [vp, vp, u64, vp]
     L.kmx_query_packed_dev.argtypes = [vp, vp, u64, vp]
     L.kmx_query_ascii.argtypes = [vp, C.c_char_p, i32, i32, u64, vp]
+    L.kmx_query_strings.argtypes = [vp, C.POINTER(C.c_char_p), i32, u64, vp]
     L.kmx_save.argtypes = [vp, C.c_char_p]
     L.kmx_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.kmx_get_stats.argtypes = [vp, C.POINTER(Stats)]

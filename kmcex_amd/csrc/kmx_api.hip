@@ -1030,7 +1030,8 @@ static int kmx_query_packed_impl(kmx_model *m, const uint64_t *kmers, uint64_t n
 // vector<string> front door (kmodel.hpp:90-116).  Strings of the model's k that hold only ACGT are packed on the host
 // (2 bits/base) and take the packed kernel; anything else -- other characters, another length -- is answered by the
 // byte-string kernel, which hashes the bytes as they are, exactly like the reference does.
-static int kmx_query_ascii_impl(kmx_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out)
+template <typename PTR>
+static int query_text(kmx_model *m, PTR ptr_of, const char *flat, int len, int stride, uint64_t n, int32_t *out)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (m->state != ST_READY) return fail(KMX_E_STATE, "query before the model is built or loaded");
@@ -1048,7 +1049,7 @@ static int kmx_query_ascii_impl(kmx_model *m, const char *strs, int len, int str
 			const u64 per = (n + T - 1) / T, lo = (u64)t * per, hi = std::min<u64>(n, lo + per);
 			unsigned bad = 0;
 			for (u64 i = lo; i < hi; i++) {
-				const unsigned char *s = (const unsigned char *)strs + i * (u64)stride;
+				const unsigned char *s = (const unsigned char *)ptr_of(i);
 				if (m->W == 1) {
 					u64 v = 0;
 					for (int j = 0; j < len; j++) { const unsigned c = lut.c[s[j]]; bad |= c; v = (v << 2) | (c & 3); }
@@ -1072,6 +1073,14 @@ static int kmx_query_ascii_impl(kmx_model *m, const char *strs, int len, int str
 		for (int t = 0; t < T; t++) clean = clean && ok[t];
 	}
 	if (clean) return kmx_query_packed(m, (const uint64_t *)pk, n, out);
+	pk_mem.reset();
+	std::vector<char> gathered;                                  // separate strings: lay them out back to back first
+	if (!flat) {
+		gathered.resize(n * (u64)len);
+		for (u64 i = 0; i < n; i++) memcpy(gathered.data() + i * (u64)len, ptr_of(i), (size_t)len);
+		flat = gathered.data();
+		stride = len;
+	}
 	HIPCHK(hipSetDevice(m->device));
 	unsigned char *ds = nullptr;
 	int *dout = nullptr;
@@ -1079,7 +1088,7 @@ static int kmx_query_ascii_impl(kmx_model *m, const char *strs, int len, int str
 	HIPCHK(hipMalloc((void **)&ds, bytes));
 	HIPCHK(hipMalloc((void **)&dout, n * 4));
 	int rc = KMX_OK;
-	if (hipMemcpyAsync(ds, strs, bytes, hipMemcpyHostToDevice, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
+	if (hipMemcpyAsync(ds, flat, bytes, hipMemcpyHostToDevice, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
 	if (!rc) {
 		kmxk::query_ascii(m->md, len, ds, stride, n, dout, m->stream);
 		if (hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "D2H copy failed");
@@ -1088,6 +1097,19 @@ static int kmx_query_ascii_impl(kmx_model *m, const char *strs, int len, int str
 	if (!rc && hipGetLastError() != hipSuccess) rc = fail(KMX_E_NODEVICE, "query kernel failed");
 	hipFree(ds); hipFree(dout);
 	return rc;
+}
+
+static int kmx_query_ascii_impl(kmx_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out)
+{
+	if (n && !strs) return fail(KMX_E_ARG, "null argument");
+	return query_text(m, [&](u64 i) { return strs + i * (u64)stride; }, strs, len, stride, n, out);
+}
+
+// the same for n separate strings of `len` characters each (what a vector<string> holds), without concatenating them
+static int kmx_query_strings_impl(kmx_model *m, const char *const *strs, int len, uint64_t n, int32_t *out)
+{
+	if (n && !strs) return fail(KMX_E_ARG, "null argument");
+	return query_text(m, [&](u64 i) { return strs[i]; }, nullptr, len, len, n, out);
 }
 
 // ------------------------------------------------------------------------------------------ persistence
@@ -1490,6 +1512,7 @@ extern "C" int kmx_kmc_read(const char *db_prefix, uint64_t *kmers, uint32_t *co
 extern "C" int kmx_query_packed_dev(kmx_model *m, const uint64_t *d_kmers, uint64_t n, int32_t *d_out) { return guarded([&] { return kmx_query_packed_dev_impl(m, d_kmers, n, d_out); }); }
 extern "C" int kmx_query_packed(kmx_model *m, const uint64_t *kmers, uint64_t n, int32_t *out) { return guarded([&] { return kmx_query_packed_impl(m, kmers, n, out); }); }
 extern "C" int kmx_query_ascii(kmx_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out) { return guarded([&] { return kmx_query_ascii_impl(m, strs, len, stride, n, out); }); }
+extern "C" int kmx_query_strings(kmx_model *m, const char *const *strs, int len, uint64_t n, int32_t *out) { return guarded([&] { return kmx_query_strings_impl(m, strs, len, n, out); }); }
 extern "C" int kmx_download(kmx_model *m, int which, int index, uint8_t *dst, uint64_t capacity, uint64_t *written) { return guarded([&] { return kmx_download_impl(m, which, index, dst, capacity, written); }); }
 extern "C" int kmx_save(kmx_model *m, const char *dir) { return guarded([&] { return kmx_save_impl(m, dir); }); }
 extern "C" int kmx_load(const char *dir, kmx_model **out) { return guarded([&] { return kmx_load_impl(dir, out); }); }

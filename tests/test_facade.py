@@ -11,12 +11,11 @@ from kmcex_amd import api
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _compile(tmp_path):
+def _compile(tmp_path, source=os.path.join(ROOT, "examples", "kmcex_main.cpp"), name="kmcEx"):
     api.load_library()
-    exe = str(tmp_path / "kmcEx")
-    subprocess.check_call(["g++", "-O3", "-m64", "-std=c++11", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "kmcex_main.cpp"), "-L" + os.path.join(ROOT, "kmcex_amd"), "-lkmx",
-                           "-Wl,-rpath," + os.path.join(ROOT, "kmcex_amd"), "-o", exe])
+    exe = str(tmp_path / name)
+    subprocess.check_call(["g++", "-O3", "-m64", "-std=c++11", "-I" + os.path.join(ROOT, "include"), source,
+                           "-L" + os.path.join(ROOT, "kmcex_amd"), "-lkmx", "-Wl,-rpath," + os.path.join(ROOT, "kmcex_amd"), "-o", exe])
     return exe
 
 
@@ -36,3 +35,18 @@ def test_driver_reproduces_reference_model_files(tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
     for f in ("header", "km.bin", "rest.bin"):
         assert sha_file(os.path.join(str(tmp_path), "db", f)) == sha_file(os.path.join(tiny, f)), f
+
+
+def test_facade_query_program_compiles(tmp_path):
+    _compile(tmp_path, os.path.join(ROOT, "tests", "facade_query.cpp"), "facade_query")
+
+
+@pytest.mark.gpu
+def test_facade_vector_of_strings_gives_reference_answers(tmp_path):
+    """get_model(dir) + kmer_to_occ(vector<string>) through include/kmodel.hpp on the REFERENCE's model files and query
+    strings (tests/golden/tiny): the printed answers are the reference's occ.txt, line for line."""
+    exe = _compile(tmp_path, os.path.join(ROOT, "tests", "facade_query.cpp"), "facade_query")
+    tiny = os.path.join(ROOT, "tests", "golden", "tiny")
+    p = subprocess.run([exe, tiny, os.path.join(tiny, "queries.txt")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout[-300:] + p.stderr
+    assert p.stdout.split() == open(os.path.join(tiny, "occ.txt")).read().split()
