@@ -47,8 +47,9 @@ def random_kmers(n: int, k: int, seed_k: int, device, start: int = 0) -> torch.T
     return splitmix64(i + seed_k) & ((1 << (2 * k)) - 1)
 
 
-def d1_counts(n: int, ci: int, cs: int, seed_c: int, device) -> torch.Tensor:
-    u = splitmix64(torch.arange(n, dtype=torch.int64, device=device) + seed_c)
+def d1_counts_range(start: int, n: int, ci: int, cs: int, seed_c: int, device) -> torch.Tensor:
+    """D1 counts of the ranks start .. start+n-1"""
+    u = splitmix64(torch.arange(start, start + n, dtype=torch.int64, device=device) + seed_c)
     sel = _umod(u, 10)
     v = _lsr(u, 8)
     a = v % 4
@@ -58,10 +59,38 @@ def d1_counts(n: int, ci: int, cs: int, seed_c: int, device) -> torch.Tensor:
     return torch.clamp(out, max=cs).to(torch.int32)
 
 
-def make_stream(n: int, k: int, ci: int, cs: int, device, seed_k: int = 1, seed_c: int = 2):
+def d1_counts(n: int, ci: int, cs: int, seed_c: int, device) -> torch.Tensor:
+    return d1_counts_range(0, n, ci, cs, seed_c, device)
+
+
+def make_stream(n: int, k: int, ci: int, cs: int, device, seed_k: int = 1, seed_c: int = 2, range_values: int = 1 << 30, chunk: int = 1 << 28):
     """Sorted distinct canonical k-mers (int64 holding the uint64 bits; k <= 31 keeps them non-negative)
-    and D1 counts (int32 holding uint32 bits)."""
-    x = random_kmers(n, k, seed_k, device)
-    x = torch.minimum(x, revcomp(x, k))
-    x = torch.unique(x, sorted=True)
-    return x, d1_counts(x.numel(), ci, cs, seed_c, device)
+    and D1 counts (int32 holding uint32 bits).
+
+    torch.unique handles fewer than 2^31 elements, so a larger stream is produced in value ranges: every range
+    regenerates the draws chunk by chunk (cheap), keeps the canonical values that fall into it, and sorts them; the
+    ranges are concatenated in order.  Same stream as the one-shot path (tests/test_synth.py)."""
+    parts = max(1, -(-n // range_values))                    # ~2^30 values per range
+    if parts == 1:
+        x = random_kmers(n, k, seed_k, device)
+        x = torch.minimum(x, revcomp(x, k))
+        x = torch.unique(x, sorted=True)
+        return x, d1_counts(x.numel(), ci, cs, seed_c, device)
+    span = 1 << (2 * k)                                      # canonical values are skewed to the low half, so cut by quantiles
+    probe = random_kmers(min(n, 1 << 22), k, seed_k, device)
+    probe = torch.minimum(probe, revcomp(probe, k)).sort().values
+    cuts = [0] + [int(probe[(len(probe) * p) // parts]) for p in range(1, parts)] + [span]
+    del probe
+    out = []
+    for p in range(parts):
+        keep = []
+        for start in range(0, n, chunk):
+            x = random_kmers(min(chunk, n - start), k, seed_k, device, start=start)
+            x = torch.minimum(x, revcomp(x, k))
+            keep.append(x[(x >= cuts[p]) & (x < cuts[p + 1])])
+        out.append(torch.unique(torch.cat(keep), sorted=True))
+        del keep
+    x = torch.cat(out)
+    del out
+    cnt = torch.cat([d1_counts_range(s0, min(chunk, x.numel() - s0), ci, cs, seed_c, device) for s0 in range(0, x.numel(), chunk)])
+    return x, cnt

@@ -21,3 +21,11 @@ def test_revcomp_involution_and_canonical():
         comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
         rc = ["".join(comp[c] for c in reversed(x)) for x in s[:50]]
         assert synth.to_strings(synth.revcomp(km, k), k)[:50] == rc
+
+
+def test_torch_stream_in_value_ranges_equals_one_shot():
+    """Streams of 2^31 draws or more are generated in value ranges (torch.unique's limit); same stream."""
+    dev = torch.device("cpu")
+    a, ca = synth_torch.make_stream(200000, 31, 1, 1023, dev)
+    b, cb = synth_torch.make_stream(200000, 31, 1, 1023, dev, range_values=30000, chunk=7777)
+    assert torch.equal(a, b) and torch.equal(ca, cb)
