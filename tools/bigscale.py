@@ -15,20 +15,33 @@ threading.Thread(target=beat, daemon=True).start()
 
 n_draw = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_500_000_000
 with_oracle = "--oracle" in sys.argv
+light = "--light" in sys.argv            # build + query + invariants on the device only (no array downloads)
 K, CI, CS, NH, NB = 31, 1, 1023, 7, 5
 dev = torch.device("cuda", 0)
 t = time.time()
 km, cnt = synth_torch.make_stream(n_draw, K, CI, CS, dev)
 torch.cuda.synchronize(); n = km.numel()
+torch.cuda.empty_cache()                      # the generator's temporaries would otherwise stay in torch's pool
+print(f"device memory in use before build: {(torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 2**30:.1f} GiB of {torch.cuda.mem_get_info()[1] / 2**30:.0f}", flush=True)
 print(f"stream: {n} k-mers in {time.time()-t:.1f}s", flush=True)
 m = KModel(CI, CS, NH, NB)
 t = time.time(); m.build_dev(K, km.data_ptr(), cnt.data_ptr(), n); dt = time.time() - t
+if "--rebuild" in sys.argv:               # a second build on the warm model (allocations kept), optionally with per-class kernel times
+    if "--profile" in sys.argv: m.set_profile(True); m.kernel_times(True)
+    t = time.time(); m.build_dev(K, km.data_ptr(), cnt.data_ptr(), n); dt2 = time.time() - t
+    print(f"warm rebuild {dt2:.2f}s = {n/dt2/1e6:.1f} M k-mers/s", flush=True)
+    if "--profile" in sys.argv:
+        for kname, v in m.kernel_times(True).items(): print(f"  {kname:14s} {v['seconds']*1e3:10.1f} ms {v['launches']} launches", flush=True)
+        m.set_profile(False)
 st = m.stats()
 print(f"GPU build {dt:.2f}s = {n/dt/1e6:.1f} M k-mers/s; L = {st.km_byte_size*8} bits per array (2^32 = {2**32}); attempts {st.attempts} successes {st.successes} rest {st.rest_entries} contended {st.contended} fin_iters {st.finisher_iters}", flush=True)
 assert st.successes + st.rest_entries >= st.n_km and st.successes + st.rest_entries - st.n_km < NB
 out = torch.empty(200_000_000, dtype=torch.int32, device=dev)
 t = time.time(); m.kmer_to_occ_dev(km.data_ptr(), 200_000_000, out.data_ptr()); torch.cuda.synchronize(); dq = time.time() - t
 print(f"query 2e8 present k-mers: {2e8/dq/1e6:.1f} M/s, nonzero {(out != 0).float().mean().item():.5f}", flush=True)
+print(f"device memory in use after build: {(torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 2**30:.1f} GiB", flush=True)
+if light:
+    sys.exit(0)
 def sha(a): return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
 gh = {}
 for a in range(NB):
