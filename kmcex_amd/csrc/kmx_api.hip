@@ -227,12 +227,21 @@ static void prof_collect(kmx_model *m)
 
 static const u64 kChunk = u64(1) << 23;                       // k-mers classified per pass of the front end
 
+static double g_malloc_seconds = 0;                           // time inside hipMalloc (KMX_CTRL_DEBUG=1 prints it per build)
+static hipError_t timed_malloc(void **p, u64 bytes)
+{
+	const auto t0 = std::chrono::steady_clock::now();
+	const hipError_t e = hipMalloc(p, bytes);
+	g_malloc_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	return e;
+}
+
 template <typename T> static int dalloc(T **p, u64 n_elems, bool zero, hipStream_t st)
 {
 	*p = nullptr;
 	u64 bytes = n_elems * sizeof(T);
 	if (!bytes) bytes = 16;
-	HIPCHK(hipMalloc((void **)p, bytes));
+	HIPCHK(timed_malloc((void **)p, bytes));
 	if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes, st));
 	return KMX_OK;
 }
@@ -244,7 +253,7 @@ template <typename T> static int ensure(T **p, u64 *cap_bytes, u64 need_bytes, b
 	if (!need_bytes) need_bytes = 16;
 	if (!*p || *cap_bytes < need_bytes) {
 		if (*p) { HIPCHK(hipStreamSynchronize(st)); hipFree(*p); *p = nullptr; }
-		HIPCHK(hipMalloc((void **)p, need_bytes));
+		HIPCHK(timed_malloc((void **)p, need_bytes));
 		*cap_bytes = need_bytes;
 	}
 	if (zero) HIPCHK(hipMemsetAsync(*p, 0, need_bytes, st));
@@ -402,7 +411,10 @@ static int alloc_arrays(kmx_model *m)
 		TRY(ensure(&m->d_bf_back[i], &m->cap_bf_back[i], ((m->byte_bf_back[i] + 3) / 4 + 1) * 4, true, m->stream));
 	}
 	TRY(ensure(&m->d_km_back, &m->cap_km_back, ((m->byte_km_back + 3) / 4 + 1) * 4, true, m->stream));
-	for (int a = 0; a < m->nb; a++) TRY(ensure(&m->d_cells[a], &m->cap_cells[a], (m->ncells + 1) * 8, true, m->stream));
+	// (hipMalloc of fresh device memory costs ~90 ms per GB on this stack, also from several threads at once:
+	// a cold build of 2.5e9 k-mers spends 2.3 s here, a rebuild on the same handle nothing)
+	const u64 need = (m->ncells + 1) * 8;
+	for (int a = 0; a < m->nb; a++) TRY(ensure(&m->d_cells[a], &m->cap_cells[a], need, true, m->stream));
 	return KMX_OK;
 }
 
@@ -809,9 +821,19 @@ static int build_common(kmx_model *m, int k, const u64 *d_kmers, const u32 *d_co
 	HIPCHK(hipMemcpyAsync(&bad, m->d_stats + ST_BAD_COUNT, 8, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipStreamSynchronize(m->stream));
 	if (bad) return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)bad, m->ci, m->cs);
+	const auto t0 = std::chrono::steady_clock::now();
 	TRY(kmx_begin(m, k, (const uint64_t *)nbf, n_total));
+	if (m->dbg_ctrl) hipStreamSynchronize(m->stream);
+	const auto t1 = std::chrono::steady_clock::now();
 	TRY(kmx_insert_batch_dev(m, (const uint64_t *)d_kmers, d_counts, n));
+	if (m->dbg_ctrl) hipStreamSynchronize(m->stream);
+	const auto t2 = std::chrono::steady_clock::now();
 	TRY(kmx_finish(m));
+	if (m->dbg_ctrl) {
+		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count() * 1e3; };
+		fprintf(stderr, "[kmx] build: begin (allocate + clear) %.1f ms of which hipMalloc %.1f ms, insert %.1f ms, finish (last block + rest table) %.1f ms\n", ms(t0, t1), g_malloc_seconds * 1e3, ms(t1, t2), ms(t2, std::chrono::steady_clock::now()));
+		g_malloc_seconds = 0;
+	}
 	HIPCHK(hipEventRecord(m->ev1, m->stream));
 	HIPCHK(hipEventSynchronize(m->ev1));
 	float ms = 0;
