@@ -66,17 +66,6 @@ template <int W> __device__ __forceinline__ bool bloom_check_pm(const Premixed<W
 	return ok;
 }
 
-// kmodel.hpp:548-550: the (k-2)-mer of an inserted k-mer goes into km_back.  During a build the filter is kept one byte
-// per bit: setting a bit is then a plain byte store (no read-modify-write at the memory side, nothing to wait for) and
-// concurrent stores of the same 1 are harmless.  (A build without km_back inserts would run 10 % faster; with atomics
-// and test-before-set they cost 2-4 % more than this; a load before the store costs 2.5 % again.)
-template <int W> __device__ __forceinline__ void km_back_insert(const ModelDev &md, const Premixed<W> &pb)
-{
-	if (!md.km_back_mod.d) return;
-	if (!md.km_back_bytes) { bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2); return; }
-	for (int j = 0; j < md.nh - 2; j++) md.km_back_bytes[mod_u64(murmur_seeded<W>(pb, md.gback, c_seeds[j]), md.km_back_mod)] = 1;
-}
-
 // Wave-aggregated counters: one atomic per wave instead of one per lane (same-address atomics serialise).
 // Call from converged code; lanes that already returned simply do not take part in the ballot.
 __device__ __forceinline__ void wave_count_add(u64 *ctr, bool pred)
@@ -151,7 +140,7 @@ __device__ __forceinline__ void commit_touches(const ModelDev &md, const Touches
 				atomicOr(cells + (t.pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
 		}
 	Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-	km_back_insert<W>(md, pb);
+	bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
 }
 
 // ------------------------------------------------------------------------------------------ pass 1
@@ -602,7 +591,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0
 						atomicOr(cells + (pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
 					}
 				Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-				km_back_insert<W>(md, pb);
+				bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
 				bd.status[row + x] = SLOT_INSERTED;
 			}
 			defer = !mine;
@@ -850,7 +839,7 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 				u64 v[W];
 				rec_load<W>(bd.Urec[lv], row + rec[r], x_, bin_, v);
 				Premixed<W> pb = premix_string<W>(drop_first_base<W>(left_align<W>(v, md.k)), md.gback);
-				km_back_insert<W>(md, pb);
+				bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
 			}
 		}
 	if (!defer) drain_vmem();                                        // the next range gathers what this one committed
@@ -1050,7 +1039,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 						atomicOr(cells + (pos >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
 					}
 				Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-				km_back_insert<W>(md, pb);
+				bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
 			}
 		}
 		return;
@@ -1481,19 +1470,6 @@ template <int W> __global__ __launch_bounds__(256) void k_query_ascii(ModelDev m
 
 // ------------------------------------------------------------------------------------------ layout conversion
 // on-disk value/tag bytes <-> cells (kmodel.hpp:199-201, :227-229).  One thread per cell (2 bytes of each).
-// km_back bytes -> bits in the on-disk order (bit p at byte p>>3, mask 0x80>>(p&7)), one u32 of the filter per thread
-__global__ __launch_bounds__(256) void k_pack_bits(const unsigned char *bytes, u64 nbits, u32 *out)
-{
-	const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
-	if (w * 32 >= nbits) return;
-	u32 v = 0;
-	for (int q = 0; q < 32; q++) {
-		const u64 p = w * 32 + q;
-		if (p < nbits && bytes[p]) v |= 1u << bit_in_word32(p);
-	}
-	out[w] = v;
-}
-
 __global__ __launch_bounds__(256) void k_cells_from_disk(const unsigned char *val, const unsigned char *tag, u64 nbytes, u64 *cells, u64 ncells)
 {
 	u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -1742,11 +1718,6 @@ void query_ascii(const ModelDev &md, int L, const unsigned char *strs, int strid
 	if (!n) return;
 	const StrGeom gf = make_geom(L), gb = make_geom(L >= 2 ? L - 2 : 0);
 	DISPATCH_W(words(md), hipLaunchKernelGGL(k_query_ascii<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, md, gf, gb, L, strs, stride, n, out));
-}
-
-void pack_bits(const unsigned char *bytes, u64 nbits, u32 *out, hipStream_t st)
-{
-	if (nbits) hipLaunchKernelGGL(k_pack_bits, dim3((unsigned)(((nbits + 31) / 32 + 255) / 256)), dim3(256), 0, st, bytes, nbits, out);
 }
 
 void cells_from_disk(const unsigned char *val, const unsigned char *tag, u64 nbytes, u64 *cells, u64 ncells, hipStream_t st)

@@ -37,7 +37,6 @@ void rest_append(const ModelDev &, const BlockDev &, int, u64 *, int *, unsigned
 void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *);
 void query_ascii(const ModelDev &, int, const unsigned char *, int, u64, int *, hipStream_t);
 void cells_from_disk(const unsigned char *, const unsigned char *, u64, u64 *, u64, hipStream_t);
-void pack_bits(const unsigned char *, u64, u32 *, hipStream_t);
 void cells_to_disk(const u64 *, u64, u64, int, unsigned char *, hipStream_t);
 void debug_hash(int, const u64 *, u64, const u32 *, int, int, u64 *, hipStream_t);
 void debug_min_kmer(int, const u64 *, u64, u64 *, hipStream_t);
@@ -154,8 +153,6 @@ struct kmx_model {
 	u32 *d_bf[3] = {nullptr, nullptr, nullptr}, *d_bf_back[3] = {nullptr, nullptr, nullptr}, *d_km_back = nullptr;
 	u64 *d_cells[KMX_MAX_NB] = {nullptr};
 	u64 cap_bf[3] = {0, 0, 0}, cap_bf_back[3] = {0, 0, 0}, cap_km_back = 0, cap_cells[KMX_MAX_NB] = {0};   // bytes allocated
-	unsigned char *d_km_back_bytes = nullptr;                  // build-time form of km_back: one byte per bit (kmx_begin .. kmx_finish)
-	u64 cap_km_back_bytes = 0;
 	RestTable rest;
 	ModelDev md;
 	// ---- build-time state
@@ -295,7 +292,6 @@ static void free_arrays(kmx_model *m)
 		m->d_bf[i] = m->d_bf_back[i] = nullptr;
 	}
 	hipFree(m->d_km_back); m->d_km_back = nullptr;
-	hipFree(m->d_km_back_bytes); m->d_km_back_bytes = nullptr; m->cap_km_back_bytes = 0;
 	for (int a = 0; a < KMX_MAX_NB; a++) { hipFree(m->d_cells[a]); m->d_cells[a] = nullptr; m->cap_cells[a] = 0; }
 	for (int i = 0; i < 3; i++) m->cap_bf[i] = m->cap_bf_back[i] = 0;
 	m->cap_km_back = 0;
@@ -399,7 +395,6 @@ static void fill_model_dev(kmx_model *m)
 		md.bf_back[i] = m->d_bf_back[i]; md.bf_back_mod[i] = make_mod(i < m->bf_num ? m->byte_bf_back[i] * 8 : 0);
 	}
 	md.km_back = m->d_km_back; md.km_back_mod = make_mod(m->byte_km_back * 8);
-	md.km_back_bytes = m->state == ST_BUILDING ? m->d_km_back_bytes : nullptr;
 	for (int a = 0; a < m->nb; a++) md.cells[a] = m->d_cells[a];
 	md.km_mod = make_mod(m->km_byte_size * 8);
 	md.bin_of_occ = m->d_bin_of_occ; md.mean_of_bin = m->d_mean_of_bin;
@@ -437,7 +432,6 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 	for (int i = 0; i < 3; i++) m->n_bf[i] = i < m->bf_num ? n_bf[i] : 0;
 	compute_sizes(m);
 	TRY(alloc_arrays(m));
-	TRY(ensure(&m->d_km_back_bytes, &m->cap_km_back_bytes, m->byte_km_back * 8 + 64, true, m->stream));   // build-time form of km_back
 	m->rest = RestTable();
 	fill_model_dev(m);
 	const int nb = m->nb;
@@ -507,7 +501,6 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 	m->t_insert_kernels = 0; m->t_total = 0;
 	memset(m->h_stats, 0, sizeof m->h_stats);
 	m->state = ST_BUILDING;
-	m->md.km_back_bytes = m->d_km_back_bytes;
 	return KMX_OK;
 }
 
@@ -810,14 +803,9 @@ static int kmx_finish_impl(kmx_model *m)
 		for (int c = 0; c < KC_QUERY; c++) after += m->kc_seconds[c];
 		m->t_insert_kernels = after - before;                   // HIP-event time inside the insert kernels of this build
 	}
-	kmxk::pack_bits(m->d_km_back_bytes, m->byte_km_back * 8, m->d_km_back, m->stream);   // km_back: bytes of the build -> bits
 	TRY(build_rest(m, n_rest));
-	m->state = ST_READY;
 	fill_model_dev(m);
-	if (m->cap_km_back_bytes > (2ull << 30)) {                  // a large byte form is handed back; a small one is kept for the next build
-		HIPCHK(hipStreamSynchronize(m->stream));
-		hipFree(m->d_km_back_bytes); m->d_km_back_bytes = nullptr; m->cap_km_back_bytes = 0;
-	}
+	m->state = ST_READY;
 	return KMX_OK;
 }
 

@@ -9,7 +9,6 @@ struct ModelDev {
 	u32 *bf[3];      ModU64 bf_mod[3];         // Bloom filters, on-disk byte layout (kmodel.hpp:250,253)
 	u32 *bf_back[3]; ModU64 bf_back_mod[3];    // their (k-2)-mer back filters       (kmodel.hpp:251,255)
 	u32 *km_back;    ModU64 km_back_mod;       // back filter of the coupled arrays  (kmodel.hpp:267-269)
-	unsigned char *km_back_bytes;              // during a build: one BYTE per km_back bit (plain stores instead of atomics), packed into km_back by kmx_finish; null otherwise
 	u64 *cells[KMX_MAX_NB];                    // coupled arrays, cell layout (device_common.h)
 	ModU64 km_mod;                             // bit_array_length                   (kmodel.hpp:33,445)
 	const u32 *bin_of_occ;                     // occ -> bin  (occu_bin.hpp:67-77)
