@@ -47,8 +47,9 @@ def _prefix(kmers: np.ndarray, k: int, p: int) -> np.ndarray:
     sh = 2 * (k - p)
     if W == 1:
         return (a[:, 0] >> np.uint64(sh)).astype(np.int64)
-    assert sh >= 64
-    return (a[:, 0] >> np.uint64(sh - 64)).astype(np.int64)
+    if sh >= 64:
+        return (a[:, 0] >> np.uint64(sh - 64)).astype(np.int64)
+    return ((a[:, 0] << np.uint64(64 - sh)) | (a[:, 1] >> np.uint64(sh))).astype(np.int64)   # prefix straddles the two words (k = 33..35)
 
 
 def write_kmc1(path_prefix: str, kmers: np.ndarray, counts: np.ndarray, k: int, ci: int, cs: int,

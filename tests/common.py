@@ -15,6 +15,9 @@ CASES = [
     ("k31_multiblock_ci2", 31, 2, 1023, 7, 5, 4000000),      # RS-scale plumbing stand-in (BASELINE configs[0])
     ("k55_multiblock", 55, 1, 4095, 9, 6, 2000000),          # 1 full block (6*2^18) + partial, two-word k-mers
     ("k32_nb4", 32, 1, 1023, 7, 4, 50000),                   # k == 32 boundary, pre_len 4
+    ("k33_first_two_word", 33, 1, 1023, 7, 5, 30000),        # first k that needs two words (k > 32 canonicalisation quirk Q4)
+    ("k64_cs65535_nh8_nb3", 64, 2, 65535, 8, 3, 30000),      # largest k, 2-byte KMC counters, three Bloom classes
+    ("k16_nh5_nb2", 16, 1, 255, 5, 2, 20000),                # short k-mers, few hashes, two arrays
 ]
 # KMC2-layout databases (what KMC 3 emits): bin-major listing, not globally sorted -> the insert order differs
 # name, k, ci, cs, nh, nb, n_draws, n_bins
@@ -28,7 +31,7 @@ GENOME_CASES = [
     ("genome_k27_ci2", 27, 2, 1023, 7, 4, 250000),
 ]
 CASE = {c[0]: c for c in CASES}
-SMALL = ["tiny_k31", "k31_ci2_200k", "k55_nh9_nb6", "k21_nh6_nb3", "k32_nb4"]
+SMALL = ["tiny_k31", "k31_ci2_200k", "k55_nh9_nb6", "k21_nh6_nb3", "k32_nb4", "k33_first_two_word", "k64_cs65535_nh8_nb3", "k16_nh5_nb2"]
 LARGE = ["k31_multiblock_ci1", "k31_multiblock_ci2", "k55_multiblock"]
 MAX_PRESENT = 400000
 ABSENT_SEED = 0xABCDEF0123                     # far outside the index range of any stream, so these draws are absent
