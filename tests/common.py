@@ -18,6 +18,9 @@ CASES = [
     ("k33_first_two_word", 33, 1, 1023, 7, 5, 30000),        # first k that needs two words (k > 32 canonicalisation quirk Q4)
     ("k64_cs65535_nh8_nb3", 64, 2, 65535, 8, 3, 30000),      # largest k, 2-byte KMC counters, three Bloom classes
     ("k16_nh5_nb2", 16, 1, 255, 5, 2, 20000),                # short k-mers, few hashes, two arrays
+    ("k27_ci3_nb8", 27, 3, 1023, 7, 8, 40000),               # ci = 3: three Bloom classes start at count 3; eight arrays
+    ("k31_nh3_nb1", 31, 1, 255, 3, 1, 20000),                # smallest nh, a single array
+    ("k31_nh12_cs8191", 31, 1, 8191, 12, 2, 20000),          # twelve hashes (4096 bins), the wide-template kernels at k <= 32
 ]
 # KMC2-layout databases (what KMC 3 emits): bin-major listing, not globally sorted -> the insert order differs
 # name, k, ci, cs, nh, nb, n_draws, n_bins
@@ -31,7 +34,7 @@ GENOME_CASES = [
     ("genome_k27_ci2", 27, 2, 1023, 7, 4, 250000),
 ]
 CASE = {c[0]: c for c in CASES}
-SMALL = ["tiny_k31", "k31_ci2_200k", "k55_nh9_nb6", "k21_nh6_nb3", "k32_nb4", "k33_first_two_word", "k64_cs65535_nh8_nb3", "k16_nh5_nb2"]
+SMALL = ["tiny_k31", "k31_ci2_200k", "k55_nh9_nb6", "k21_nh6_nb3", "k32_nb4", "k33_first_two_word", "k64_cs65535_nh8_nb3", "k16_nh5_nb2", "k27_ci3_nb8", "k31_nh3_nb1", "k31_nh12_cs8191"]
 LARGE = ["k31_multiblock_ci1", "k31_multiblock_ci2", "k55_multiblock"]
 MAX_PRESENT = 400000
 ABSENT_SEED = 0xABCDEF0123                     # far outside the index range of any stream, so these draws are absent
