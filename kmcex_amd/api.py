@@ -54,8 +54,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
-    if not os.path.exists(path) or _build.stale():
+    path = os.environ.get("KMX_LIBRARY")        # a specially built variant (tools/stress_small_tables.py); never set in normal use
+    if path:
+        if not os.path.exists(path):
+            raise KmxError(-2, f"KMX_LIBRARY={path} does not exist")
+    else:
+        path = _build.LIB
+    if path == _build.LIB and (not os.path.exists(path) or _build.stale()):
         try:
             _build.build_lib()
         except Exception as e:  # noqa: BLE001

@@ -628,15 +628,21 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0
 // Sharing a slot with a foreign position only delays a record.  `defer`: the winners do not touch the array at all;
 // they set REC_WON in their record and k_reorder -- 256 workgroups per list instead of one -- applies tag/value bits
 // and the km_back insert.  One CU issues a random access every ~2.8 ns, which is what bounded this kernel before.
-#define KMX_FIN_T 16384
+// KMX_FIN_LOG2 can be lowered at compile time (tools/stress_small_tables.py builds such a library) so that slot sharing,
+// the table-2 route and MARK words of foreign positions are exercised constantly; the product uses 2^14 slots per table.
+#ifndef KMX_FIN_LOG2
+#define KMX_FIN_LOG2 14
+#endif
+#define KMX_FIN_T (1 << KMX_FIN_LOG2)
+#define KMX_FIN_MAX_POS (1ULL << (KMX_FIN_LOG2 + 22))   // slot index + 22 identity bits name a position exactly below this
 #define FIN_MARK 0x80000000u
 // workgroup barrier for LDS-only hand-offs: __syncthreads() would also wait for every outstanding global store and
 // atomic of the wave (status bytes, failure counters), 2-4 us each time
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ u32 fin_ident(u64 q) { return (u32)(q >> 14) & 0x3FFFFFu; }                  // tag13 | hi9 << 13
-__device__ __forceinline__ u32 fin_key(u32 x, u64 q) { return ((0x3FFFFu - x) << 13) | ((u32)(q >> 14) & 0x1FFFu); }
+__device__ __forceinline__ u32 fin_ident(u64 q) { return (u32)(q >> KMX_FIN_LOG2) & 0x3FFFFFu; }        // tag13 | hi9 << 13
+__device__ __forceinline__ u32 fin_key(u32 x, u64 q) { return ((0x3FFFFu - x) << 13) | ((u32)(q >> KMX_FIN_LOG2) & 0x1FFFu); }
 __device__ __forceinline__ u32 fin_slot1(u64 q) { return (u32)q & (KMX_FIN_T - 1); }
-__device__ __forceinline__ u32 fin_slot2(u64 q) { return ((u32)q ^ ((fin_ident(q) * 0x9E3779B1u) >> 18)) & (KMX_FIN_T - 1); }
+__device__ __forceinline__ u32 fin_slot2(u64 q) { return ((u32)q ^ ((fin_ident(q) * 0x9E3779B1u) >> (32 - KMX_FIN_LOG2))) & (KMX_FIN_T - 1); }
 
 template <int W, int NHM, int RPT>
 __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd, int pp, int i, int a, int lv, int n, const u32 *s_list, bool snapshot, bool defer,
@@ -646,7 +652,7 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 	const u64 row = (u64)i * KMX_BUCKET;
 	u64 *cells = md.cells[a];
 	const int sbase = a * md.nh;
-	u32 x[RPT], bin[RPT], rec[RPT], um[RPT], cidx[RPT][NHM];
+	u32 x[RPT], bin[RPT], rec[RPT], um[RPT], ghost[RPT], cidx[RPT][NHM];   // ghost: won, but these positions are not published yet
 	u64 bits[RPT];                                                   // bit_in_cell of position j in nibble j
 	bool live[RPT], won[RPT];
 #pragma unroll
@@ -656,7 +662,7 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 		won[r] = false;
 		x[r] = bin[r] = 0;
 		bits[r] = 0;
-		rec[r] = um[r] = 0;
+		rec[r] = um[r] = ghost[r] = 0;
 		if (live[r]) {
 			rec[r] = s_list ? s_list[slot] : (u32)slot;
 			u64 v[W];
@@ -717,14 +723,14 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 		for (int r = 0; r < RPT; r++) {
 #pragma unroll
 			for (int j = 0; j < NHM; j++) asm volatile("" : "+v"(cidx[r][j]));
-			asm volatile("" : "+v"(bits[r]), "+v"(x[r]), "+v"(bin[r]), "+v"(um[r]));
+			asm volatile("" : "+v"(bits[r]), "+v"(x[r]), "+v"(bin[r]), "+v"(um[r]), "+v"(ghost[r]));
 		}
-		u32 resv[RPT], second[RPT];                                  // positions reserved in this iteration / moved to table 2
+		u32 resv[RPT], second[RPT], hold[RPT];                       // positions reserved in this iteration / moved to table 2 / held
 		bool mine[RPT];
 		// 1
 #pragma unroll
 		for (int r = 0; r < RPT; r++) {
-			resv[r] = live[r] ? um[r] : 0u;
+			resv[r] = live[r] ? um[r] : ghost[r];
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
 				if (j < md.nh && ((resv[r] >> j) & 1u)) atomicMax(s_t1 + fin_slot1(FIN_Q(r, j)), fin_key(x[r], FIN_Q(r, j)));
@@ -748,49 +754,59 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		lds_barrier();
-		// 3 (reads only)
+		// 3 (reads only).  In table 2 the priority alone decides: two positions of ONE record may share a slot there,
+		// and whoever has the highest priority on a slot has it on every position that maps to it.
 #pragma unroll
 		for (int r = 0; r < RPT; r++) {
-			mine[r] = live[r];
+			hold[r] = 0;
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
 				if (j < md.nh && ((resv[r] >> j) & 1u)) {
 					const u64 q = FIN_Q(r, j);
-					const u32 held = ((second[r] >> j) & 1u) ? s_t2[fin_slot2(q)] : s_t1[fin_slot1(q)];
-					mine[r] &= held == fin_key(x[r], q);
+					const u32 key = fin_key(x[r], q);
+					const bool held = ((second[r] >> j) & 1u) ? (s_t2[fin_slot2(q)] >> 13) == (key >> 13) : s_t1[fin_slot1(q)] == key;
+					hold[r] |= held ? 1u << j : 0u;
 				}
+			mine[r] = live[r] && hold[r] == resv[r];
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		lds_barrier();
-		// 3 (the winners publish what they commit; duplicates of a position inside one k-mer OR their values, as the
-		// reference's set loop does, kmodel.hpp:611-618)
+		// 3 (the winners publish what they commit).  Only the holder of a slot writes to it in this phase, so a MARK it
+		// finds there is its own: the same position again (a k-mer may hit a position twice; the values OR, as in the
+		// reference's set loop, kmodel.hpp:611-618) or ANOTHER of its positions in the same slot -- that one is published
+		// in a later iteration, the record staying on as a "ghost" that keeps reserving it with its priority, so that
+		// nobody interested in it can hold it before the MARK has been seen.
 #pragma unroll
 		for (int r = 0; r < RPT; r++) {
-			if (!mine[r]) continue;
+			if (!mine[r] && !ghost[r]) continue;
+			const u32 pub = mine[r] ? resv[r] : (ghost[r] & hold[r]);
+			u32 later = mine[r] ? 0u : (ghost[r] & ~hold[r]);
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
-				if (j < md.nh && ((resv[r] >> j) & 1u)) {
+				if (j < md.nh && ((pub >> j) & 1u)) {
 					const u64 q = FIN_Q(r, j);
-					*(((second[r] >> j) & 1u) ? s_t2 + fin_slot2(q) : s_t1 + fin_slot1(q)) = FIN_MARK | fin_ident(q);
+					u32 *slot = ((second[r] >> j) & 1u) ? s_t2 + fin_slot2(q) : s_t1 + fin_slot1(q);
+					const u32 cur = *slot, mark = FIN_MARK | fin_ident(q) | (((bin[r] >> j) & 1u) << 30);
+					if (!(cur & FIN_MARK)) *slot = mark;
+					else if ((cur & 0x3FFFFFu) == fin_ident(q)) *slot = cur | mark;
+					else later |= 1u << j;
 				}
+			if (mine[r]) {
+				if (!defer) {
 #pragma unroll
-			for (int j = 0; j < NHM; j++)
-				if (j < md.nh && ((resv[r] >> j) & 1u) && ((bin[r] >> j) & 1u)) {
-					const u64 q = FIN_Q(r, j);
-					atomicOr(((second[r] >> j) & 1u) ? s_t2 + fin_slot2(q) : s_t1 + fin_slot1(q), 0x40000000u);
+					for (int j = 0; j < NHM; j++)
+						if (j < md.nh && ((resv[r] >> j) & 1u)) {
+							const u32 b = FIN_BIT(r, j);
+							atomicOr(cells + cidx[r][j], CELL_TAG(b) | (((bin[r] >> j) & 1u) ? CELL_VAL(b) : 0ULL));
+						}
 				}
-			if (!defer) {
-#pragma unroll
-				for (int j = 0; j < NHM; j++)
-					if (j < md.nh && ((resv[r] >> j) & 1u)) {
-						const u32 b = FIN_BIT(r, j);
-						atomicOr(cells + cidx[r][j], CELL_TAG(b) | (((bin[r] >> j) & 1u) ? CELL_VAL(b) : 0ULL));
-					}
+				bd.status[row + x[r]] = SLOT_INSERTED;
+				live[r] = false;
+				won[r] = true;
+				succ++;
 			}
-			bd.status[row + x[r]] = SLOT_INSERTED;
-			live[r] = false;
-			won[r] = true;
-			succ++;
+			ghost[r] = later;
+			if (later) s_pending[par] = 1;
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		lds_barrier();
@@ -972,7 +988,7 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 	if (n == 0) return;
 	const int a = (i + t) % md.nb;
 	constexpr int RPT = KMX_FIN_RPT(NHM);
-	const bool lds_path = n <= KMX_FIN_RANGES * RPT * 1024 && !force_global && md.km_mod.d < (1ULL << 36);
+	const bool lds_path = n <= KMX_FIN_RANGES * RPT * 1024 && !force_global && md.km_mod.d < KMX_FIN_MAX_POS;
 	if (blockIdx.y > 0) {
 		if (s != 0 || !lds_path) return;                             // finish_global drops the claims itself
 		const u64 row = (u64)i * KMX_BUCKET;
