@@ -60,6 +60,28 @@ def test_kmc_reader_lists_what_the_writer_wrote(tmp_path):
         api.kmc_list(str(tmp_path / "missing"))
 
 
+def test_kmc_reader_record_shapes_and_slice_boundaries(tmp_path):
+    """Every record shape the decoder has a fast path for (suffix of 1..8 bytes, counters of 1..3 bytes, k from 9 to 35
+    incl. the two-word k = 33..35 whose LUT prefix straddles the words) and sizes around the per-thread slice boundaries
+    (1, 2, a few, 65536 +- 1, several slices): the listing equals what the writer wrote, also when the last records of a
+    slice take the byte-wise tail path."""
+    rng = np.random.default_rng(5)
+    for k in (9, 12, 13, 16, 21, 27, 31, 32, 33, 35):
+        for cs in (255, 1023, 70000):
+            for n in (1, 2, 7, 65535, 65537, 200001):
+                if 4 ** k < 4 * n:
+                    continue
+                if rng.random() < 0.5 and n > 1000:           # half of the big ones: enough to cover every shape
+                    continue
+                km, cnt = synth.make_stream(n, k, 1, cs, seed_k=int(rng.integers(1, 1 << 20)))
+                db = str(tmp_path / f"db_{k}_{cs}_{n}")
+                kmcdb.write_kmc1(db, km, cnt, k, 1, cs)
+                k2, total, okm, ocnt = api.kmc_list(db)
+                assert (k2, total) == (k, len(cnt)), (k, cs, n)
+                assert np.array_equal(okm.reshape(km.shape), km) and np.array_equal(ocnt, cnt), (k, cs, n)
+                os.remove(db + ".kmc_pre"); os.remove(db + ".kmc_suf")
+
+
 def test_kmc2_layout_lists_bin_major(tmp_path):
     """KMC2 prefix files (per-bin LUTs, kmc_file.cpp:188-235, :449): the listing walks bin after bin."""
     for k, ci, cs, n, n_bins in ((31, 1, 1023, 20000, 5), (55, 1, 4095, 4000, 3), (21, 2, 255, 2500, 16)):
