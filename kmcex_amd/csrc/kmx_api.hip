@@ -8,6 +8,7 @@
 #include "kmx_types.h"
 
 #include <algorithm>
+#include <atomic>
 #include <exception>
 #include <new>
 #include <cstdarg>
@@ -227,12 +228,12 @@ static void prof_collect(kmx_model *m)
 
 static const u64 kChunk = u64(1) << 23;                       // k-mers classified per pass of the front end
 
-static double g_malloc_seconds = 0;                           // time inside hipMalloc (KMX_CTRL_DEBUG=1 prints it per build)
+static std::atomic<unsigned long long> g_malloc_ns{0};       // time inside hipMalloc (KMX_CTRL_DEBUG=1 prints it per build)
 static hipError_t timed_malloc(void **p, u64 bytes)
 {
 	const auto t0 = std::chrono::steady_clock::now();
 	const hipError_t e = hipMalloc(p, bytes);
-	g_malloc_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	g_malloc_ns += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
 	return e;
 }
 
@@ -831,8 +832,7 @@ static int build_common(kmx_model *m, int k, const u64 *d_kmers, const u32 *d_co
 	TRY(kmx_finish(m));
 	if (m->dbg_ctrl) {
 		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count() * 1e3; };
-		fprintf(stderr, "[kmx] build: begin (allocate + clear) %.1f ms of which hipMalloc %.1f ms, insert %.1f ms, finish (last block + rest table) %.1f ms\n", ms(t0, t1), g_malloc_seconds * 1e3, ms(t1, t2), ms(t2, std::chrono::steady_clock::now()));
-		g_malloc_seconds = 0;
+		fprintf(stderr, "[kmx] build: begin (allocate + clear) %.1f ms of which hipMalloc %.1f ms, insert %.1f ms, finish (last block + rest table) %.1f ms\n", ms(t0, t1), (double)g_malloc_ns.exchange(0) * 1e-6, ms(t1, t2), ms(t2, std::chrono::steady_clock::now()));
 	}
 	HIPCHK(hipEventRecord(m->ev1, m->stream));
 	HIPCHK(hipEventSynchronize(m->ev1));
