@@ -1098,10 +1098,14 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 
 // survivors of the block go to the rest table (kmodel.hpp:567-571); slot 0 is remembered for the
 // stale-slot duplicate of the final block (quirk Q1)
-template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev bd, int pp, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts)
+template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev bd, int pp, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, u64 *feedback)
 {
 	__shared__ int s_cnt;
 	__shared__ unsigned long long s_base;
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // the block's contention figures go straight to the host's pinned words
+		feedback[0] = bd.stats[ST_MAX_U0]; feedback[1] = bd.stats[ST_MAX_UFIN];
+		bd.stats[ST_MAX_U0] = 0; bd.stats[ST_MAX_UFIN] = 0;
+	}
 	if (threadIdx.x == 0) s_cnt = 0;
 	__syncthreads();
 	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
@@ -1716,9 +1720,9 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	KPROF_END(prof, st);
 }
 
-void rest_append(const ModelDev &md, const BlockDev &bd, int pp, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, hipStream_t st)
+void rest_append(const ModelDev &md, const BlockDev &bd, int pp, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, u64 *feedback, hipStream_t st)
 {
-	DISPATCH_W(words(md), hipLaunchKernelGGL(k_rest_append<W>, dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, bd, pp, rest_kmers, rest_counts, rest_n, stale_kmers, stale_counts));
+	DISPATCH_W(words(md), hipLaunchKernelGGL(k_rest_append<W>, dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, bd, pp, rest_kmers, rest_counts, rest_n, stale_kmers, stale_counts, feedback));
 }
 
 void query(const ModelDev &md, const u64 *kmers, u64 n, int *out, hipStream_t st, KernelProf *prof)

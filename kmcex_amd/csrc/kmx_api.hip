@@ -34,7 +34,7 @@ void classify_count(const ModelDev &, const u64 *, const u32 *, u64, u64, int *,
 void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int *, u64 *, u32 *, u64, hipStream_t);
 void block_init(const BlockDev &, int, int, int, hipStream_t);
 void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *);
-void rest_append(const ModelDev &, const BlockDev &, int, u64 *, int *, unsigned long long *, u64 *, int *, hipStream_t);
+void rest_append(const ModelDev &, const BlockDev &, int, u64 *, int *, unsigned long long *, u64 *, int *, u64 *, hipStream_t);
 void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *);
 void query_ascii(const ModelDev &, int, const unsigned char *, int, u64, int *, hipStream_t);
 void cells_from_disk(const unsigned char *, const unsigned char *, u64, u64 *, u64, hipStream_t);
@@ -179,6 +179,7 @@ struct kmx_model {
 	hipEvent_t ev_in = nullptr, ev_side = nullptr;
 	int *h_total = nullptr;                                    // pinned
 	u64 *h_feedback = nullptr;                                 // pinned: ST_MAX_U0 as of some earlier block (heuristic input)
+	u64 *d_feedback = nullptr;                                 // the same words as the device sees them (k_rest_append writes them)
 	u64 epoch = 1, blocks = 0, rounds = 0;
 	int nsub = 1;                                              // grid-wide ordered passes in round 0 (see process_block)
 	// test hooks, read from the environment by kmx_begin: forced pass counts, forced older code
@@ -321,7 +322,8 @@ static int kmx_create_impl(int ci, int cs, int nh, int nb, kmx_model **out)
 	HIPCHK(hipMalloc((void **)&m->d_nbf, 3 * 8));
 	HIPCHK(hipMemset(m->d_stats, 0, ST_N * 8));
 	HIPCHK(hipHostMalloc((void **)&m->h_total, 64));
-	HIPCHK(hipHostMalloc((void **)&m->h_feedback, 64));
+	HIPCHK(hipHostMalloc((void **)&m->h_feedback, 64, hipHostMallocMapped));
+	HIPCHK(hipHostGetDevicePointer((void **)&m->d_feedback, m->h_feedback, 0));
 	m->h_feedback[0] = ~0ULL; m->h_feedback[1] = 0;
 	{
 		auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
@@ -549,7 +551,8 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 	m->bd.counts = m->d_stg_counts + head;
 	int pp = 0;
 	kmxk::block_init(m->bd, nb, pp, (int)n_in_block, m->stream);
-	// Contention feedback (pinned words copied back after every block, so they lag by a block or two; they steer a
+	// Contention feedback (pinned words that k_rest_append writes at the end of every block, read here while the device is
+	// some blocks behind; they steer a
 	// launch-count heuristic only, never the result): the largest contended set per list, and the largest set that
 	// reached the single-workgroup finisher.  Small sets are decided by the finisher alone; when too much reaches it,
 	// grid-wide ordered passes are added in front of it.
@@ -570,8 +573,6 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 		pp ^= 1;
 		m->rounds++;
 	}
-	HIPCHK(hipMemcpyAsync(m->h_feedback, m->d_stats + ST_MAX_U0, 16, hipMemcpyDeviceToHost, m->stream));
-	HIPCHK(hipMemsetAsync(m->d_stats + ST_MAX_U0, 0, 16, m->stream));
 	TRY(ensure_rest_capacity(m, n_in_block + (u64)nb));
 	if (final_partial) {
 		int row = (int)((n_in_block - 1) / KMX_BUCKET);
@@ -579,7 +580,7 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 			hipLaunchKernelGGL(k_stale_dup, dim3(1), dim3(64), 0, m->stream, row + 1, nb, m->W, (const u64 *)m->d_stale_kmers,
 			                   (const int *)m->d_stale_counts, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stats);
 	}
-	kmxk::rest_append(m->md, m->bd, pp, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->stream);
+	kmxk::rest_append(m->md, m->bd, pp, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream);
 	m->blocks++;
 	HIPCHK(hipGetLastError());
 	return KMX_OK;
