@@ -106,6 +106,12 @@ def test_build_save_query_bit_exact(name, golden, tmp_path):
     # reload what we saved and query again (load path)
     m2 = KModel.load(d)
     assert np.array_equal(m2.kmer_to_occ_packed(q), occ)
+    # ... and a loaded model saves the same three files again (load -> save round trip)
+    d2 = str(tmp_path / "model_again")
+    os.makedirs(d2)
+    m2.save(d2)
+    for f in ("header", "km.bin", "rest.bin"):
+        assert sha_file(os.path.join(d2, f)) == g["sha256"][f], f
     m.close(); m2.close(); o.close()
 
 
