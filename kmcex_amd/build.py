@@ -30,7 +30,7 @@ def stale() -> bool:
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
-    objs = []
+    objs, cmds = [], []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
@@ -40,8 +40,12 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
             cmd.insert(2, "c++")
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
         objs.append(obj)
+        cmds.append(cmd)
+    procs = [subprocess.Popen(c) for c in cmds]                  # the translation units compile side by side
+    failed = [c for c, p in zip(cmds, procs) if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
