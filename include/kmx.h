@@ -84,6 +84,44 @@ int kmx_finish(kmx_model *m);
 int kmx_build_dev(kmx_model *m, int k, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n);
 int kmx_build_host(kmx_model *m, int k, const uint64_t *kmers, const uint32_t *counts, uint64_t n);
 
+/* ---- ONE model built by several GPUs (one process per GPU) -------------------------------------
+ * The reference's insert is n_bits OpenMP threads in a rotation: thread i walks buffer i against array (i + t) % n_bits,
+ * barrier, next t (insert_with_thread, kmodel.hpp:557-573).  Here the arrays are owned whole by different GPUs and the
+ * survivors of a list travel round the ring as *messages*; the order-free filters (Bloom, back, km_back: set_bit is an
+ * atomic OR, kmodel.hpp:576-581) are built as per-rank partial filters and merged by OR.  These entry points are the
+ * per-rank compute; the exchange between them (RCCL all-to-all / send-recv / broadcast over xGMI) belongs to the caller
+ * (kmcex_amd/dist.py, torch.distributed).  All pointers are DEVICE pointers; work is enqueued on the model's stream.     */
+typedef struct kmx_ring_list {
+	int32_t list;             /* buffer index i of the block; the round attempts array (i + t) % nb (kmodel.hpp:563) */
+	int32_t n_host;           /* >= 0: entries, known on the host (round 0, fresh from the stream); -1: read it from src_msg */
+	const void *src_kmers;    /* n_host >= 0: packed k-mers / uint32 counts of the list                                */
+	const void *src_counts;
+	const void *src_msg;      /* n_host < 0: the list as a message (kmx_ring_msg_bytes) left by kmx_ring_round_dev      */
+	void *dst_msg;            /* survivors of this round, in list order, as a message; NULL = last round: rest table     */
+} kmx_ring_list;
+/* pass 1 on this rank's slice (get_km_kmer_count's histogram, kmodel.hpp:423-428); the caller sums over the ranks      */
+int kmx_count_classes_dev(kmx_model *m, const uint32_t *d_counts, uint64_t n, uint64_t n_bf[3]);
+/* kmx_begin with whole-model figures (every rank sizes and allocates the whole model, kmodel.hpp:402-456)             */
+int kmx_shard_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world);
+/* pass 2 front end on this rank's slice (kmodel.hpp:70-73): Bloom-class k-mers -> this rank's partial filters;
+ * coupled-array k-mers compacted in listing order into d_out_* (capacity n); *n_out on the host                       */
+int kmx_shard_classify_dev(kmx_model *m, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n, uint64_t *d_out_kmers, uint32_t *d_out_counts, uint64_t *n_out);
+/* bytes of one list message: 64-byte header (word 0 = entries) + 2^18 k-mers + 2^18 counts                             */
+uint64_t kmx_ring_msg_bytes(int k);
+/* insert_array(buff[i], (i + t) % nb, ...) for the lists this rank holds in round t (kmodel.hpp:543-555, :560-565)     */
+int kmx_ring_round_dev(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists);
+/* stale-slot duplicate of the final partial block for the lists this rank retired (kmodel.hpp:520-527)                 */
+int kmx_ring_stale_dup_dev(kmx_model *m, int first_unused_row);
+/* this rank's statistics (attempts, successes, ..., rest_entries = survivors it holds) and its survivor list           */
+int kmx_shard_local(kmx_model *m, kmx_stats *partial, void **d_rest_kmers, void **d_rest_counts);
+/* kld->build() on the survivors of ALL ranks + the summed statistics; the handle becomes a full replica (kmodel.hpp:80) */
+int kmx_shard_complete(kmx_model *m, const uint64_t *d_rest_kmers, const int32_t *d_rest_counts, uint64_t n_rest, const kmx_stats *totals);
+/* device memory of filter / array storage for the caller's collectives: which 0 bf[i], 1 bf_back[i], 2 km_back
+ * (bytes rounded up to 32-bit words), 3 the cells of coupled array i (value+tag interleaved, 8 bytes per 16 positions)  */
+int kmx_dev_view(kmx_model *m, int which, int index, void **ptr, uint64_t *bytes);
+/* dst |= src over n 32-bit words (merging partial filters)                                                              */
+int kmx_or_words_dev(kmx_model *m, void *d_dst, const void *d_src, uint64_t n_words);
+
 /* vector<int> KModel::kmer_to_occ(vector<string>, t_num)                   kmodel.hpp:90-98   */
 int kmx_query_packed(kmx_model *m, const uint64_t *kmers, uint64_t n, int32_t *out);
 int kmx_query_packed_dev(kmx_model *m, const uint64_t *d_kmers, uint64_t n, int32_t *d_out);

@@ -40,7 +40,15 @@ ABI_SYMBOLS = [
     "kmx_query_packed", "kmx_query_packed_dev", "kmx_query_ascii", "kmx_query_strings", "kmx_save", "kmx_load", "kmx_get_stats",
     "kmx_download", "kmx_debug_hash", "kmx_debug_min_kmer", "kmx_occubin", "kmx_microbench", "kmx_last_build_seconds",
     "kmx_set_profile", "kmx_get_kernel_times", "kmx_kmc_info", "kmx_kmc_read", "kmx_debug_mod",
+    "kmx_count_classes_dev", "kmx_shard_begin", "kmx_shard_classify_dev", "kmx_ring_msg_bytes", "kmx_ring_round_dev",
+    "kmx_ring_stale_dup_dev", "kmx_shard_local", "kmx_shard_complete", "kmx_dev_view", "kmx_or_words_dev",
 ]
+
+
+class RingList(C.Structure):
+    """kmx_ring_list of include/kmx.h"""
+    _fields_ = [("list", C.c_int32), ("n_host", C.c_int32), ("src_kmers", C.c_void_p), ("src_counts", C.c_void_p),
+                ("src_msg", C.c_void_p), ("dst_msg", C.c_void_p)]
 
 _lib = None
 
@@ -102,6 +110,17 @@ def load_library():
     L.kmx_last_build_seconds.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.kmx_kmc_info.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(u64)]
     L.kmx_kmc_read.argtypes = [C.c_char_p, vp, vp, u64, C.POINTER(u64)]
+    L.kmx_count_classes_dev.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.kmx_shard_begin.argtypes = [vp, i32, C.POINTER(u64), u64, i32, i32]
+    L.kmx_shard_classify_dev.argtypes = [vp, vp, vp, u64, vp, vp, C.POINTER(u64)]
+    L.kmx_ring_msg_bytes.restype = u64
+    L.kmx_ring_msg_bytes.argtypes = [i32]
+    L.kmx_ring_round_dev.argtypes = [vp, i32, C.POINTER(RingList), i32]
+    L.kmx_ring_stale_dup_dev.argtypes = [vp, i32]
+    L.kmx_shard_local.argtypes = [vp, C.POINTER(Stats), C.POINTER(vp), C.POINTER(vp)]
+    L.kmx_shard_complete.argtypes = [vp, vp, vp, u64, C.POINTER(Stats)]
+    L.kmx_dev_view.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(u64)]
+    L.kmx_or_words_dev.argtypes = [vp, vp, vp, u64]
     L.kmx_set_profile.argtypes = [vp, i32]
     L.kmx_get_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), i32]
     _lib = L
@@ -212,6 +231,52 @@ class KModel:
 
     def set_stream(self, stream_ptr: int) -> None:
         _chk(self.L.kmx_set_stream(self.h, stream_ptr))
+
+    # ---- one model, several GPUs: this rank's share (include/kmx.h, "ONE model built by several GPUs"; driven by dist.py)
+    def count_classes_dev(self, d_counts_ptr: int, n: int):
+        arr = (C.c_uint64 * 3)()
+        _chk(self.L.kmx_count_classes_dev(self.h, d_counts_ptr, n, arr))
+        return [int(x) for x in arr]
+
+    def shard_begin(self, k: int, n_bf, n_total: int, rank: int, world: int) -> None:
+        arr = (C.c_uint64 * 3)(*[int(x) for x in list(n_bf) + [0, 0, 0]][:3])
+        _chk(self.L.kmx_shard_begin(self.h, k, arr, n_total, rank, world))
+
+    def shard_classify_dev(self, d_kmers_ptr: int, d_counts_ptr: int, n: int, d_out_kmers_ptr: int, d_out_counts_ptr: int) -> int:
+        n_out = C.c_uint64(0)
+        _chk(self.L.kmx_shard_classify_dev(self.h, d_kmers_ptr, d_counts_ptr, n, d_out_kmers_ptr, d_out_counts_ptr, C.byref(n_out)))
+        return int(n_out.value)
+
+    def ring_msg_bytes(self, k: int) -> int:
+        return int(self.L.kmx_ring_msg_bytes(k))
+
+    def ring_round_dev(self, t: int, lists) -> None:
+        """lists: (list, n_host, src_kmers_ptr, src_counts_ptr, src_msg_ptr, dst_msg_ptr) tuples, 0 for null pointers"""
+        arr = (RingList * max(len(lists), 1))()
+        for e, (i, n_host, sk, sc, sm, dm) in enumerate(lists):
+            arr[e] = RingList(i, n_host, sk or None, sc or None, sm or None, dm or None)
+        _chk(self.L.kmx_ring_round_dev(self.h, t, arr, len(lists)))
+
+    def ring_stale_dup_dev(self, first_unused_row: int) -> None:
+        _chk(self.L.kmx_ring_stale_dup_dev(self.h, first_unused_row))
+
+    def shard_local(self):
+        st, pk, pc = Stats(), C.c_void_p(), C.c_void_p()
+        _chk(self.L.kmx_shard_local(self.h, C.byref(st), C.byref(pk), C.byref(pc)))
+        return st, pk.value or 0, pc.value or 0
+
+    def shard_complete(self, d_rest_kmers_ptr: int, d_rest_counts_ptr: int, n_rest: int, totals: Stats) -> None:
+        _chk(self.L.kmx_shard_complete(self.h, d_rest_kmers_ptr or None, d_rest_counts_ptr or None, n_rest, C.byref(totals)))
+
+    def dev_view(self, which: str, index: int = 0):
+        """(device pointer, bytes) of a filter ("bf", "bf_back", "km_back") or of the cells of coupled array `index` ("cells")"""
+        sel = {"bf": 0, "bf_back": 1, "km_back": 2, "cells": 3}[which]
+        p, n = C.c_void_p(), C.c_uint64(0)
+        _chk(self.L.kmx_dev_view(self.h, sel, index, C.byref(p), C.byref(n)))
+        return p.value or 0, int(n.value)
+
+    def or_words_dev(self, d_dst_ptr: int, d_src_ptr: int, n_words: int) -> None:
+        _chk(self.L.kmx_or_words_dev(self.h, d_dst_ptr, d_src_ptr, n_words))
 
     # ---- query
     def kmer_to_occ(self, kmers, t_num: int = 4):             # kmodel.hpp:90,100 (t_num kept for signature parity)

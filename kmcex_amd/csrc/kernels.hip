@@ -1098,7 +1098,8 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 
 // survivors of the block go to the rest table (kmodel.hpp:567-571); slot 0 is remembered for the
 // stale-slot duplicate of the final block (quirk Q1)
-template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev bd, int pp, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, u64 *feedback)
+// (i0: first list of the launch -- the whole block with grid.y = nb, or ONE list that a rank of the multi-GPU ring retires)
+template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev bd, int pp, int i0, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, u64 *feedback)
 {
 	__shared__ int s_cnt;
 	__shared__ unsigned long long s_base;
@@ -1108,7 +1109,7 @@ template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev b
 	}
 	if (threadIdx.x == 0) s_cnt = 0;
 	__syncthreads();
-	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	const int i = i0 + blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
 	const int n = bd.n[pp][i];
 	if (x == 0 && n == 0) stale_counts[i] = 0;
 	const bool act = x < n;
@@ -1130,6 +1131,64 @@ template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev b
 	store_kmer<W>(rest_kmers, p, v);
 	rest_counts[p] = c;
 	if (x == 0) { store_kmer<W>(stale_kmers, (u64)i, v); stale_counts[i] = c; }
+}
+
+// ------------------------------------------------------------------------------------------ multi-GPU ring (one model, several GPUs)
+// The rotation insert_array(buff[i], (i + t) % n_thread, ...) (kmodel.hpp:560-565) with the arrays owned whole by
+// different GPUs: after a round the survivors of a list travel, in list order, to the GPU that owns the next array.
+// A list in flight is a *message* in device memory: u64 header[8] (header[0] = n), BUCKET*W packed k-mers, BUCKET
+// counts.  The receiver starts the next round from a fresh identity list over the message (the reference physically
+// moves its KmerBuff entries in reorder_buffer, so the order of a list is all there is to it).
+template <int W> __global__ __launch_bounds__(256) void k_ring_import(BlockDev bd, int nb, RingLists rl, u64 *stg_kmers, u32 *stg_counts)
+{
+	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	const RingList e = rl.e[i];
+	const u64 row = (u64)i * KMX_BUCKET;
+	int n = 0;
+	if (e.active) {
+		const u64 *src_k = e.n_host >= 0 ? e.src_kmers : e.src_msg + KMX_MSG_HDR;
+		const u32 *src_c = e.n_host >= 0 ? e.src_counts : (const u32 *)(e.src_msg + KMX_MSG_HDR + (u64)KMX_BUCKET * W);
+		n = e.n_host >= 0 ? e.n_host : (int)e.src_msg[0];
+		if (n > (int)KMX_BUCKET) n = (int)KMX_BUCKET;               // a malformed header must not walk out of the buffers
+		if (x < n) {
+			u64 v[W];
+			load_kmer<W>(src_k, (u64)x, v);
+			store_kmer<W>(stg_kmers, row + x, v);
+			stg_counts[row + x] = src_c[x];
+		}
+		bd.list[0][row + x] = (u32)x;
+	}
+	if (x < (int)KMX_NTILES) { bd.tile_cnt[0][i * KMX_NTILES + x] = 0; bd.tile_cnt[1][i * KMX_NTILES + x] = 0; }
+	if (x == 0) {
+		bd.n[0][i] = n;                                            // lists that are elsewhere in the ring this round are empty here
+		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, nb)] = 0;
+	}
+}
+
+// survivors of the round (list[1], after k_reorder) in list order -> message
+template <int W> __global__ __launch_bounds__(256) void k_ring_export(BlockDev bd, RingLists rl)
+{
+	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	const RingList e = rl.e[i];
+	if (!e.active || !e.dst_msg) return;
+	const int n = bd.n[1][i];
+	const u64 row = (u64)i * KMX_BUCKET;
+	if (x == 0) e.dst_msg[0] = (u64)n;
+	if (x >= n) return;
+	const u32 idx = list_entry(bd, 1, row, x);
+	u64 v[W];
+	load_kmer<W>(bd.kmers, row + idx, v);
+	store_kmer<W>(e.dst_msg + KMX_MSG_HDR, (u64)x, v);
+	((u32 *)(e.dst_msg + KMX_MSG_HDR + (u64)KMX_BUCKET * W))[x] = bd.counts[row + idx];
+}
+
+// dst |= src, 32-bit words (merging the partial Bloom / back filters of the ranks: set_bit is an OR, kmodel.hpp:576-581)
+__global__ __launch_bounds__(256) void k_or_words(u32 *dst, const u32 *src, u64 n)
+{
+	for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+		const u32 s = src[i];
+		if (s) dst[i] |= s;
+	}
 }
 
 // ------------------------------------------------------------------------------------------ query
@@ -1720,9 +1779,26 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	KPROF_END(prof, st);
 }
 
-void rest_append(const ModelDev &md, const BlockDev &bd, int pp, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, u64 *feedback, hipStream_t st)
+// lists [i0, i0 + n_lists) of the block go to the rest table
+void rest_append(const ModelDev &md, const BlockDev &bd, int pp, int i0, int n_lists, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, u64 *feedback, hipStream_t st)
 {
-	DISPATCH_W(words(md), hipLaunchKernelGGL(k_rest_append<W>, dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, bd, pp, rest_kmers, rest_counts, rest_n, stale_kmers, stale_counts, feedback));
+	DISPATCH_W(words(md), hipLaunchKernelGGL(k_rest_append<W>, dim3(KMX_BUCKET / 256, n_lists), dim3(256), 0, st, bd, pp, i0, rest_kmers, rest_counts, rest_n, stale_kmers, stale_counts, feedback));
+}
+
+void ring_import(const ModelDev &md, const BlockDev &bd, const RingLists &rl, u64 *stg_kmers, u32 *stg_counts, hipStream_t st)
+{
+	DISPATCH_W(words(md), hipLaunchKernelGGL(k_ring_import<W>, dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, bd, md.nb, rl, stg_kmers, stg_counts));
+}
+void ring_export(const ModelDev &md, const BlockDev &bd, const RingLists &rl, hipStream_t st)
+{
+	DISPATCH_W(words(md), hipLaunchKernelGGL(k_ring_export<W>, dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, bd, rl));
+}
+void or_words(u32 *dst, const u32 *src, u64 n, hipStream_t st)
+{
+	if (!n) return;
+	u64 blocks = (n + 1023) / 1024;
+	if (blocks > 65536) blocks = 65536;
+	hipLaunchKernelGGL(k_or_words, dim3((unsigned)blocks), dim3(256), 0, st, dst, src, n);
 }
 
 void query(const ModelDev &md, const u64 *kmers, u64 n, int *out, hipStream_t st, KernelProf *prof)

@@ -34,7 +34,10 @@ void classify_count(const ModelDev &, const u64 *, const u32 *, u64, u64, int *,
 void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int *, u64 *, u32 *, u64, hipStream_t);
 void block_init(const BlockDev &, int, int, int, hipStream_t);
 void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *);
-void rest_append(const ModelDev &, const BlockDev &, int, u64 *, int *, unsigned long long *, u64 *, int *, u64 *, hipStream_t);
+void rest_append(const ModelDev &, const BlockDev &, int, int, int, u64 *, int *, unsigned long long *, u64 *, int *, u64 *, hipStream_t);
+void ring_import(const ModelDev &, const BlockDev &, const RingLists &, u64 *, u32 *, hipStream_t);
+void ring_export(const ModelDev &, const BlockDev &, const RingLists &, hipStream_t);
+void or_words(u32 *, const u32 *, u64, hipStream_t);
 void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *);
 void query_ascii(const ModelDev &, int, const unsigned char *, int, u64, int *, hipStream_t);
 void cells_from_disk(const unsigned char *, const unsigned char *, u64, u64 *, u64, hipStream_t);
@@ -181,6 +184,8 @@ struct kmx_model {
 	u64 *h_feedback = nullptr;                                 // pinned: ST_MAX_U0 as of some earlier block (heuristic input)
 	u64 *d_feedback = nullptr;                                 // the same words as the device sees them (k_rest_append writes them)
 	u64 epoch = 1, blocks = 0, rounds = 0;
+	bool ring = false;                                         // built by several GPUs (kmx_shard_begin): this handle holds ONE rank's share
+	int ring_rank = 0, ring_world = 1;
 	int nsub = 1;                                              // grid-wide ordered passes in round 0 (see process_block)
 	// test hooks, read from the environment by kmx_begin: forced pass counts, forced older code
 	// paths (KMX_ROUND_* flags of kmx_types.h), a trace of the pass-count controller
@@ -503,6 +508,7 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 	}
 	m->t_insert_kernels = 0; m->t_total = 0;
 	memset(m->h_stats, 0, sizeof m->h_stats);
+	m->ring = false; m->ring_rank = 0; m->ring_world = 1;
 	m->state = ST_BUILDING;
 	return KMX_OK;
 }
@@ -543,20 +549,12 @@ __global__ void k_stale_dup(int first_unused_row, int nb, int W, const u64 *stal
 	atomicAdd(stats + ST_ATTEMPTS, (u64)(nb - 1));
 }
 
-// insert_with_thread (kmodel.hpp:557-573) for the block at staging offset `head`
-static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_partial)
+// Contention feedback (pinned words that k_rest_append writes, read here while the device is some blocks behind; they
+// steer a launch-count heuristic only, never the result): the largest contended set per list, and the largest set that
+// reached the single-workgroup finisher.  Small sets are decided by the finisher alone; when too much reaches it,
+// grid-wide ordered passes are added in front of it.
+static void steer_passes(kmx_model *m)
 {
-	const int nb = m->nb;
-	m->bd.kmers = m->d_stg_kmers + head * m->W;
-	m->bd.counts = m->d_stg_counts + head;
-	int pp = 0;
-	kmxk::block_init(m->bd, nb, pp, (int)n_in_block, m->stream);
-	// Contention feedback (pinned words that k_rest_append writes at the end of every block, read here while the device is
-	// some blocks behind; they steer a
-	// launch-count heuristic only, never the result): the largest contended set per list, and the largest set that
-	// reached the single-workgroup finisher.  Small sets are decided by the finisher alone; when too much reaches it,
-	// grid-wide ordered passes are added in front of it.
-	const int force0 = m->dbg_nsub0, force1 = m->dbg_nsub1;
 	const u64 u0 = ((volatile u64 *)m->h_feedback)[0], ufin = ((volatile u64 *)m->h_feedback)[1];
 	if (u0 != ~0ULL) {
 		const u64 fin = 1024ull * KMX_FIN_RPT(m->nh <= 8 ? 8 : 16);
@@ -565,11 +563,26 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 		else if (m->nsub > 1 && ufin < fin / 4) m->nsub--;
 	}
 	if (m->dbg_ctrl) fprintf(stderr, "[kmx] block %llu feedback u0=%lld ufin=%lld -> nsub=%d\n", (unsigned long long)m->blocks, (long long)u0, (long long)ufin, m->nsub);
+}
+static int passes_of_round(const kmx_model *m, int t)
+{
+	int nsub = t == 0 ? m->nsub : m->nsub / 2;
+	if (t == 0 && m->dbg_nsub0 >= 0) nsub = m->dbg_nsub0;
+	if (t > 0 && m->dbg_nsub1 >= 0) nsub = m->dbg_nsub1;
+	return nsub;
+}
+
+// insert_with_thread (kmodel.hpp:557-573) for the block at staging offset `head`
+static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_partial)
+{
+	const int nb = m->nb;
+	m->bd.kmers = m->d_stg_kmers + head * m->W;
+	m->bd.counts = m->d_stg_counts + head;
+	int pp = 0;
+	kmxk::block_init(m->bd, nb, pp, (int)n_in_block, m->stream);
+	steer_passes(m);
 	for (int t = 0; t < nb; t++) {
-		int nsub = t == 0 ? m->nsub : m->nsub / 2;
-		if (t == 0 && force0 >= 0) nsub = force0;
-		if (t > 0 && force1 >= 0) nsub = force1;
-		kmxk::round(m->md, m->bd, t, pp, nsub, &m->epoch, m->dbg_flags, m->stream, &m->prof);
+		kmxk::round(m->md, m->bd, t, pp, passes_of_round(m, t), &m->epoch, m->dbg_flags, m->stream, &m->prof);
 		pp ^= 1;
 		m->rounds++;
 	}
@@ -580,9 +593,35 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 			hipLaunchKernelGGL(k_stale_dup, dim3(1), dim3(64), 0, m->stream, row + 1, nb, m->W, (const u64 *)m->d_stale_kmers,
 			                   (const int *)m->d_stale_counts, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stats);
 	}
-	kmxk::rest_append(m->md, m->bd, pp, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream);
+	kmxk::rest_append(m->md, m->bd, pp, 0, nb, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream);
 	m->blocks++;
 	HIPCHK(hipGetLastError());
+	return KMX_OK;
+}
+
+// per-tile counters / per-chunk totals of the classification front end for a batch of n k-mers
+static int ensure_front_end(kmx_model *m, u64 n)
+{
+	const u64 n_chunks = (n + kChunk - 1) / kChunk, tiles = (u64)kmxk::classify_tiles(n);
+	if (tiles > m->tile_cap) {
+		HIPCHK(hipStreamSynchronize(m->stream));
+		hipFree(m->d_tile_cnt); hipFree(m->d_tile_off);
+		m->d_tile_cnt = m->d_tile_off = nullptr;
+		m->tile_cap = 0;
+		TRY(dalloc(&m->d_tile_cnt, tiles, false, m->stream));
+		TRY(dalloc(&m->d_tile_off, tiles, false, m->stream));
+		m->tile_cap = tiles;
+	}
+	if (n_chunks > m->totals_cap) {
+		HIPCHK(hipStreamSynchronize(m->stream));
+		hipFree(m->d_totals);
+		if (m->h_totals) hipHostFree(m->h_totals);
+		m->d_totals = nullptr; m->h_totals = nullptr;
+		m->totals_cap = 0;
+		TRY(dalloc(&m->d_totals, n_chunks, false, m->stream));
+		HIPCHK(hipHostMalloc((void **)&m->h_totals, n_chunks * 4));
+		m->totals_cap = n_chunks;
+	}
 	return KMX_OK;
 }
 
@@ -598,24 +637,8 @@ static int kmx_insert_batch_dev_impl(kmx_model *m, const uint64_t *d_kmers, cons
 	if (!n) return KMX_OK;
 	HIPCHK(hipSetDevice(m->device));
 	const u64 blk = (u64)m->nb * KMX_BUCKET;
-	const u64 n_chunks = (n + kChunk - 1) / kChunk, tiles = (u64)kmxk::classify_tiles(n);
-	if (tiles > m->tile_cap) {
-		HIPCHK(hipStreamSynchronize(m->stream));
-		hipFree(m->d_tile_cnt); hipFree(m->d_tile_off);
-		m->d_tile_cnt = m->d_tile_off = nullptr;
-		TRY(dalloc(&m->d_tile_cnt, tiles, false, m->stream));
-		TRY(dalloc(&m->d_tile_off, tiles, false, m->stream));
-		m->tile_cap = tiles;
-	}
-	if (n_chunks > m->totals_cap) {
-		HIPCHK(hipStreamSynchronize(m->stream));
-		hipFree(m->d_totals);
-		if (m->h_totals) hipHostFree(m->h_totals);
-		m->d_totals = nullptr; m->h_totals = nullptr;
-		TRY(dalloc(&m->d_totals, n_chunks, false, m->stream));
-		HIPCHK(hipHostMalloc((void **)&m->h_totals, n_chunks * 4));
-		m->totals_cap = n_chunks;
-	}
+	const u64 n_chunks = (n + kChunk - 1) / kChunk;
+	TRY(ensure_front_end(m, n));
 	const u64 *km0 = (const u64 *)d_kmers;
 	const u32 *ct0 = (const u32 *)d_counts;
 	const u64 c0 = std::min<u64>(kChunk, n);
@@ -996,6 +1019,202 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 	}
 	cleanup();
 	return rc;
+}
+
+// ------------------------------------------------------------------------------------------ one model, several GPUs
+// SURVEY §8e.  One process per GPU; each handle holds ONE rank's share of a single model.  What the reference does with
+// n_bits OpenMP threads -- thread i walks buffer i against array (i + t) % n_bits, barrier, rotate (kmodel.hpp:560-565) --
+// is done by a ring of GPUs that own the arrays whole: after a round the survivors of a list travel to the owner of the
+// next array.  The order-free parts (Bloom filters, back filters, km_back: set_bit is an OR, kmodel.hpp:576-581) are
+// built as per-rank partial filters and merged by OR.  The exchange itself (RCCL all-to-all / send-recv / broadcast)
+// is the caller's: kmcex_amd/dist.py drives these entry points through torch.distributed.
+static int kmx_count_classes_dev_impl(kmx_model *m, const uint32_t *d_counts, uint64_t n, uint64_t n_bf[3])
+{
+	if (!m || !n_bf) return fail(KMX_E_ARG, "null argument");
+	HIPCHK(hipSetDevice(m->device));
+	HIPCHK(hipMemsetAsync(m->d_nbf, 0, 24, m->stream));
+	HIPCHK(hipMemsetAsync(m->d_stats, 0, ST_N * 8, m->stream));
+	kmxk::histogram((const u32 *)d_counts, n, m->ci, m->cs, m->bf_num, m->d_nbf, m->d_stats, m->stream);    // pass 1 (kmodel.hpp:423-428)
+	u64 bad = 0;
+	HIPCHK(hipMemcpyAsync(n_bf, m->d_nbf, 24, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipMemcpyAsync(&bad, m->d_stats + ST_BAD_COUNT, 8, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipStreamSynchronize(m->stream));
+	if (bad) return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)bad, m->ci, m->cs);
+	return KMX_OK;
+}
+
+static int kmx_shard_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world)
+{
+	if (world < 1 || rank < 0 || rank >= world) return fail(KMX_E_ARG, "bad rank %d of %d", rank, world);
+	TRY(kmx_begin_impl(m, k, n_bf, n_total));                   // whole-model sizes (kmodel.hpp:402-456): every rank allocates every array
+	m->ring = true; m->ring_rank = rank; m->ring_world = world;
+	m->bd.kmers = m->d_stg_kmers;                              // the lists a rank attempts are imported into the block staging area
+	m->bd.counts = m->d_stg_counts;
+	return KMX_OK;
+}
+
+// Front end of this rank's slice of the listing (kmodel.hpp:70-73): Bloom-class k-mers go into this rank's PARTIAL
+// filters; coupled-array k-mers are compacted, in listing order, into the caller's buffers (capacity >= n).
+static int kmx_shard_classify_dev_impl(kmx_model *m, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n, uint64_t *d_out_kmers, uint32_t *d_out_counts, uint64_t *n_out)
+{
+	if (!m || !n_out) return fail(KMX_E_ARG, "null argument");
+	if (m->state != ST_BUILDING || !m->ring) return fail(KMX_E_STATE, "shard_classify before shard_begin");
+	*n_out = 0;
+	if (!n) return KMX_OK;
+	HIPCHK(hipSetDevice(m->device));
+	TRY(ensure_front_end(m, n));
+	const u64 n_chunks = (n + kChunk - 1) / kChunk;
+	kmxk::classify_count(m->md, (const u64 *)d_kmers, (const u32 *)d_counts, n, kChunk, m->d_tile_cnt, m->d_tile_off, m->d_totals, m->d_stats, m->stream, &m->prof);
+	HIPCHK(hipMemcpyAsync(m->h_totals, m->d_totals, n_chunks * 4, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipStreamSynchronize(m->stream));
+	u64 base = 0;
+	for (u64 ci = 0, done = 0; ci < n_chunks; ci++) {
+		const u64 c = std::min<u64>(kChunk, n - done);
+		kmxk::classify_scatter(m->md, (const u64 *)d_kmers + done * m->W, (const u32 *)d_counts + done, c, m->d_tile_off + ci * (kChunk / KMX_CLS_TILE),
+		                       (u64 *)d_out_kmers, (u32 *)d_out_counts, base, m->stream);
+		base += (u64)m->h_totals[ci];
+		done += c;
+	}
+	HIPCHK(hipGetLastError());
+	*n_out = base;
+	return KMX_OK;
+}
+
+static uint64_t ring_msg_bytes(int k) { return 8ull * KMX_MSG_HDR + (u64)KMX_BUCKET * (8ull * ((k + 31) / 32) + 4); }
+
+// One round t on the lists this rank holds: import, A/B/S/R (the same kernels as the single-GPU build; the lists that
+// are elsewhere in the ring are empty here), then every list leaves as a message or, after the last round, goes to the
+// rest table (kmodel.hpp:567-571).
+static int kmx_ring_round_dev_impl(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists)
+{
+	if (!m || (n_lists && !lists)) return fail(KMX_E_ARG, "null argument");
+	if (m->state != ST_BUILDING || !m->ring) return fail(KMX_E_STATE, "ring_round before shard_begin");
+	const int nb = m->nb;
+	if (t < 0 || t >= nb || n_lists < 0 || n_lists > nb) return fail(KMX_E_ARG, "bad round %d / %d lists", t, n_lists);
+	if (m->km_byte_size == 0) return KMX_OK;                      // divergence D2: no arrays to insert into
+	HIPCHK(hipSetDevice(m->device));
+	RingLists rl;
+	memset(&rl, 0, sizeof rl);
+	for (int e = 0; e < n_lists; e++) {
+		const kmx_ring_list &l = lists[e];
+		if (l.list < 0 || l.list >= nb || rl.e[l.list].active) return fail(KMX_E_ARG, "bad or repeated list %d", l.list);
+		if (l.n_host > (int)KMX_BUCKET) return fail(KMX_E_ARG, "list %d longer than a buffer", l.list);
+		if (l.n_host >= 0 ? (l.n_host > 0 && (!l.src_kmers || !l.src_counts)) : !l.src_msg) return fail(KMX_E_ARG, "list %d has no source", l.list);
+		RingList &r = rl.e[l.list];
+		r.active = 1; r.n_host = l.n_host;
+		r.src_kmers = (const u64 *)l.src_kmers; r.src_counts = (const u32 *)l.src_counts; r.src_msg = (const u64 *)l.src_msg;
+		r.dst_msg = (u64 *)l.dst_msg;
+	}
+	if (t == 0) steer_passes(m);
+	kmxk::ring_import(m->md, m->bd, rl, m->d_stg_kmers, m->d_stg_counts, m->stream);
+	kmxk::round(m->md, m->bd, t, 0, passes_of_round(m, t), &m->epoch, m->dbg_flags, m->stream, &m->prof);
+	m->rounds++;
+	bool any_out = false;
+	for (int i = 0; i < nb; i++) any_out |= rl.e[i].active && rl.e[i].dst_msg;
+	if (any_out) kmxk::ring_export(m->md, m->bd, rl, m->stream);
+	for (int i = 0; i < nb; i++)
+		if (rl.e[i].active && !rl.e[i].dst_msg) {
+			TRY(ensure_rest_capacity(m, (u64)KMX_BUCKET + (u64)nb));
+			kmxk::rest_append(m->md, m->bd, 1, i, 1, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream);
+		}
+	if (t == nb - 1) m->blocks++;
+	HIPCHK(hipGetLastError());
+	return KMX_OK;
+}
+
+// Quirk Q1 in the ring: the rank that retired list i in the previous block holds its stale slot 0 (kmodel.hpp:520-527, :539)
+static int kmx_ring_stale_dup_dev_impl(kmx_model *m, int first_unused_row)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	if (m->state != ST_BUILDING || !m->ring) return fail(KMX_E_STATE, "ring_stale_dup before shard_begin");
+	if (first_unused_row < 0 || first_unused_row >= m->nb || m->km_byte_size == 0) return KMX_OK;
+	HIPCHK(hipSetDevice(m->device));
+	TRY(ensure_rest_capacity(m, (u64)m->nb));
+	hipLaunchKernelGGL(k_stale_dup, dim3(1), dim3(64), 0, m->stream, first_unused_row, m->nb, m->W, (const u64 *)m->d_stale_kmers,
+	                   (const int *)m->d_stale_counts, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stats);
+	HIPCHK(hipGetLastError());
+	return KMX_OK;
+}
+
+// this rank's share when its last round is enqueued: statistics and the survivors it retired (device pointers)
+static int kmx_shard_local_impl(kmx_model *m, kmx_stats *partial, void **d_rest_kmers, void **d_rest_counts)
+{
+	if (!m || !partial) return fail(KMX_E_ARG, "null argument");
+	if (m->state != ST_BUILDING || !m->ring) return fail(KMX_E_STATE, "shard_local before shard_begin");
+	HIPCHK(hipSetDevice(m->device));
+	unsigned long long n_rest = 0;
+	HIPCHK(hipMemcpyAsync(m->h_stats, m->d_stats, ST_N * 8, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipMemcpyAsync(&n_rest, m->d_rest_n, 8, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipStreamSynchronize(m->stream));
+	if (m->h_stats[ST_BAD_COUNT]) return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)m->h_stats[ST_BAD_COUNT], m->ci, m->cs);
+	if (m->prof.on) prof_collect(m);
+	memset(partial, 0, sizeof *partial);
+	partial->attempts = m->h_stats[ST_ATTEMPTS]; partial->successes = m->h_stats[ST_SUCCESSES];
+	partial->fast_commits = m->h_stats[ST_SUCCESSES] - m->h_stats[ST_SLOW_SUCC];
+	partial->contended = m->h_stats[ST_CONTENDED]; partial->finisher_iters = m->h_stats[ST_FIN_ITERS];
+	partial->rest_entries = n_rest; partial->blocks = m->blocks; partial->rounds = m->rounds;
+	if (d_rest_kmers) *d_rest_kmers = m->d_rest_kmers;
+	if (d_rest_counts) *d_rest_counts = m->d_rest_counts;
+	return KMX_OK;
+}
+
+// The merged model: the caller has OR-merged the filters and broadcast the arrays into this handle's memory
+// (kmx_dev_view); `d_rest_*` hold the survivors of ALL ranks (any order: KRestData::build sorts, rest.hpp:95-135).
+static int kmx_shard_complete_impl(kmx_model *m, const uint64_t *d_rest_kmers, const int32_t *d_rest_counts, uint64_t n_rest, const kmx_stats *totals)
+{
+	if (!m || !totals) return fail(KMX_E_ARG, "null argument");
+	if (m->state != ST_BUILDING || !m->ring) return fail(KMX_E_STATE, "shard_complete before shard_begin");
+	if (n_rest && (!d_rest_kmers || !d_rest_counts)) return fail(KMX_E_ARG, "null rest list");
+	HIPCHK(hipSetDevice(m->device));
+	if (n_rest && (const u64 *)d_rest_kmers != m->d_rest_kmers) {
+		if (n_rest > m->rest_cap) {
+			HIPCHK(hipStreamSynchronize(m->stream));
+			hipFree(m->d_rest_kmers); hipFree(m->d_rest_counts);
+			m->d_rest_kmers = nullptr; m->d_rest_counts = nullptr; m->rest_cap = 0;
+			TRY(dalloc(&m->d_rest_kmers, n_rest * m->W, false, m->stream));
+			TRY(dalloc(&m->d_rest_counts, n_rest, false, m->stream));
+			m->rest_cap = n_rest;
+		}
+		HIPCHK(hipMemcpyAsync(m->d_rest_kmers, d_rest_kmers, n_rest * m->W * 8, hipMemcpyDeviceToDevice, m->stream));
+		HIPCHK(hipMemcpyAsync(m->d_rest_counts, d_rest_counts, n_rest * 4, hipMemcpyDeviceToDevice, m->stream));
+	}
+	TRY(build_rest(m, n_rest));
+	m->h_stats[ST_ATTEMPTS] = totals->attempts; m->h_stats[ST_SUCCESSES] = totals->successes;
+	m->h_stats[ST_SLOW_SUCC] = totals->successes - totals->fast_commits;
+	m->h_stats[ST_CONTENDED] = totals->contended; m->h_stats[ST_FIN_ITERS] = totals->finisher_iters;
+	m->blocks = totals->blocks; m->rounds = totals->rounds;
+	fill_model_dev(m);
+	m->ring = false;
+	m->state = ST_READY;
+	return KMX_OK;
+}
+
+// device memory of one filter / array of this handle, for the collectives of the caller (which: as kmx_download; 3 = the
+// cells of coupled array `index`, value and tag interleaved -- see device_common.h)
+static int kmx_dev_view_impl(kmx_model *m, int which, int index, void **ptr, uint64_t *bytes)
+{
+	if (!m || !ptr || !bytes) return fail(KMX_E_ARG, "null argument");
+	if (m->state == ST_EMPTY) return fail(KMX_E_STATE, "no arrays yet");
+	if (which >= 0 && which <= 1 && (index < 0 || index >= m->bf_num)) return fail(KMX_E_ARG, "bad filter index");
+	if (which == 3 && (index < 0 || index >= m->nb)) return fail(KMX_E_ARG, "bad array index");
+	auto words = [](u64 nbytes) { return ((nbytes + 3) / 4) * 4; };
+	switch (which) {
+	case 0: *ptr = m->d_bf[index]; *bytes = words(m->byte_bf[index]); break;
+	case 1: *ptr = m->d_bf_back[index]; *bytes = words(m->byte_bf_back[index]); break;
+	case 2: *ptr = m->d_km_back; *bytes = words(m->byte_km_back); break;
+	case 3: *ptr = m->d_cells[index]; *bytes = m->ncells * 8; break;
+	default: return fail(KMX_E_ARG, "bad selector");
+	}
+	return KMX_OK;
+}
+
+static int kmx_or_words_dev_impl(kmx_model *m, void *d_dst, const void *d_src, uint64_t n_words)
+{
+	if (!m || (n_words && (!d_dst || !d_src))) return fail(KMX_E_ARG, "null argument");
+	HIPCHK(hipSetDevice(m->device));
+	kmxk::or_words((u32 *)d_dst, (const u32 *)d_src, n_words, m->stream);
+	HIPCHK(hipGetLastError());
+	return KMX_OK;
 }
 
 // ------------------------------------------------------------------------------------------ KMC listing (host only)
@@ -1530,6 +1749,16 @@ extern "C" int kmx_finish(kmx_model *m) { return guarded([&] { return kmx_finish
 extern "C" int kmx_build_dev(kmx_model *m, int k, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n) { return guarded([&] { return kmx_build_dev_impl(m, k, d_kmers, d_counts, n); }); }
 extern "C" int kmx_build_host(kmx_model *m, int k, const uint64_t *kmers, const uint32_t *counts, uint64_t n) { return guarded([&] { return kmx_build_host_impl(m, k, kmers, counts, n); }); }
 extern "C" int kmx_build_from_kmc(kmx_model *m, const char *db_prefix) { return guarded([&] { return kmx_build_from_kmc_impl(m, db_prefix); }); }
+extern "C" int kmx_count_classes_dev(kmx_model *m, const uint32_t *d_counts, uint64_t n, uint64_t n_bf[3]) { return guarded([&] { return kmx_count_classes_dev_impl(m, d_counts, n, n_bf); }); }
+extern "C" int kmx_shard_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world) { return guarded([&] { return kmx_shard_begin_impl(m, k, n_bf, n_total, rank, world); }); }
+extern "C" int kmx_shard_classify_dev(kmx_model *m, const uint64_t *d_kmers, const uint32_t *d_counts, uint64_t n, uint64_t *d_out_kmers, uint32_t *d_out_counts, uint64_t *n_out) { return guarded([&] { return kmx_shard_classify_dev_impl(m, d_kmers, d_counts, n, d_out_kmers, d_out_counts, n_out); }); }
+extern "C" uint64_t kmx_ring_msg_bytes(int k) { return ring_msg_bytes(k); }
+extern "C" int kmx_ring_round_dev(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists) { return guarded([&] { return kmx_ring_round_dev_impl(m, t, lists, n_lists); }); }
+extern "C" int kmx_ring_stale_dup_dev(kmx_model *m, int first_unused_row) { return guarded([&] { return kmx_ring_stale_dup_dev_impl(m, first_unused_row); }); }
+extern "C" int kmx_shard_local(kmx_model *m, kmx_stats *partial, void **d_rest_kmers, void **d_rest_counts) { return guarded([&] { return kmx_shard_local_impl(m, partial, d_rest_kmers, d_rest_counts); }); }
+extern "C" int kmx_shard_complete(kmx_model *m, const uint64_t *d_rest_kmers, const int32_t *d_rest_counts, uint64_t n_rest, const kmx_stats *totals) { return guarded([&] { return kmx_shard_complete_impl(m, d_rest_kmers, d_rest_counts, n_rest, totals); }); }
+extern "C" int kmx_dev_view(kmx_model *m, int which, int index, void **ptr, uint64_t *bytes) { return guarded([&] { return kmx_dev_view_impl(m, which, index, ptr, bytes); }); }
+extern "C" int kmx_or_words_dev(kmx_model *m, void *d_dst, const void *d_src, uint64_t n_words) { return guarded([&] { return kmx_or_words_dev_impl(m, d_dst, d_src, n_words); }); }
 extern "C" int kmx_kmc_info(const char *db_prefix, int *k, uint64_t *total_kmers) { return guarded([&] { return kmx_kmc_info_impl(db_prefix, k, total_kmers); }); }
 extern "C" int kmx_kmc_read(const char *db_prefix, uint64_t *kmers, uint32_t *counts, uint64_t capacity, uint64_t *n_read) { return guarded([&] { return kmx_kmc_read_impl(db_prefix, kmers, counts, capacity, n_read); }); }
 extern "C" int kmx_query_packed_dev(kmx_model *m, const uint64_t *d_kmers, uint64_t n, int32_t *d_out) { return guarded([&] { return kmx_query_packed_dev_impl(m, d_kmers, n, d_out); }); }

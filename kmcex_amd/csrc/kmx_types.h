@@ -67,6 +67,18 @@ struct BlockDev {
 
 #define LIST_HOLE 0x80000000u
 
+// One list of a multi-GPU ring round (kernels.hip, k_ring_import / k_ring_export), indexed by list number.
+#define KMX_MSG_HDR 8                          // u64 words of message header; word 0 = number of entries
+struct RingList {
+	int active;              // this rank attempts the list this round
+	int n_host;              // >= 0: entries, known on the host (fresh from the stream); < 0: read from the message header
+	const u64 *src_kmers;    // n_host >= 0
+	const u32 *src_counts;
+	const u64 *src_msg;      // n_host < 0: message received from the rank that owns the previous array
+	u64 *dst_msg;            // survivors of the round as a message; null in the last round (they go to the rest table)
+};
+struct RingLists { RingList e[KMX_MAX_NB]; };
+
 enum { SLOT_UNDECIDED = 0, SLOT_FAILED = 1, SLOT_INSERTED = 2 };
 
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).

@@ -1,17 +1,34 @@
-"""Multi-GPU plumbing shared by bench.py and the gloo tests: one process per GPU, torch.distributed
-(backend "nccl" = RCCL over xGMI on MI355X, "gloo" on CPU for tests).
+"""One KModel across several GPUs: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on MI355X;
+"gloo" for the CPU tests and for rehearsing N ranks on a one-GPU box).
 
-What shards today: *models*.  Every rank owns one listing (one KMC database / sample)
-and builds + queries its own KModel; there is no data-path collective, only the timing/count reduction
-below.  Queries against ONE model shard by batch (`split_batch`): every rank holds a replica of the
-read-only model and answers its slice -- again no collective on the data path.
+What the reference does with OpenMP threads inside ONE process (SURVEY.md §2 a-d, §8e) maps onto the ranks like this:
+
+* **coupled arrays = a ring** -- the reference's insert is the rotation ``insert_array(buff[i], (i + t) % n_thread, ...)``
+  (``kmodel.hpp:560-565``): thread ``i`` walks buffer ``i`` against array ``(i + t) % nb``, barrier, next ``t``.  Here the
+  arrays are owned whole (``owner_of_array``): round ``t`` of a block runs on the rank that owns the array, then the
+  survivors of the list travel, in list order, to the owner of the next array (RCCL send/recv, one xGMI hop).
+  Round 0 needs buffer ``i`` of every block on the owner of array ``i``: the k-mers are routed there by ONE
+  **all-to-all** from the ranks that listed them (``plan_routing``).
+* **Bloom filters, back filters, km_back** are order-free (``set_bit`` is an OR, ``kmodel.hpp:576-581``): every rank fills
+  partial filters from what it handles and the partials are merged by position range -- an all-to-all of ranges, an OR
+  on the owner, an all-gather (``or_allreduce``).  That moves 1.7 B per Bloom k-mer and 0.3 B per coupled k-mer
+  instead of 8 B per hashed position.
+* **queries** shard by batch over read-only replicas (``query_replicas``): after the merge every rank holds the whole
+  model (47 GB at 10^10 k-mers, far below 288 GB).
+
+The per-rank compute is behind an *engine* (``DeviceEngine`` = libkmx.so through the C ABI; the tests also drive the same
+orchestration with a CPU engine made of the oracle, which is how the N>1 protocol is checked without a GPU).
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
+
+BUCKET = 1 << 18            # kmodel.hpp:276 bucket_size
 
 
 def env_world():
@@ -42,14 +59,342 @@ def reduce_job(seconds, units, device="cpu"):
     return t.tolist(), u.tolist()
 
 
-def gather_slices(local: torch.Tensor, n_total: int, world: int, rank: int):
+def gather_slices(local: torch.Tensor, n_total: int, world: int, rank: int, comm: "Comm | None" = None):
     """All-gather the per-rank answers of a batch split with `split_batch` back into batch order (ragged slices)."""
     if world == 1:
         return local
     sizes = [split_batch(n_total, world, r) for r in range(world)]
+    if comm is not None:
+        return comm.all_gather_v(local, [hi - lo for lo, hi in sizes])
     width = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros(width, dtype=local.dtype, device=local.device)
     pad[: local.numel()] = local
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
     return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)])
+
+
+# ------------------------------------------------------------------------------------------------ who owns what
+def owner_of_array(a: int, nb: int, world: int) -> int:
+    """Arrays are owned whole, in contiguous runs, by the first min(world, nb) ranks: consecutive arrays mostly share a
+    rank, so a list changes GPUs only where a run ends (the rotation visits the arrays in order, kmodel.hpp:563)."""
+    return a * min(world, nb) // nb
+
+
+def _segments(off: int, c: int, nb: int):
+    """The range [off, off + c) of the coupled-array stream cut at buffer boundaries: (lo, hi, buffer index) rows.
+    Element g of the stream sits in buffer (g >> 18) % nb of block g // (nb << 18) (push_to_array, kmodel.hpp:508-513)."""
+    if c <= 0:
+        return np.zeros((0, 3), dtype=np.int64)
+    first, last = off // BUCKET, (off + c - 1) // BUCKET
+    seg = np.arange(first, last + 1, dtype=np.int64)
+    lo = np.maximum(seg * BUCKET, off)
+    hi = np.minimum((seg + 1) * BUCKET, off + c)
+    return np.stack([lo, hi, seg % nb], axis=1)
+
+
+def plan_routing(counts_per_rank, nb: int, world: int, rank: int):
+    """All-to-all plan that brings every buffer of the coupled-array stream to the rank owning the array it meets first.
+
+    `counts_per_rank[q]` = coupled-array k-mers rank q holds (its listing slice, in listing order; slices are in rank
+    order).  Returns (send_slices, send_splits, recv_splits): local [lo, hi) slices in send order (grouped by
+    destination, ascending stream position inside a destination) and the per-rank split sizes.  Received pieces, taken
+    in source-rank order, are this rank's buffers in ascending stream position."""
+    offs = np.concatenate([[0], np.cumsum(np.asarray(counts_per_rank, dtype=np.int64))])
+    own = np.array([owner_of_array(a, nb, world) for a in range(nb)], dtype=np.int64)
+    recv_splits = []
+    for q in range(world):
+        seg = _segments(int(offs[q]), int(counts_per_rank[q]), nb)
+        mine = own[seg[:, 2]] == rank
+        recv_splits.append(int((seg[mine, 1] - seg[mine, 0]).sum()))
+    seg = _segments(int(offs[rank]), int(counts_per_rank[rank]), nb)
+    dest = own[seg[:, 2]]
+    send_slices, send_splits = [], []
+    for d in range(world):
+        rows = seg[dest == d]
+        send_slices += [(int(lo - offs[rank]), int(hi - offs[rank])) for lo, hi, _ in rows]
+        send_splits.append(int((rows[:, 1] - rows[:, 0]).sum()))
+    return send_slices, send_splits, recv_splits
+
+
+def list_length(n_km: int, nb: int, b: int, i: int) -> int:
+    """entries of buffer i in block b (push_to_array / push_last_to_array, kmodel.hpp:508-527)"""
+    return int(min(max(n_km - (b * nb + i) * BUCKET, 0), BUCKET))
+
+
+# ------------------------------------------------------------------------------------------------ the exchange
+class Comm:
+    """The collectives of the sharded build on top of torch.distributed.  Backend "nccl" (RCCL over xGMI) moves device
+    tensors directly; with "gloo" (CPU tests, rehearsal of N ranks on one GPU) device tensors are staged through the host.
+    """
+
+    def __init__(self, group=None):
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.staged = self.on and dist.get_backend(group) != "nccl"
+        self.bytes_sent = 0                                 # payload this rank handed to the backend (reporting)
+
+    def _wire(self, t: torch.Tensor) -> torch.Tensor:
+        return t.cpu() if (self.staged and t.is_cuda) else t
+
+    def all_reduce_ints(self, values, device, op=None):
+        if self.world == 1:
+            return [int(v) for v in values]
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64, device="cpu" if self.staged else device)
+        dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=self.group)
+        return [int(v) for v in t.tolist()]
+
+    def all_gather_ints(self, value: int, device):
+        if self.world == 1:
+            return [int(value)]
+        t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if self.staged else device)
+        out = torch.empty(self.world, dtype=torch.int64, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
+        return [int(v) for v in out.tolist()]
+
+    def all_to_all_v(self, send: torch.Tensor, send_splits, recv_splits) -> torch.Tensor:
+        """rows of `send` grouped by destination -> rows received, grouped by source"""
+        if self.world == 1:
+            return send
+        n_recv = int(sum(recv_splits))
+        w = self._wire(send.contiguous())
+        out = torch.empty((n_recv,) + tuple(send.shape[1:]), dtype=send.dtype, device=w.device)
+        dist.all_to_all_single(out, w, [int(x) for x in recv_splits], [int(x) for x in send_splits], group=self.group)
+        self.bytes_sent += (int(sum(send_splits)) - int(send_splits[self.rank])) * send.element_size() * int(np.prod(send.shape[1:], dtype=np.int64))
+        return out.to(send.device) if out.device != send.device else out
+
+    def exchange(self, sends, recvs):
+        """point-to-point hand-offs of one ring step: sends = [(tensor, dst rank)], recvs = [(tensor, src rank)]"""
+        if not sends and not recvs:
+            return
+        stage_out = [(self._wire(t), d) for t, d in sends]
+        stage_in = [(torch.empty(t.shape, dtype=t.dtype, device="cpu") if (self.staged and t.is_cuda) else t, s) for t, s in recvs]
+        ops = [dist.P2POp(dist.isend, t, d, group=self.group) for t, d in stage_out] + [dist.P2POp(dist.irecv, t, s, group=self.group) for t, s in stage_in]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for (dst, _), (st, _) in zip(recvs, stage_in):
+            if st is not dst:
+                dst.copy_(st)
+        self.bytes_sent += sum(t.numel() * t.element_size() for t, _ in sends)
+
+    def broadcast(self, t: torch.Tensor, src: int):
+        if self.world == 1:
+            return
+        if self.staged and t.is_cuda:
+            h = t.cpu()
+            dist.broadcast(h, src, group=self.group)
+            if self.rank != src:
+                t.copy_(h)
+        else:
+            dist.broadcast(t, src, group=self.group)
+        if self.rank == src:
+            self.bytes_sent += t.numel() * t.element_size()
+
+    def all_gather_v(self, local: torch.Tensor, counts) -> torch.Tensor:
+        """ragged all-gather of rows: rank q contributes counts[q] rows; result in rank order"""
+        if self.world == 1:
+            return local
+        width = int(max(counts))
+        pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+        w = self._wire(pad)
+        out = torch.empty((self.world * width,) + tuple(local.shape[1:]), dtype=local.dtype, device=w.device)
+        dist.all_gather_into_tensor(out, w, group=self.group)
+        self.bytes_sent += pad.numel() * pad.element_size() * (self.world - 1)
+        out = out.to(local.device) if out.device != local.device else out
+        return torch.cat([out[q * width: q * width + int(counts[q])] for q in range(self.world)])
+
+    def or_allreduce(self, words: torch.Tensor, or_into):
+        """Bitwise OR of `words` (int32, same length on every rank) over the ranks, in place, by position range: an
+        all-to-all brings range r of every rank's partial filter to rank r, `or_into(dst, src)` merges them there, an
+        all-gather hands every rank the merged filter (RCCL has no OR reduction)."""
+        if self.world == 1 or words.numel() == 0:
+            return
+        P, n = self.world, words.numel()
+        chunk = -(-n // P)
+        pad = torch.zeros(chunk * P, dtype=words.dtype, device=words.device)
+        pad[:n] = words
+        w = self._wire(pad)
+        got = torch.empty_like(w)
+        dist.all_to_all_single(got, w, group=self.group)
+        got = got.to(words.device) if got.device != words.device else got
+        acc = got[:chunk]
+        for q in range(1, P):
+            or_into(acc, got[q * chunk: (q + 1) * chunk])
+        aw = self._wire(acc.contiguous())
+        full = torch.empty(chunk * P, dtype=words.dtype, device=aw.device)
+        dist.all_gather_into_tensor(full, aw, group=self.group)
+        words.copy_(full[:n])
+        self.bytes_sent += 2 * chunk * (P - 1) * words.element_size()
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+
+# ------------------------------------------------------------------------------------------------ the GPU engine
+class _DevMem:
+    """Zero-copy torch view of device memory that libkmx owns (filters, arrays, survivor lists)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
+
+
+def dev_tensor(ptr: int, n: int, dtype: torch.dtype, device) -> torch.Tensor:
+    if n == 0 or not ptr:
+        return torch.empty(0, dtype=dtype, device=device)
+    return torch.as_tensor(_DevMem(ptr, n, {torch.int32: "<i4", torch.int64: "<i8"}[dtype]), device=device)
+
+
+class DeviceEngine:
+    """This rank's share of the model in HBM: libkmx.so through the C ABI (include/kmx.h, "ONE model built by several GPUs").
+    Tensors are int64 (packed k-mers, uint64 bit patterns) and int32 (counts, filter words) on `device`."""
+
+    def __init__(self, model, device):
+        self.m, self.device = model, device
+        model.set_stream(torch.cuda.current_stream(device).cuda_stream)     # kernels and collectives order on ONE stream
+
+    def count_classes(self, counts):
+        return self.m.count_classes_dev(counts.data_ptr(), counts.numel())
+
+    def shard_begin(self, k, n_bf, n_total, rank, world):
+        self.k, self.W = k, (k + 31) // 32
+        self.m.shard_begin(k, n_bf, n_total, rank, world)
+
+    def classify(self, kmers, counts):
+        n = counts.numel()
+        out_k = torch.empty_like(kmers)
+        out_c = torch.empty_like(counts)
+        n_out = self.m.shard_classify_dev(kmers.data_ptr(), counts.data_ptr(), n, out_k.data_ptr(), out_c.data_ptr())
+        return out_k[:n_out], out_c[:n_out]
+
+    def new_message(self):
+        return torch.zeros(self.m.ring_msg_bytes(self.k) // 8, dtype=torch.int64, device=self.device)
+
+    def ring_round(self, t, lists):
+        """lists: dicts {list, n (or None), kmers, counts, msg, out}; tensors or None"""
+        ptr = lambda x: 0 if x is None else x.data_ptr()                                   # noqa: E731
+        self.m.ring_round_dev(t, [(l["list"], -1 if l.get("n") is None else l["n"], ptr(l.get("kmers")), ptr(l.get("counts")), ptr(l.get("msg")), ptr(l.get("out"))) for l in lists])
+
+    def stale_dup(self, first_unused_row):
+        self.m.ring_stale_dup_dev(first_unused_row)
+
+    def local(self):
+        st, pk, pc = self.m.shard_local()
+        n = int(st.rest_entries)
+        km = dev_tensor(pk, n * self.W, torch.int64, self.device)
+        return st, (km.view(n, self.W) if self.W > 1 else km), dev_tensor(pc, n, torch.int32, self.device)
+
+    def view(self, which, index=0):
+        p, nbytes = self.m.dev_view(which, index)
+        return dev_tensor(p, nbytes // 4, torch.int32, self.device)
+
+    def or_into(self, dst, src):
+        self.m.or_words_dev(dst.data_ptr(), src.data_ptr(), dst.numel())
+
+    def complete(self, rest_kmers, rest_counts, totals):
+        rest_kmers, rest_counts = rest_kmers.contiguous(), rest_counts.contiguous()
+        self.m.shard_complete(rest_kmers.data_ptr() if rest_counts.numel() else 0, rest_counts.data_ptr() if rest_counts.numel() else 0, rest_counts.numel(), totals)
+
+
+# ------------------------------------------------------------------------------------------------ the sharded build
+STAT_FIELDS = ("attempts", "successes", "fast_commits", "contended", "finisher_iters")
+
+
+def build_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: torch.Tensor, counts: torch.Tensor, n_total: int | None = None):
+    """KModel::init (kmodel.hpp:57-86) of ONE model by `comm.world` ranks.  `kmers` / `counts`: this rank's contiguous slice
+    of the listing (slices in rank order = listing order).  On return every rank holds the whole model.
+
+    Returns a dict of figures (n_km, blocks, bytes this rank sent)."""
+    rank, world, dev = comm.rank, comm.world, counts.device
+    sent0 = comm.bytes_sent
+    # pass 1 (get_km_kmer_count, kmodel.hpp:423-434): class histogram of the slice, summed over the ranks
+    local_hist = eng.count_classes(counts)
+    tot = comm.all_reduce_ints(local_hist + [counts.numel()], dev)
+    n_bf, n_all = tot[:3], tot[3]
+    eng.shard_begin(k, n_bf, n_all if n_total is None else n_total, rank, world)
+    # pass 2 front end on the slice: partial Bloom/back filters + this rank's coupled-array k-mers in listing order
+    km_loc, cnt_loc = eng.classify(kmers, counts)
+    per_rank = comm.all_gather_ints(cnt_loc.shape[0], dev)
+    n_km = int(sum(per_rank))
+    # all-to-all: every buffer of the stream goes to the owner of the array it meets in round 0
+    send_slices, send_splits, recv_splits = plan_routing(per_rank, nb, world, rank)
+    if world > 1:
+        pick = lambda t: torch.cat([t[lo:hi] for lo, hi in send_slices]) if send_slices else t[:0]      # noqa: E731
+        km_mine = comm.all_to_all_v(pick(km_loc), send_splits, recv_splits)
+        cnt_mine = comm.all_to_all_v(pick(cnt_loc), send_splits, recv_splits)
+    else:
+        km_mine, cnt_mine = km_loc, cnt_loc
+    del km_loc, cnt_loc
+    own = [owner_of_array(a, nb, world) for a in range(nb)]
+    blk = nb * BUCKET
+    n_blocks = -(-n_km // blk)
+    msgs = {}
+
+    def msg(i, parity):
+        if (i, parity) not in msgs:
+            msgs[(i, parity)] = eng.new_message()
+        return msgs[(i, parity)]
+
+    pos = 0                                                     # read position in this rank's routed stream
+    for b in range(n_blocks):
+        n_in_block = min(blk, n_km - b * blk)
+        if n_in_block < blk and b > 0:                          # final partial block: quirk Q1 (kmodel.hpp:520-527)
+            row = (n_in_block - 1) // BUCKET
+            if row + 1 < nb:
+                eng.stale_dup(row + 1)
+        for t in range(nb):
+            lists, sends, recvs = [], [], []
+            for i in range(nb):
+                n_i = list_length(n_km, nb, b, i)
+                a = (i + t) % nb                                # kmodel.hpp:563
+                if n_i == 0:
+                    continue
+                if own[a] == rank:
+                    ent = {"list": i, "out": msg(i, (t + 1) & 1) if t + 1 < nb else None}
+                    if t == 0:
+                        ent.update(n=n_i, kmers=km_mine[pos:pos + n_i], counts=cnt_mine[pos:pos + n_i])
+                        pos += n_i
+                    else:
+                        ent.update(msg=msg(i, t & 1))
+                    lists.append(ent)
+                    if t + 1 < nb and own[(a + 1) % nb] != rank:
+                        sends.append((msg(i, (t + 1) & 1), own[(a + 1) % nb]))
+                elif t + 1 < nb and own[(a + 1) % nb] == rank:
+                    recvs.append((msg(i, (t + 1) & 1), own[a]))
+            if lists:
+                eng.ring_round(t, lists)
+            comm.exchange(sends, recvs)
+    # merge: survivors -> every rank; filters OR-merged by range; every array from its owner
+    st, rest_km, rest_cnt = eng.local()
+    rest_counts = comm.all_gather_ints(int(st.rest_entries), dev)
+    rest_km_all = comm.all_gather_v(rest_km, rest_counts)
+    rest_cnt_all = comm.all_gather_v(rest_cnt, rest_counts)
+    sums = comm.all_reduce_ints([getattr(st, f) for f in STAT_FIELDS], dev)
+    for f, v in zip(STAT_FIELDS, sums):
+        setattr(st, f, v)
+    st.blocks, st.rounds = n_blocks, n_blocks * nb
+    if world > 1:
+        for i in range(bf_num):
+            comm.or_allreduce(eng.view("bf", i), eng.or_into)
+            comm.or_allreduce(eng.view("bf_back", i), eng.or_into)
+        comm.or_allreduce(eng.view("km_back"), eng.or_into)
+        for a in range(nb):
+            comm.broadcast(eng.view("cells", a), own[a])
+    eng.complete(rest_km_all, rest_cnt_all, st)
+    return {"n_km": n_km, "blocks": n_blocks, "bytes_sent": comm.bytes_sent - sent0, "arrays_owned": [a for a in range(nb) if own[a] == rank]}
+
+
+def query_replicas(model, comm: Comm, queries: torch.Tensor, k: int) -> torch.Tensor:
+    """Batched kmer_to_occ (kmodel.hpp:90-98) against ONE model replicated on every rank: each rank answers its slice of
+    the batch (the reference splits the vector over OpenMP threads the same way), the answers are gathered in batch order."""
+    W = (k + 31) // 32
+    n = queries.numel() // W
+    lo, hi = split_batch(n, comm.world, comm.rank)
+    out = torch.empty(hi - lo, dtype=torch.int32, device=queries.device)
+    if hi > lo:
+        q = queries.reshape(n, W)[lo:hi].contiguous()
+        model.kmer_to_occ_dev(q.data_ptr(), hi - lo, out.data_ptr())
+    return gather_slices(out, n, comm.world, comm.rank, comm)

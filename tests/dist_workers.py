@@ -1,0 +1,139 @@
+"""Worker processes of the multi-rank tests (spawned, one per rank): a GPU worker that runs the product
+(kmcex_amd.dist over libkmx.so, several ranks sharing cuda:0, exchange over gloo = the rehearsal transport) and a CPU
+worker that drives the SAME orchestration with an engine made of the oracle (tests/oracle_engine.py)."""
+import os
+import socket
+import sys
+import tempfile
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def listing_of(spec):
+    """(k, ci, cs, nh, nb, kmers, counts, kmers the golden query set is drawn from); kmers / counts in LISTING order; spec =
+    ("synth", name) | ("kmc2", name) | ("genome", name) | ("raw", k, ci, cs, nh, nb, n, seed_k, seed_c, min_count)"""
+    from common import CASE, GENOME_CASES, KMC2_CASES
+    from kmcex_amd import api, kmcdb, synth
+    kind = spec[0]
+    if kind == "synth":
+        _, k, ci, cs, nh, nb, n = CASE[spec[1]]
+        km, cnt = synth.make_stream(n, k, ci, cs)
+        base = km
+    elif kind == "kmc2":
+        name, k, ci, cs, nh, nb, n, n_bins = [c for c in KMC2_CASES if c[0] == spec[1]][0]
+        km, cnt = synth.make_stream(n, k, ci, cs)
+        base = km
+        with tempfile.TemporaryDirectory(prefix="kmx_dist_") as tmp:           # the database lists bin-major: not sorted
+            kmcdb.write_kmc2(os.path.join(tmp, "db"), km, cnt, k, ci, cs, n_bins=n_bins)
+            _, _, km, cnt = api.kmc_list(os.path.join(tmp, "db"))
+    elif kind == "genome":
+        name, k, ci, cs, nh, nb, n_bases = [c for c in GENOME_CASES if c[0] == spec[1]][0]
+        km, cnt = synth.genome_stream(n_bases, k, ci, cs)
+        base = km
+    else:
+        _, k, ci, cs, nh, nb, n, seed_k, seed_c, min_count = spec
+        km, cnt = synth.make_stream(n, k, ci, cs, seed_k=seed_k, seed_c=seed_c)
+        cnt = np.maximum(cnt, min_count).astype(np.uint32)
+        base = km
+    return k, ci, cs, nh, nb, km, cnt, base
+
+
+def queries_of(spec, km, k):
+    from common import genome_query_set, query_set
+    return genome_query_set(km, k) if spec[0] == "genome" else query_set(km, k)
+
+
+def _to_torch(km, cnt, k, device):
+    import torch
+    W = (k + 31) // 32
+    tk = torch.from_numpy(np.ascontiguousarray(km, dtype=np.uint64).view(np.int64).reshape(-1, W) if W > 1 else np.ascontiguousarray(km, dtype=np.uint64).view(np.int64))
+    tc = torch.from_numpy(np.ascontiguousarray(cnt, dtype=np.uint32).view(np.int32))
+    return tk.to(device), tc.to(device)
+
+
+def gpu_worker(rank, world, port, spec, out_dir, q, load_dir=None):
+    """One rank of a single-model build (or, with load_dir, of a replica query) sharing cuda:0 with the others."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        import torch
+        import torch.distributed as dist
+        from common import sha_file, sha_occ
+        from kmcex_amd import KModel
+        from kmcex_amd import dist as kd
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm = kd.Comm()
+        res = {"rank": rank}
+        if load_dir is not None:                                    # replica query of a model directory (every rank loads it)
+            from kmcex_amd import synth
+            m = KModel.load(load_dir)
+            qs = open(os.path.join(load_dir, "queries.txt")).read().split()
+            qk = synth.from_strings(qs, 31).reshape(-1)
+            tq = torch.from_numpy(qk.view(np.int64)).to(dev)
+            occ = kd.query_replicas(m, comm, tq, 31).cpu().numpy()
+            res["occ"] = occ.tolist()
+        else:
+            k, ci, cs, nh, nb, km, cnt, base = listing_of(spec)
+            lo, hi = kd.split_batch(len(cnt), world, rank)          # this rank lists a contiguous slice of the database
+            tk, tc = _to_torch(km[lo:hi], cnt[lo:hi], k, dev)
+            m = KModel(ci, cs, nh, nb)
+            eng = kd.DeviceEngine(m, dev)
+            info = kd.build_sharded(eng, comm, k, nb, 1 if ci == 1 else 3, tk, tc)
+            st = m.stats()
+            res.update(info=info, stats=(st.n_km, list(st.n_bf), st.attempts, st.successes, st.rest_entries, st.blocks, st.rounds))
+            qk = queries_of(spec, base, k)
+            tq = torch.from_numpy(np.ascontiguousarray(qk, dtype=np.uint64).view(np.int64).reshape(-1)).to(dev)
+            occ = kd.query_replicas(m, comm, tq, k).cpu().numpy()
+            res["occ_sha"] = sha_occ(occ)
+            d = os.path.join(out_dir, f"rank{rank}")                # EVERY rank saves: each must hold the whole model
+            os.makedirs(d, exist_ok=True)
+            m.save(d)
+            res["sha"] = {f: sha_file(os.path.join(d, f)) for f in ("header", "km.bin", "rest.bin")}
+        m.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put(res)
+    except Exception:  # noqa: BLE001
+        q.put({"rank": rank, "error": traceback.format_exc()})
+
+
+def run_ranks(target, world, *args, timeout=600):
+    """spawn `world` ranks of `target(rank, world, port, *args, q)`; returns their result dicts in rank order"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    ps = [ctx.Process(target=target, args=(r, world, port) + tuple(args[:2]) + (q,) + tuple(args[2:])) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=timeout))
+            if "error" in res[-1]:                                  # the others would wait for it in a collective
+                break
+    finally:
+        failed = any("error" in r for r in res) or len(res) < world
+        for p in ps:
+            p.join(timeout=1 if failed else 60)
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=10)
+    res.sort(key=lambda r: r["rank"])
+    for r in res:
+        assert "error" not in r, r["error"]
+    return res

@@ -1,0 +1,53 @@
+"""ONE model built and queried by several ranks: kmcex_amd.dist over libkmx.so, the ranks sharing cuda:0
+and exchanging over gloo (the rehearsal transport: RCCL refuses two ranks on one device; on a multi-GPU node the same
+orchestration runs over "nccl").  The bar is the single-GPU bar: the files EVERY rank saves are the reference's files,
+the statistics are the sequential ones, the replica query gives the golden answers."""
+import os
+
+import numpy as np
+import pytest
+
+from dist_workers import gpu_worker, run_ranks
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _golden_of(golden, spec):
+    sect = {"synth": "cases", "kmc2": "kmc2_cases", "genome": "genome_cases"}[spec[0]]
+    return golden[sect][spec[1]]
+
+
+# world sizes: 2 (uneven runs of arrays), nb (one array per rank) or the most ranks the box lets share a GPU (5 + pytest)
+@pytest.mark.parametrize("spec,world", [
+    (("synth", "tiny_k31"), 2),
+    (("synth", "k31_multiblock_ci1"), 2),          # 2 full blocks + a partial block with unused rows: quirk Q1 across ranks
+    (("synth", "k31_multiblock_ci1"), 5),          # nb ranks: the reference's rotation, one array per GPU
+    (("synth", "k55_multiblock"), 2),              # two-word k-mers, nh 9, nb 6
+    (("synth", "k55_multiblock"), 5),              # 6 arrays on 5 ranks
+    (("kmc2", "k31_kmc2_6bins"), 2),               # bin-major (unsorted) listing order
+    (("kmc2", "k31_kmc2_6bins"), 3),
+    (("synth", "k31_multiblock_ci2"), 4),          # three Bloom classes merged by OR
+    (("synth", "k27_ci3_nb8"), 3),                 # 8 arrays on 3 ranks, a single partial block
+    (("synth", "k31_nh3_nb1"), 2),                 # one array: rank 1 only lists and classifies
+    (("genome", "genome_k31_ci1"), 3),
+], ids=lambda v: v[1] if isinstance(v, tuple) else f"w{v}")
+def test_single_model_over_ranks_is_bit_exact(spec, world, golden, tmp_path):
+    g = _golden_of(golden, spec)
+    res = run_ranks(gpu_worker, world, spec, str(tmp_path))
+    for r in res:
+        assert r["sha"] == {f: g["sha256"][f] for f in ("header", "km.bin", "rest.bin")}, f"rank {r['rank']} holds a different model"
+        assert r["occ_sha"] == g["occ_sha256"]
+        if "stats" in g:
+            assert r["stats"][2:5] == (g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
+    owned = sorted(a for r in res for a in r["info"]["arrays_owned"])
+    assert owned == list(range(len(owned)))                        # every array has exactly one owner
+
+
+def test_replica_query_of_reference_files():
+    """2 ranks load the model the REFERENCE wrote (tests/golden/tiny) and answer the batch by slices."""
+    d = os.path.join(ROOT, "tests", "golden", "tiny")
+    exp = np.loadtxt(os.path.join(d, "occ.txt"), dtype=np.int32).tolist()
+    res = run_ranks(gpu_worker, 2, None, None, d)
+    for r in res:
+        assert r["occ"] == exp
