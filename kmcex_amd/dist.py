@@ -291,6 +291,9 @@ class DeviceEngine:
         p, nbytes = self.m.dev_view(which, index)
         return dev_tensor(p, nbytes // 4, torch.int32, self.device)
 
+    def array_views(self, a):
+        return [self.view("cells", a)]                              # value and tag bits interleaved: one tensor per array
+
     def or_into(self, dst, src):
         self.m.or_words_dev(dst.data_ptr(), src.data_ptr(), dst.numel())
 
@@ -382,7 +385,8 @@ def build_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: torch.Te
             comm.or_allreduce(eng.view("bf_back", i), eng.or_into)
         comm.or_allreduce(eng.view("km_back"), eng.or_into)
         for a in range(nb):
-            comm.broadcast(eng.view("cells", a), own[a])
+            for v in eng.array_views(a):
+                comm.broadcast(v, own[a])
     eng.complete(rest_km_all, rest_cnt_all, st)
     return {"n_km": n_km, "blocks": n_blocks, "bytes_sent": comm.bytes_sent - sent0, "arrays_owned": [a for a in range(nb) if own[a] == rank]}
 

@@ -435,6 +435,89 @@ int kmo_build(kmo_model *m, int k, const uint64_t *kmers, const uint32_t *counts
 	return 0;
 }
 
+/* ---- the same model in per-rank pieces: what kmcex_amd/dist.py exchanges between GPUs, restated on the CPU so that the
+ * N>1 protocol (routing, ring of arrays, OR-merge) can be checked against the sequential build without a GPU.
+ * Test infrastructure like everything else in this file. ---- */
+int kmo_shard_begin(kmo_model *m, int k, const uint64_t n_bf[3], uint64_t total_kmers)
+{
+	if (!m || k < 3 || k > 64) return -1;
+	m->k = k;
+	for (int i = 0; i < 3; i++) m->n_bf[i] = i < m->bf_num ? n_bf[i] : 0;
+	m->total = total_kmers;
+	init_bf_parameter(m);                                   /* kmodel.hpp:402-420 */
+	uint64_t nbf = 0;
+	for (int i = 0; i < m->bf_num; i++) nbf += m->n_bf[i];
+	m->n_km = m->total - nbf;                               /* kmodel.hpp:433 */
+	init_km_parameter(m);                                   /* kmodel.hpp:436-456 */
+	m->attempts = m->successes = 0;
+	return 0;
+}
+
+/* pass 2 front end on a slice of the listing (kmodel.hpp:70-73): Bloom classes into this model's (partial) filters,
+ * the others compacted in order; returns how many were compacted, (uint64_t)-1 on a count outside [ci, cs] */
+uint64_t kmo_shard_classify(kmo_model *m, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint64_t *out_kmers, uint32_t *out_counts)
+{
+	int k = m->k, W = (k + 31) / 32;
+	char s[MAXLEN];
+	uint64_t o = 0;
+	for (uint64_t i = 0; i < n; i++) {
+		const uint64_t *w = kmers + i * (uint64_t)W;
+		uint32_t c = counts[i];
+		if (c < (uint32_t)m->ci || c > (uint32_t)m->cs) return (uint64_t)-1;
+		if (c < (uint32_t)(m->ci + m->bf_num)) {
+			int f = (int)(c - (uint32_t)m->ci);
+			kmo_packed_to_ascii(w, k, s);
+			bloom_insert(s, k, m->bf[f], m->len_bf[f], m->nh - 1);
+			bloom_insert(s + 1, k - 2, m->bf_back[f], m->len_bf_back[f], m->nh - 2);
+		} else {
+			for (int q = 0; q < W; q++) out_kmers[o * (uint64_t)W + q] = w[q];
+			out_counts[o++] = c;
+		}
+	}
+	return o;
+}
+
+/* insert_array(buff, a, n) (kmodel.hpp:543-555) on a list handed over as plain arrays: survivors come back in the order
+ * reorder_buffer leaves them; returns their number (n must be >= 1: the n == 0 case reads a stale slot, quirk Q2) */
+int kmo_ring_insert(kmo_model *m, int a, const uint64_t *kmers, const uint32_t *counts, int n, uint64_t *out_kmers, uint32_t *out_counts)
+{
+	int W = (m->k + 31) / 32;
+	if (n < 1 || n > (int)BUCKET || a < 0 || a >= m->nb || m->km_bit_size == 0) return -1;
+	kbuf_t *buf = (kbuf_t *)calloc((size_t)n, sizeof(kbuf_t));
+	for (int c = 0; c < n; c++) {
+		const uint64_t *w = kmers + (uint64_t)c * (uint64_t)W;
+		buf[c].w[0] = W == 2 ? w[0] : 0; buf[c].w[1] = W == 2 ? w[1] : w[0]; buf[c].occ = counts[c];
+	}
+	uint64_t att = 0, suc = 0;
+	int left = n;
+	insert_array(m, buf, a, &left, &att, &suc);
+	m->attempts += att; m->successes += suc;
+	for (int c = 0; c < left; c++) {
+		if (W == 2) { out_kmers[2 * c] = buf[c].w[0]; out_kmers[2 * c + 1] = buf[c].w[1]; }
+		else out_kmers[c] = buf[c].w[1];
+		out_counts[c] = buf[c].occ;
+	}
+	free(buf);
+	return left;
+}
+
+/* kld->build() (rest.hpp:157-161) on the survivors of every rank + the summed statistics */
+int kmo_shard_complete(kmo_model *m, const uint64_t *kmers, const int32_t *counts, uint64_t n, uint64_t attempts, uint64_t successes)
+{
+	int W = (m->k + 31) / 32;
+	rest_vec rest = {0, 0, 0};
+	for (uint64_t e = 0; e < n; e++) {
+		kbuf_t b;
+		const uint64_t *w = kmers + e * (uint64_t)W;
+		b.w[0] = W == 2 ? w[0] : 0; b.w[1] = W == 2 ? w[1] : w[0]; b.occ = (uint32_t)counts[e];
+		rest_push(&rest, &b);
+	}
+	rest_build(m, &rest);
+	free(rest.v);
+	m->attempts = attempts; m->successes = successes;
+	return 0;
+}
+
 void kmo_get_stats(const kmo_model *m, kmo_stats *st)
 {
 	memset(st, 0, sizeof(*st));

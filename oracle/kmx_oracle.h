@@ -49,6 +49,12 @@ int        kmo_save(const kmo_model *m, const char *dir);
 kmo_model *kmo_load(const char *dir);
 void       kmo_get_stats(const kmo_model *m, kmo_stats *st);
 
+/* the same build in per-rank pieces (checks the multi-GPU protocol of kmcex_amd/dist.py on the CPU; tests only) */
+int      kmo_shard_begin(kmo_model *m, int k, const uint64_t n_bf[3], uint64_t total_kmers);
+uint64_t kmo_shard_classify(kmo_model *m, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint64_t *out_kmers, uint32_t *out_counts);
+int      kmo_ring_insert(kmo_model *m, int a, const uint64_t *kmers, const uint32_t *counts, int n, uint64_t *out_kmers, uint32_t *out_counts);
+int      kmo_shard_complete(kmo_model *m, const uint64_t *kmers, const int32_t *counts, uint64_t n, uint64_t attempts, uint64_t successes);
+
 /* query (kmodel.hpp:90-116).  strs: n records of `stride` bytes, each holding `len` chars. */
 int kmo_query_ascii(const kmo_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out, int threads);
 int kmo_query_packed(const kmo_model *m, int k, const uint64_t *kmers, uint64_t n, int32_t *out, int threads);

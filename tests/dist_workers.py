@@ -111,6 +111,39 @@ def gpu_worker(rank, world, port, spec, out_dir, q, load_dir=None):
         q.put({"rank": rank, "error": traceback.format_exc()})
 
 
+def cpu_worker(rank, world, port, spec, out_dir, q):
+    """One rank of the same orchestration (kmcex_amd.dist.build_sharded) over gloo with the ORACLE as the per-rank engine:
+    checks the protocol -- routing all-to-all, ring of arrays, OR-merge, survivor gather -- without a GPU."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        import torch
+        import torch.distributed as dist
+        torch.set_num_threads(1)
+        os.environ["OMP_NUM_THREADS"] = "1"
+        from common import sha_file, sha_occ
+        from kmcex_amd import dist as kd
+        from oracle_engine import OracleEngine
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm = kd.Comm()
+        k, ci, cs, nh, nb, km, cnt, base = listing_of(spec)
+        lo, hi = kd.split_batch(len(cnt), world, rank)
+        tk, tc = _to_torch(km[lo:hi], cnt[lo:hi], k, "cpu")
+        eng = OracleEngine(ci, cs, nh, nb)
+        info = kd.build_sharded(eng, comm, k, nb, eng.bf_num, tk, tc)
+        so = eng.o.stats()
+        res = {"rank": rank, "info": info, "stats": (so.n_km, list(so.n_bf), so.attempts, so.successes, so.rest_entries)}
+        d = os.path.join(out_dir, f"rank{rank}")
+        eng.o.save(d)
+        res["sha"] = {f: sha_file(os.path.join(d, f)) for f in ("header", "km.bin", "rest.bin")}
+        if rank == 0:
+            res["occ_sha"] = sha_occ(eng.o.query_packed(k, queries_of(spec, base, k), threads=2))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put(res)
+    except Exception:  # noqa: BLE001
+        q.put({"rank": rank, "error": traceback.format_exc()})
+
+
 def run_ranks(target, world, *args, timeout=600):
     """spawn `world` ranks of `target(rank, world, port, *args, q)`; returns their result dicts in rank order"""
     import torch.multiprocessing as mp

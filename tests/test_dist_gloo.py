@@ -1,9 +1,12 @@
-"""CPU, world_size 2 over gloo: the N>1 plumbing of bench.py (per-rank seeds, batch split, timing/count reduction,
-ragged answer gather).  The data path itself has no collective (one model per rank)."""
+"""CPU, world_size 2-3 over gloo: (i) the N>1 plumbing of bench.py (per-rank seeds, batch split, timing/count reduction,
+ragged answer gather); (ii) the single-model protocol of kmcex_amd.dist -- routing all-to-all, ring of arrays, OR-merge of
+partial filters, survivor gather -- run for real over gloo with the CPU oracle as the per-rank engine and compared with the
+reference's files (the GPU engine goes through the same orchestration in tests/test_gpu_dist.py)."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -66,3 +69,48 @@ def test_split_batch_covers_everything_once():
             sizes = [hi - lo for lo, hi in cuts]
             assert max(sizes) - min(sizes) <= 1
     assert kd.stream_seeds(0) == (1, 2)
+
+
+def test_routing_plan_partitions_the_stream():
+    """every element of the coupled-array stream is sent exactly once, to the owner of the array its buffer meets first,
+    and arrives in ascending stream position"""
+    rng = np.random.default_rng(5)
+    B = kd.BUCKET
+    for world, nb in ((1, 5), (2, 5), (3, 8), (5, 5), (5, 6), (8, 5), (4, 1)):
+        counts = [int(x) for x in rng.integers(0, 5 * B, size=world)]
+        counts[rng.integers(0, world)] = 0                                 # a rank whose slice holds no coupled-array k-mer
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        plans = [kd.plan_routing(counts, nb, world, r) for r in range(world)]
+        for r, (slices, send, recv) in enumerate(plans):
+            assert sum(send) == counts[r] and sum(hi - lo for lo, hi in slices) == counts[r]
+            assert [plans[d][2][r] for d in range(world)] == send              # what r sends to d is what d expects from r
+            pos = 0
+            for d in range(world):                                              # the slices of destination d, in order
+                got = 0
+                while got < send[d]:
+                    lo, hi = slices[pos]
+                    g = np.arange(lo, hi) + offs[r]
+                    assert (np.array([kd.owner_of_array(int(a), nb, world) for a in np.unique((g // B) % nb)]) == d).all()
+                    got += hi - lo
+                    pos += 1
+                assert got == send[d]
+        n_km = int(offs[-1])
+        total = sum(kd.list_length(n_km, nb, b, i) for b in range(-(-n_km // (nb * B))) for i in range(nb))
+        assert total == n_km
+
+
+@pytest.mark.parametrize("spec,world", [
+    (("synth", "tiny_k31"), 2),
+    (("synth", "k31_ci2_200k"), 3),                # three Bloom classes, one partial block
+    (("synth", "k55_nh9_nb6"), 2),                 # two-word k-mers, 6 arrays on 2 ranks
+    (("synth", "k31_multiblock_ci1"), 2),          # 2 full blocks + partial block with unused rows: quirk Q1 across ranks
+    (("kmc2", "k31_kmc2_6bins"), 3),               # unsorted listing order
+], ids=lambda v: v[1] if isinstance(v, tuple) else f"w{v}")
+def test_single_model_protocol_with_oracle_engine(spec, world, golden, tmp_path):
+    from dist_workers import cpu_worker, run_ranks
+    g = golden[{"synth": "cases", "kmc2": "kmc2_cases"}[spec[0]]][spec[1]]
+    res = run_ranks(cpu_worker, world, spec, str(tmp_path), timeout=900)
+    for r in res:
+        assert r["sha"] == {f: g["sha256"][f] for f in ("header", "km.bin", "rest.bin")}, f"rank {r['rank']} holds a different model"
+        assert r["stats"][2:5] == (g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
+    assert res[0]["occ_sha"] == g["occ_sha256"]
