@@ -11,8 +11,11 @@ are timed in a second, separately bracketed region.  `value` is the insert rate 
 whole job); the query rate is reported beside it.
 
 Workload at N=1: BASELINE.json configs[1] -- synthetic 100 M distinct canonical 31-mers, nh=7 nb=5 ci=1
-cs=1023, D1 counts.  N>1: one independent stream + model per rank (weak scaling, no
-data-path collective).
+cs=1023, D1 counts.  N>1: `value` = one independent stream + model per rank (weak scaling, no
+data-path collective); beside it `single_model` = ONE model over the concatenation of the N streams, built by the N
+ranks together (kmcex_amd/dist.py: k-mer routing all-to-all, ring of arrays over send/recv, OR-merged filters,
+replica queries; see DESIGN.md §multi-GPU).  `init_db` (N=1) times the reference's real entry point, KModel::init on a
+KMC database of the same stream in tmpfs (kmodel.hpp:57-86), host feed included.
 """
 import argparse
 import json
@@ -46,7 +49,65 @@ def parse():
     ap.add_argument("--nb", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="k-mers of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-init-db", action="store_true", help="skip the KModel::init(database) leg")
+    ap.add_argument("--no-single-model", action="store_true", help="skip the one-model-over-all-ranks leg")
+    ap.add_argument("--single-model-steps", type=int, default=2)
     return ap.parse_args()
+
+
+def write_kmc1_from_device(prefix, km, cnt, k, ci, cs):
+    """The listing as a KMC1 database -- records packed on the GPU, written once.  Plumbing."""
+    import struct
+    from kmcex_amd import kmcdb
+    p = kmcdb.lut_prefix_len(k)
+    sb = (k - p) // 4                                             # suffix bytes per record
+    csz = 1
+    while cs >= (1 << (8 * csz)):
+        csz += 1
+    n = km.numel()
+    with open(prefix + ".kmc_suf", "wb") as f:
+        f.write(b"KMCS")
+        step = 1 << 25
+        for lo in range(0, n, step):
+            x, c = km[lo:lo + step], cnt[lo:lo + step].to(torch.int64)
+            cols = [((x >> (8 * (sb - 1 - j))) & 0xFF).to(torch.uint8) for j in range(sb)] + [((c >> (8 * b)) & 0xFF).to(torch.uint8) for b in range(csz)]
+            f.write(torch.stack(cols, dim=1).cpu().numpy().tobytes())
+        f.write(b"KMCS")
+    pre = km >> (2 * (k - p))
+    lut = torch.searchsorted(pre, torch.arange(4 ** p, dtype=torch.int64, device=km.device), right=False).cpu().numpy().astype(np.uint64)
+    hdr = struct.pack("<IIIIIIQB3xI", k, 0, csz, p, ci, cs & 0xFFFFFFFF, n, 0, cs >> 32)
+    hdr = hdr + b"\0" * (64 - len(hdr))
+    with open(prefix + ".kmc_pre", "wb") as f:
+        f.write(b"KMCP")
+        f.write(lut.tobytes())
+        f.write(hdr)
+        f.write(struct.pack("<I", 64))
+        f.write(b"KMCP")
+
+
+def init_db_leg(a, km, cnt, reps=3):
+    """KModel::init(db_file) end to end (kmodel.hpp:57-86): listing decode on the host cores, pinned H2D, insert, rest build."""
+    import shutil
+    from kmcex_amd import KModel
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="kmx_bench_db_", dir=base)
+    try:
+        db = os.path.join(tmp, "db")
+        write_kmc1_from_device(db, km, cnt, a.k, a.ci, a.cs)
+        m = KModel(a.ci, a.cs, a.nh, a.nb)
+        ts = []
+        for _ in range(reps + 1):                                 # first call allocates: warm-up
+            t0 = time.perf_counter()
+            m.init(db)
+            ts.append(time.perf_counter() - t0)
+        st = m.stats()
+        m.close()
+        best, mean = min(ts[1:]), sum(ts[1:]) / reps
+        return {"init_db_value": km.numel() / mean, "init_db_ms": mean * 1e3, "init_db_best_ms": best * 1e3, "init_db_reps": reps,
+                "init_db_what": "KModel::init(database in tmpfs): KMC listing decode + pinned hipMemcpyAsync + insert + rest build, wall clock",
+                "init_db_attempts": st.attempts, "init_db_bytes": os.path.getsize(db + ".kmc_suf")}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def sync_all(distributed):
@@ -89,6 +150,58 @@ def cpu_baseline(a):
     out["query_value"] = len(q) / t_q
     out["host_cpus"] = ncpu
     return out
+
+
+def headline(a, world, n, q, n_all, nq_all, t_ins, t_q, st, roof, cpu, extra, init_db):
+    line = {
+        "metric": "k-mers/s encoded (insert) + k-mers/s queried, k=31 nh=7; % HBM-BW roofline",
+        "value_is": "k-mers/s encoded (insert); the query rate is query_value",
+        "value": n_all * a.steps / t_ins, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": t_ins / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"synthetic {n} distinct canonical {a.k}-mers per GPU, D1 counts, insert then query "
+                               f"({q.numel()} queries: all inserted k-mers shuffled, half reverse-complemented, +10% absent)",
+                   "k": a.k, "nh": a.nh, "nb": a.nb, "ci": a.ci, "cs": a.cs, "kmers_per_gpu": n,
+                   "parallelism": f"{world} independent model(s), one per GPU (value); one model over all ranks in single_model"},
+        "query_value": nq_all * a.steps / t_q, "query_ms_per_step": t_q / a.steps * 1e3,
+        "stats": {"n_km": st.n_km, "n_bf": list(st.n_bf)[: st.bf_num], "attempts": st.attempts, "successes": st.successes,
+                  "rest_entries": st.rest_entries, "fast_commits": st.fast_commits, "contended": st.contended,
+                  "finisher_iters": st.finisher_iters, "blocks": st.blocks, "rounds": st.rounds},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    line.update(extra)
+    line.update(init_db)
+    return line
+
+
+def single_model_leg(a, m, km, cnt, q, out, rank, world, dev, rehearsal, distributed):
+    """ONE model over the concatenation of all ranks' streams (rank order = listing order), built by the ranks together
+    and queried over replicas.  Weak scaling: world * kmers_per_gpu k-mers in one model."""
+    from kmcex_amd import dist as kd
+    comm = kd.Comm()
+    eng = kd.DeviceEngine(m, dev)
+    bf_num = 1 if a.ci == 1 else 3
+    info = kd.build_sharded(eng, comm, a.k, a.nb, bf_num, km, cnt)                      # warm-up (allocations)
+    sync_all(distributed)
+    t0 = time.perf_counter()
+    for _ in range(a.single_model_steps):
+        info = kd.build_sharded(eng, comm, a.k, a.nb, bf_num, km, cnt)
+    sync_all(distributed)
+    t_b = time.perf_counter() - t0
+    st = m.stats()
+    # the batch = every rank's query set; each rank answers its own slice against its replica (no collective on the data path)
+    t0 = time.perf_counter()
+    for _ in range(a.single_model_steps):
+        m.kmer_to_occ_dev(q.data_ptr(), q.numel(), out.data_ptr())
+    sync_all(distributed)
+    t_qq = time.perf_counter() - t0
+    (t_b, t_qq), (n_all, nq_all, sent) = kd.reduce_job([t_b, t_qq], [km.numel(), q.numel(), info["bytes_sent"]], device="cpu" if rehearsal else dev)
+    return {"what": "ONE model over all ranks' streams: routing all-to-all + ring of arrays (send/recv) + OR-merged filters + array broadcast; queries over replicas",
+            "transport": "gloo, ranks sharing one GPU (rehearsal: rates are not xGMI rates)" if rehearsal else ("nccl (RCCL)" if world > 1 else "none (one rank)"),
+            "value": n_all * a.single_model_steps / t_b, "unit": "k-mers/s", "ms_per_build": t_b / a.single_model_steps * 1e3, "kmers": n_all,
+            "query_value": nq_all * a.single_model_steps / t_qq, "steps": a.single_model_steps, "scaling": "weak",
+            "bytes_exchanged_per_build": sent, "blocks": info["blocks"],
+            "stats": {"n_km": st.n_km, "attempts": st.attempts, "successes": st.successes, "rest_entries": st.rest_entries}}
 
 
 def main():
@@ -225,6 +338,37 @@ def main():
                                            "atomic_or_Gtouch_s": (1 << 27) / ta / 1e9,
                                            "gather_GBps_at_32B": (1 << 27) * G / tg / 1e9,
                                            "atomic_GBps_at_32B": (1 << 27) * G / ta / 1e9}}
+    init_db = {}
+    if rank == 0 and world == 1 and not a.no_init_db and a.k <= 31:
+        try:
+            init_db = init_db_leg(a, km, cnt)
+        except Exception as e:  # noqa: BLE001
+            init_db = {"init_db_error": repr(e)}
+    # ---- ONE model over all ranks' streams; a watchdog ends the job with what is measured if the exchange hangs
+    single = None
+    if not a.no_single_model:
+        import threading
+        done = threading.Event()
+
+        def give_up():
+            if done.is_set():
+                return
+            if rank == 0:
+                partial["single_model"] = {"error": "no result after 300 s: exchange presumed hung"}
+                print(json.dumps(partial), flush=True)
+            os._exit(0)
+        partial = {}
+        if rank == 0:
+            partial = headline(a, world, n, q, n_all, nq_all, t_ins, t_q, st, roof, None, extra, init_db)
+        wd = threading.Timer(300.0, give_up)
+        wd.daemon = True
+        wd.start()
+        try:
+            single = single_model_leg(a, m, km, cnt, q, out, rank, world, dev, rehearsal, distributed)
+        except Exception as e:  # noqa: BLE001
+            single = {"error": repr(e)}
+        done.set()
+        wd.cancel()
     cpu = None
     if rank == 0 and world == 1 and a.cpu_sample > 0:
         try:
@@ -232,23 +376,8 @@ def main():
         except Exception as e:  # noqa: BLE001
             cpu = {"error": repr(e)}
     if rank == 0:
-        line = {
-            "metric": "k-mers/s encoded (insert) + k-mers/s queried, k=31 nh=7; % HBM-BW roofline",
-            "value_is": "k-mers/s encoded (insert); the query rate is query_value",
-            "value": n_all * a.steps / t_ins, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": t_ins / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"synthetic {n} distinct canonical {a.k}-mers per GPU, D1 counts, insert then query "
-                                   f"({q.numel()} queries: all inserted k-mers shuffled, half reverse-complemented, +10% absent)",
-                       "k": a.k, "nh": a.nh, "nb": a.nb, "ci": a.ci, "cs": a.cs, "kmers_per_gpu": n,
-                       "parallelism": f"{world} independent model(s), one per GPU"},
-            "query_value": nq_all * a.steps / t_q, "query_ms_per_step": t_q / a.steps * 1e3,
-            "stats": {"n_km": st.n_km, "n_bf": list(st.n_bf)[: st.bf_num], "attempts": st.attempts, "successes": st.successes,
-                      "rest_entries": st.rest_entries, "fast_commits": st.fast_commits, "contended": st.contended,
-                      "finisher_iters": st.finisher_iters, "blocks": st.blocks, "rounds": st.rounds},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-        line.update(extra)
+        line = headline(a, world, n, q, n_all, nq_all, t_ins, t_q, st, roof, cpu, extra, init_db)
+        line["single_model"] = single
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()                      # rank 0 may still have been in its roofline leg: leave together

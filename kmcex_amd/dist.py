@@ -128,8 +128,9 @@ class Comm:
     tensors directly; with "gloo" (CPU tests, rehearsal of N ranks on one GPU) device tensors are staged through the host.
     """
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, shortcut=True):
         self.group = group
+        self.shortcut = shortcut                            # False: a single rank still goes through the backend (tests of the RCCL path)
         self.on = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if self.on else 0
         self.world = dist.get_world_size(group) if self.on else 1
@@ -140,14 +141,14 @@ class Comm:
         return t.cpu() if (self.staged and t.is_cuda) else t
 
     def all_reduce_ints(self, values, device, op=None):
-        if self.world == 1:
+        if self.world == 1 and self.shortcut:
             return [int(v) for v in values]
         t = torch.tensor([int(v) for v in values], dtype=torch.int64, device="cpu" if self.staged else device)
         dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=self.group)
         return [int(v) for v in t.tolist()]
 
     def all_gather_ints(self, value: int, device):
-        if self.world == 1:
+        if self.world == 1 and self.shortcut:
             return [int(value)]
         t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if self.staged else device)
         out = torch.empty(self.world, dtype=torch.int64, device=t.device)
@@ -156,7 +157,7 @@ class Comm:
 
     def all_to_all_v(self, send: torch.Tensor, send_splits, recv_splits) -> torch.Tensor:
         """rows of `send` grouped by destination -> rows received, grouped by source"""
-        if self.world == 1:
+        if self.world == 1 and self.shortcut:
             return send
         n_recv = int(sum(recv_splits))
         w = self._wire(send.contiguous())
@@ -180,7 +181,7 @@ class Comm:
         self.bytes_sent += sum(t.numel() * t.element_size() for t, _ in sends)
 
     def broadcast(self, t: torch.Tensor, src: int):
-        if self.world == 1:
+        if self.world == 1 and self.shortcut:
             return
         if self.staged and t.is_cuda:
             h = t.cpu()
@@ -194,7 +195,7 @@ class Comm:
 
     def all_gather_v(self, local: torch.Tensor, counts) -> torch.Tensor:
         """ragged all-gather of rows: rank q contributes counts[q] rows; result in rank order"""
-        if self.world == 1:
+        if self.world == 1 and self.shortcut:
             return local
         width = int(max(counts))
         pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -210,7 +211,7 @@ class Comm:
         """Bitwise OR of `words` (int32, same length on every rank) over the ranks, in place, by position range: an
         all-to-all brings range r of every rank's partial filter to rank r, `or_into(dst, src)` merges them there, an
         all-gather hands every rank the merged filter (RCCL has no OR reduction)."""
-        if self.world == 1 or words.numel() == 0:
+        if (self.world == 1 and self.shortcut) or words.numel() == 0:
             return
         P, n = self.world, words.numel()
         chunk = -(-n // P)

@@ -144,6 +144,45 @@ def cpu_worker(rank, world, port, spec, out_dir, q):
         q.put({"rank": rank, "error": traceback.format_exc()})
 
 
+def rccl_worker(rank, world, port, spec, out_dir, q):
+    """The collectives of kmcex_amd.dist.Comm through the REAL backend of a multi-GPU node ("nccl" = RCCL) with the one
+    rank a one-GPU box allows: dtypes, ragged splits and in-place semantics of every call the sharded build makes."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        import torch
+        import torch.distributed as dist
+        from kmcex_amd import KModel
+        from kmcex_amd import dist as kd
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        comm = kd.Comm(shortcut=False)
+        assert not comm.staged
+        g = torch.Generator(device="cpu").manual_seed(3)
+        km = torch.randint(-2**62, 2**62, (1000, 2), dtype=torch.int64, generator=g).to(dev)
+        cn = torch.randint(0, 1000, (1000,), dtype=torch.int32, generator=g).to(dev)
+        assert comm.all_reduce_ints([3, 4, 5], dev) == [3, 4, 5]
+        assert comm.all_gather_ints(7, dev) == [7]
+        assert torch.equal(comm.all_to_all_v(km, [1000], [1000]), km)
+        assert torch.equal(comm.all_to_all_v(cn[:0], [0], [0]), cn[:0])
+        assert torch.equal(comm.all_gather_v(km[:17], [17]), km[:17])
+        assert torch.equal(comm.all_gather_v(cn[:0], [0]), cn[:0])
+        b = cn.clone()
+        comm.broadcast(b, 0)
+        assert torch.equal(b, cn)
+        m = KModel(1, 1023, 7, 5)
+        eng = kd.DeviceEngine(m, dev)
+        w = cn[:999].clone()                                        # odd length: exercises the padding of the range split
+        comm.or_allreduce(w, eng.or_into)
+        assert torch.equal(w, cn[:999])
+        m.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put({"rank": rank, "ok": True})
+    except Exception:  # noqa: BLE001
+        q.put({"rank": rank, "error": traceback.format_exc()})
+
+
 def run_ranks(target, world, *args, timeout=600):
     """spawn `world` ranks of `target(rank, world, port, *args, q)`; returns their result dicts in rank order"""
     import torch.multiprocessing as mp

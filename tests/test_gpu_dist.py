@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from dist_workers import gpu_worker, run_ranks
+from dist_workers import gpu_worker, rccl_worker, run_ranks
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -51,3 +51,9 @@ def test_replica_query_of_reference_files():
     res = run_ranks(gpu_worker, 2, None, None, d)
     for r in res:
         assert r["occ"] == exp
+
+
+def test_collectives_through_rccl():
+    """every torch.distributed call of the sharded build, on the "nccl" (RCCL) backend with the single rank this box has"""
+    res = run_ranks(rccl_worker, 1, None, None, timeout=300)
+    assert res[0]["ok"]
