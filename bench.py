@@ -291,13 +291,13 @@ def main():
         A, S, nbf = st.attempts, st.successes, sum(st.n_bf)
         W8 = 8 * ((a.k + 31) // 32) + 4
         alg = {  # algorithmic bytes of ONE step per kernel class (SURVEY.md §8d formula, split by kernel)
-            "check_claim": G * A * a.nh + A * W8,
-            "verify_commit": G * (S * a.nh + 2 * S * (a.nh - 2)),
+            "check": G * A * a.nh + A * W8,                              # reads: every attempt looks at its nh positions
+            "commit": G * (S * a.nh + 2 * S * (a.nh - 2)),              # write-backs + km_back read-modify-write
             "classify": G * 2 * nbf * ((a.nh - 1) + (a.nh - 2)) + n * W8,
         }
         per_q = G * (a.nb * a.nh + (a.nh - 2) + 2 + 6) + W8      # §8d: ~48 touches per query
         alg["query"] = q.numel() * per_q
-        total_insert_alg = alg["check_claim"] + alg["verify_commit"] + alg["classify"]
+        total_insert_alg = alg["check"] + alg["commit"] + alg["classify"]
         classes = {}
         for name, v in kt.items():
             if v["launches"]:
@@ -313,7 +313,7 @@ def main():
         # runs of this same command, tools/pmc_summary.py); only valid for the default workload they were taken on
         traffic, traffic_src = None, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic_default_workload.json")
-        kname = {"check_claim": "k_round_check_claim", "verify_commit": "k_round_verify_commit", "classify": "k_classify_count"}.get(dom)
+        kname = {"check": "k_round_check_emit", "commit": "k_round_commit", "classify": "k_classify_count"}.get(dom)
         if a.n == 100_000_000 and (a.k, a.nh, a.nb, a.ci, a.cs) == (31, 7, 5, 1, 1023) and os.path.exists(pmc_file) and kname:
             pm = json.load(open(pmc_file))
             for kn, kv in pm["kernels"].items():

@@ -160,9 +160,9 @@ int kmx_occubin(int cs, int nh, uint32_t *bin_of_occ, uint32_t *mean_of_bin);
 int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds);
 
 /* Per-kernel-class timing with HIP events recorded on the model's stream around each launch (off by default).
- * classes: 0 classify(+Bloom insert) 1 check_claim 2 verify_commit 3 ordered slow path 4 reorder 5 rest append 6 query.
- * seconds[7], launches[7] accumulate until reset.                                                          */
-#define KMX_KERNEL_CLASSES 7
+ * classes: 0 classify(+Bloom insert) 1 check (+ claim emission) 2 commit 3 ordered slow path 4 reorder 5 rest append 6 query
+ * 7 detect (opposite claims).  seconds[8], launches[8] accumulate until reset.                               */
+#define KMX_KERNEL_CLASSES 8
 int kmx_set_profile(kmx_model *m, int on);
 int kmx_get_kernel_times(kmx_model *m, double *seconds, uint64_t *launches, int reset);
 

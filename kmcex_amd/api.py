@@ -336,14 +336,14 @@ class KModel:
         _chk(self.L.kmx_download(self.h, self.DL[which], index, buf.ctypes.data, cap, C.byref(w)))
         return buf[:w.value].copy()
 
-    KERNEL_CLASSES = ["classify", "check_claim", "verify_commit", "slow_path", "reorder", "rest_append", "query"]
+    KERNEL_CLASSES = ["classify", "check", "commit", "slow_path", "reorder", "rest_append", "query", "detect"]
 
     def set_profile(self, on: bool) -> None:
         _chk(self.L.kmx_set_profile(self.h, int(on)))
 
     def kernel_times(self, reset: bool = True) -> dict:
-        sec = (C.c_double * 7)()
-        cnt = (C.c_uint64 * 7)()
+        sec = (C.c_double * 8)()
+        cnt = (C.c_uint64 * 8)()
         _chk(self.L.kmx_get_kernel_times(self.h, sec, cnt, int(reset)))
         return {n: {"seconds": sec[i], "launches": int(cnt[i])} for i, n in enumerate(self.KERNEL_CLASSES)}
 

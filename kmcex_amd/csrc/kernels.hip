@@ -139,8 +139,10 @@ __device__ __forceinline__ void commit_touches(const ModelDev &md, const Touches
 			if (!((t.cell[j] >> (16 + b)) & 1ULL))          // already tagged => already carries this value
 				atomicOr(cells + (t.pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
 		}
-	Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-	bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+	if (md.kmb_direct) {
+		Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
+		bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+	}
 }
 
 // ------------------------------------------------------------------------------------------ pass 1
@@ -303,6 +305,7 @@ __global__ __launch_bounds__(256) void k_block_init(BlockDev bd, int nb, int pp,
 {
 	int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
 	bd.list[pp][(u64)i * KMX_BUCKET + x] = (u32)x;
+	bd.surv[(u64)i * KMX_BUCKET + x] = 0;
 	if (x < KMX_NTILES) { bd.tile_cnt[0][i * KMX_NTILES + x] = 0; bd.tile_cnt[1][i * KMX_NTILES + x] = 0; }
 	if (x == 0) {
 		int lo = i * (int)KMX_BUCKET;
@@ -312,44 +315,69 @@ __global__ __launch_bounds__(256) void k_block_init(BlockDev bd, int nb, int pp,
 	}
 }
 
-// ------------------------------------------------------------------------------------------ A: check + claim
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_claim(ModelDev md, BlockDev bd, int t, int pp)
+// ------------------------------------------------------------------------------------------ A: check + emit claims
+// Claims are a partitioned stream, not atomics on the cells.  A candidate (no conflict with the committed state) emits
+// one tuple (position, wanted value, list slot) per position it saw untagged.  The tuples are hash-partitioned by position
+// into KMX_CL_BINS bins per list: inside a workgroup they are counted per bin in LDS, each run is reserved with ONE global
+// atomic per (workgroup, bin), the tuples are sorted by bin in LDS and written out run by run -- LDS-staged write combining:
+// the memory system sees 8-byte stores that fill lines instead of one memory-side atomic per claimed position.
+// k_round_detect then finds, bin by bin in an LDS table, the positions wanted with both values.
+#define CL_POS_BITS 44
+#define CL_TUPLE(pos, want, x) ((u64)(pos) | ((u64)(want) << CL_POS_BITS) | ((u64)(x) << (CL_POS_BITS + 1)))
+#define CL_POS(tp) ((tp) & ((1ULL << CL_POS_BITS) - 1))
+#define CL_WANT(tp) ((u32)((tp) >> CL_POS_BITS) & 1u)
+#define CL_X(tp) ((u32)((tp) >> (CL_POS_BITS + 1)) & (KMX_BUCKET - 1))
+__device__ __forceinline__ u64 cl_hash(u64 pos) { return pos * 0x9E3779B97F4A7C15ULL; }
+template <int NHM> __device__ __forceinline__ u32 cl_bin(u64 h) { return (u32)(h >> (64 - KMX_CL_BINS_LOG2(NHM))); }
+
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_emit(ModelDev md, BlockDev bd, int t, int pp)
 {
-	__shared__ int s_fail;
+	constexpr int NBIN = KMX_CL_BINS(NHM);
+	__shared__ int s_fail, s_tmp[4];
+	__shared__ int s_cnt[NBIN], s_off[NBIN], s_base[NBIN];
+	__shared__ u64 s_tup[256 * NHM];
 	const int i = blockIdx.y;
 	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;                                  // kmodel.hpp:563
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		if (n) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
-		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, md.nb)] = 0;   // verify_commit files this round's records
+		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, md.nb)] = 0;   // k_round_commit files this round's records
 	}
+	u64 *tup = bd.cl_tup + (u64)i * NBIN * KMX_CL_CAP;
+	int *gcnt = bd.cl_cnt + i * KMX_CL_MAXBINS;
 	// grid-stride over the list: later rounds are launched with fewer workgroups (lists shrink round by round)
 	for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
 		if (threadIdx.x == 0) s_fail = 0;
+		if (threadIdx.x < NBIN) s_cnt[threadIdx.x] = 0;
 		__syncthreads();
 		const int x = base + threadIdx.x;
 		bool failed = false;
+		u32 um = 0, bin = 0;
+		int rank[NHM];
+		Touches<NHM> tc;
 		if (x < n) {
 			const u32 raw = bd.list[pp][row + x];
 			const u32 idx = (raw & LIST_HOLE) ? bd.mover[pp][row + (raw & ~LIST_HOLE)] : raw;
 			if (raw & LIST_HOLE) bd.list[pp][row + x] = idx;            // later kernels of the round read plain entries
 			u64 v[W];
 			load_kmer<W>(bd.kmers, row + idx, v);
-			const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+			bin = md.bin_of_occ[bd.counts[row + idx]];
 			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
-			Touches<NHM> tc;
 			gather_touches<W, NHM, false>(md, pm, a, tc);
 			failed = touches_conflict<NHM>(md, tc, bin);
 			bd.status[row + x] = failed ? SLOT_FAILED : SLOT_UNDECIDED;
 			if (!failed) {
-				u64 *cells = md.cells[a];
 #pragma unroll
 				for (int j = 0; j < NHM; j++)
 					if (j < md.nh) {
-						u32 b = bit_in_cell(tc.pos[j]);
-						if (!((tc.cell[j] >> (16 + b)) & 1ULL)) atomicOr(cells + (tc.pos[j] >> 4), CELL_CLAIM((bin >> j) & 1u, b));
+						const u32 b = bit_in_cell(tc.pos[j]);
+						if (!((tc.cell[j] >> (16 + b)) & 1ULL)) {
+							um |= 1u << j;
+							rank[j] = atomicAdd(&s_cnt[cl_bin<NHM>(cl_hash(tc.pos[j]))], 1);
+						}
 					}
+				bd.um[row + x] = (unsigned short)um;
 			}
 		}
 		// survivors are counted per 1024-slot tile as they fail, so the reorder needs no counting pass
@@ -357,8 +385,92 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_c
 		if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&s_fail, (int)__popcll(mask));
 		__syncthreads();
 		if (threadIdx.x == 0 && s_fail) atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (base >> 10), s_fail);
+		// one run per bin: its offset in the LDS staging area (scan) and its place in the bin (ONE global atomic per run)
+		int total;
+		{
+			const int c = threadIdx.x < NBIN ? s_cnt[threadIdx.x] : 0;
+			const int ex = block_excl_scan_256(c, s_tmp, &total);
+			if (threadIdx.x < NBIN) {
+				s_off[threadIdx.x] = ex;
+				s_base[threadIdx.x] = c ? atomicAdd(gcnt + threadIdx.x, c) : 0;
+			}
+		}
+		__syncthreads();
+		if (um) {
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((um >> j) & 1u))
+					s_tup[s_off[cl_bin<NHM>(cl_hash(tc.pos[j]))] + rank[j]] = CL_TUPLE(tc.pos[j], (bin >> j) & 1u, x);
+		}
+		__syncthreads();
+		for (int q = threadIdx.x; q < total; q += 256) {               // consecutive lanes, consecutive tuples of a run
+			const u64 tp = s_tup[q];
+			const u32 b = cl_bin<NHM>(cl_hash(CL_POS(tp)));
+			const int g = s_base[b] + (q - s_off[b]);
+			if (g < KMX_CL_CAP) tup[(u64)b * KMX_CL_CAP + g] = tp;
+			else bd.cl_ovf[i] = 1;                                     // the whole list takes the ordered path this round
+		}
 		__syncthreads();
 	}
+}
+
+// ------------------------------------------------------------------------------------------ D: opposite claims, bin by bin
+// One workgroup per (bin, list): every tuple of the bin goes into an open-addressing table in LDS keyed by a 30-bit
+// fingerprint of its position (the bin and the slot take other bits of the same hash, so two positions that share an
+// entry agree in 52 hash bits: it happens once in ~10^9 builds and only sends a k-mer down the ordered path, which is
+// exact for any superset of the truly contended k-mers).  An entry collects which values are wanted there; a second pass
+// marks every candidate that meets the opposite value on one of its positions as contended.
+template <int NHM> __global__ __launch_bounds__(1024) void k_round_detect(BlockDev bd)
+{
+	constexpr int NBIN = KMX_CL_BINS(NHM), T = 1 << KMX_CL_TBITS;
+	__shared__ u32 s_t[T];
+	const int i = blockIdx.y, b = blockIdx.x;
+	int *gc = bd.cl_cnt + i * KMX_CL_MAXBINS + b;
+	int cnt = *gc;
+	if (cnt == 0) return;                                            // uniform: nothing was emitted into this bin
+	if (cnt > KMX_CL_CAP) cnt = KMX_CL_CAP;                          // check_emit has raised cl_ovf[i]
+	int tb = 10;
+	while ((1 << tb) < 4 * cnt && tb < KMX_CL_TBITS) tb++;           // load <= 1/4 (<= 5/8 for a full bin): short probe chains
+	const u32 tmask = (1u << tb) - 1;
+	for (int q = threadIdx.x; q < (1 << tb); q += 1024) s_t[q] = 0;
+	__syncthreads();
+	const u64 *tp = bd.cl_tup + ((u64)i * NBIN + b) * KMX_CL_CAP;
+	const u64 row = (u64)i * KMX_BUCKET;
+	constexpr int U = 8;                                             // tuples per thread in flight: the loads of a batch are issued together
+	for (int q0 = 0; q0 < cnt; q0 += U * 1024) {
+		u64 e[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) { const int q = q0 + u * 1024 + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			if (e[u] == ~0ULL) continue;
+			const u64 h = cl_hash(CL_POS(e[u]));
+			const u32 fp = (u32)(h >> 11) & 0x3FFFFFFFu, w = 1u << CL_WANT(e[u]);
+			u32 slot = (u32)(h >> 41) & tmask;
+			for (;;) {                                               // a free slot always exists: 2^KMX_CL_TBITS > KMX_CL_CAP
+				const u32 old = atomicCAS(&s_t[slot], 0u, (fp << 2) | w);
+				if (old == 0) break;
+				if ((old >> 2) == fp) { if (!(old & w)) atomicOr(&s_t[slot], w); break; }
+				slot = (slot + 1) & tmask;
+			}
+		}
+	}
+	__syncthreads();
+	for (int q0 = 0; q0 < cnt; q0 += U * 1024) {
+		u64 e[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) { const int q = q0 + u * 1024 + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			if (e[u] == ~0ULL) continue;
+			const u64 h = cl_hash(CL_POS(e[u]));
+			const u32 fp = (u32)(h >> 11) & 0x3FFFFFFFu;
+			u32 slot = (u32)(h >> 41) & tmask, cur;
+			while (((cur = s_t[slot]) >> 2) != fp) slot = (slot + 1) & tmask;
+			if (cur & (2u >> CL_WANT(e[u]))) bd.status[row + CL_X(e[u])] = SLOT_CONTENDED;   // the other value is wanted there too
+		}
+	}
+	if (threadIdx.x == 0) *gc = 0;                                   // (every thread has read it) ready for the next round
 }
 
 // ------------------------------------------------------------------------------------------ S: ordered slow path (helpers)
@@ -376,17 +488,6 @@ template <int NHM> __device__ __forceinline__ void reserve_untagged(const ModelD
 		if (j < md.nh) {
 			u32 b = bit_in_cell(tc.pos[j]);
 			if (!((tc.cell[j] >> (16 + b)) & 1ULL)) atomicMax(resv_slot(bd, i, tc.pos[j]), key);
-		}
-}
-// drop this k-mer's claim bits (they are read by verify_commit only)
-template <int NHM> __device__ __forceinline__ void clear_claims(const ModelDev &md, int a, const Touches<NHM> &tc, u32 bin)
-{
-	u64 *cells = md.cells[a];
-#pragma unroll
-	for (int j = 0; j < NHM; j++)
-		if (j < md.nh) {
-			const u64 cb = CELL_CLAIM((bin >> j) & 1u, bit_in_cell(tc.pos[j]));
-			if (tc.cell[j] & cb) atomicAnd(cells + (tc.pos[j] >> 4), ~cb);
 		}
 }
 // A k-mer owns its outcome when it does not conflict with what is committed by now and holds the reservation of every
@@ -428,46 +529,56 @@ template <int W> __device__ __forceinline__ u32 rec_load(const u64 *rec, u64 slo
 	return (u32)(h >> 48);
 }
 
-// ------------------------------------------------------------------------------------------ B: verify + commit
-// Uncontended candidates commit.  Contended ones file a record in U[0] and place their reservations right away
-// (epoch `epoch`), which saves the first reserve pass of the ordered slow path; their claim bits must stay until
-// every verify_commit thread has read them, so they are dropped by the first slow kernel.
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_verify_commit(ModelDev md, BlockDev bd, int t, int pp, u64 epoch)
+// ------------------------------------------------------------------------------------------ B: commit
+// Candidates that k_round_detect left alone cannot interact with any other candidate of the list (no position of theirs
+// is wanted with the other value), so they commit in parallel: one atomic OR per position they saw untagged (tag + value
+// in one word, kmodel.hpp:611-618) and the km_back insert (:548-550) -- no second look at the cells.  Contended ones file
+// a record in U[0] (with the untagged mask of the check) and place their reservations right away (epoch `epoch`), which
+// saves the first reserve pass of the ordered slow path.
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit(ModelDev md, BlockDev bd, int t, int pp, u64 epoch)
 {
 	__shared__ int s_cnt, s_base;
 	const int i = blockIdx.y;
 	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;
+	const int sbase = a * md.nh;
+	u64 *cells = md.cells[a];
+	const bool all_contended = bd.cl_ovf[i] != 0;
 	for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
 		if (threadIdx.x == 0) s_cnt = 0;
 		__syncthreads();
 		const int x = base + threadIdx.x;
-		const bool active = x < n && bd.status[row + x] == SLOT_UNDECIDED;
-		bool contended = false;
+		const int st = x < n ? (int)bd.status[row + x] : (int)SLOT_FAILED;
+		const bool active = st == SLOT_UNDECIDED || st == SLOT_CONTENDED;
+		const bool contended = active && (st == SLOT_CONTENDED || all_contended);
 		u64 v[W];
 		u32 bin = 0, um = 0;
 		if (active) {
 			const u32 idx = bd.list[pp][row + x];
 			load_kmer<W>(bd.kmers, row + idx, v);
 			bin = md.bin_of_occ[bd.counts[row + idx]];
+			um = bd.um[row + x];
 			Aligned<W> al = left_align<W>(v, md.k);
 			Premixed<W> pm = premix_string<W>(al, md.gfull);
-			Touches<NHM> tc;
-			gather_touches<W, NHM, false>(md, pm, a, tc);
+			const u64 key = resv_key(epoch, (u32)x);
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
-				if (j < md.nh) {
-					u32 b = bit_in_cell(tc.pos[j]);
-					u32 want = (bin >> j) & 1u;
-					bool tagged = (tc.cell[j] >> (16 + b)) & 1ULL;
-					contended |= !tagged && ((tc.cell[j] >> (32 + 16 * (1 - want) + b)) & 1ULL);
-					um |= tagged ? 0u : 1u << j;
+				if (j < md.nh && ((um >> j) & 1u)) {
+					const u64 pos = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(sbase + j) & 127]), md.km_mod);
+					if (contended) atomicMax(resv_slot(bd, i, pos), key);
+					else {
+						const u32 b = bit_in_cell(pos);
+						atomicOr(cells + (pos >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
+					}
 				}
 			if (!contended) {
-				commit_touches<W, NHM>(md, tc, bin, a, al);
+				if (md.kmb_direct) {
+					Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
+					bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+				}
 				bd.status[row + x] = SLOT_INSERTED;
-			} else reserve_untagged<NHM>(md, bd, i, tc, resv_key(epoch, (u32)x));
+			} else bd.status[row + x] = SLOT_UNDECIDED;              // the ordered path decides it
 		}
 		const int p = block_append_slot(bd.Un + UN_IDX(0, i, md.nb), contended, &s_cnt, &s_base);
 		if (contended) rec_store<W>(bd.Urec[0], row + p, (u32)x, bin, v, um);
@@ -524,7 +635,6 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve(
 				Premixed<W> pm = premix_string<W>(al, md.gfull);
 				Touches<NHM> tc;
 				gather_touches<W, NHM, false>(md, pm, a, tc);
-				if (s == 0) clear_claims<NHM>(md, a, tc, bin);
 				mine = owns_outcome<NHM, false>(md, bd, i, tc, bin, resv_key(epoch, x));
 				if (mine) {
 					commit_touches<W, NHM>(md, tc, bin, a, al);
@@ -577,7 +687,6 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0
 				if (j < md.nh && ((um >> j) & 1u)) {
 					pos[j] = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(sbase + j) & 127]), md.km_mod);
 					held[j] = *resv_slot(bd, i, pos[j]);
-					atomicAnd(cells + (pos[j] >> 4), ~CELL_CLAIM((bin >> j) & 1u, bit_in_cell(pos[j])));
 				}
 			mine = true;
 #pragma unroll
@@ -590,8 +699,10 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0
 						const u32 b = bit_in_cell(pos[j]);
 						atomicOr(cells + (pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
 					}
-				Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-				bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+				if (md.kmb_direct) {
+					Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
+					bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+				}
 				bd.status[row + x] = SLOT_INSERTED;
 			}
 			defer = !mine;
@@ -850,7 +961,7 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 		if (won[r]) {
 			u64 *hdr = bd.Urec[lv] + (row + rec[r]) * (1 + W);
 			if (defer) *hdr |= REC_WON;                                // k_reorder applies it
-			else {                                                     // kmodel.hpp:548-550
+			else if (md.kmb_direct) {                                  // kmodel.hpp:548-550
 				u32 x_, bin_;
 				u64 v[W];
 				rec_load<W>(bd.Urec[lv], row + rec[r], x_, bin_, v);
@@ -957,7 +1068,6 @@ __device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev
 			Premixed<W> pm = premix_string<W>(al, md.gfull);
 			Touches<NHM> tc;
 			gather_touches<W, NHM, true>(md, pm, a, tc);
-			if (first) clear_claims<NHM>(md, a, tc, bin);
 			if (owns_outcome<NHM, true>(md, bd, i, tc, bin, resv_key(first ? epoch_b : epoch, x))) {
 				commit_touches<W, NHM>(md, tc, bin, a, al);
 				bd.status[row + x] = SLOT_INSERTED;
@@ -976,9 +1086,7 @@ __device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev
 	}
 }
 
-// Workgroups (i, 0) are the finishers.  Workgroups (i, 1..KMX_FIN_HELPERS) only drop the claim bits of list i's contended
-// k-mers (s == 0: nobody has yet) -- independent random atomics that one CU would take tens of microseconds to issue and
-// that nothing in the finisher reads.
+// One workgroup per list.
 template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch_b, u64 epoch0, int force_global)
 {
 	__shared__ u32 s_t1[KMX_FIN_T], s_t2[KMX_FIN_T], s_list[KMX_FIN_RPT(NHM) * 1024];
@@ -989,25 +1097,6 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 	const int a = (i + t) % md.nb;
 	constexpr int RPT = KMX_FIN_RPT(NHM);
 	const bool lds_path = n <= KMX_FIN_RANGES * RPT * 1024 && !force_global && md.km_mod.d < KMX_FIN_MAX_POS;
-	if (blockIdx.y > 0) {
-		if (s != 0 || !lds_path) return;                             // finish_global drops the claims itself
-		const u64 row = (u64)i * KMX_BUCKET;
-		u64 *cells = md.cells[a];
-		const int sbase = a * md.nh;
-		for (int u = (blockIdx.y - 1) * 1024 + threadIdx.x; u < n; u += KMX_FIN_HELPERS * 1024) {
-			u32 x, bin;
-			u64 v[W];
-			const u32 um = rec_load<W>(bd.Urec[0], row + u, x, bin, v);
-			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
-#pragma unroll
-			for (int j = 0; j < NHM; j++)
-				if (j < md.nh && ((um >> j) & 1u)) {                     // claimed in check_claim iff untagged, and it still was in verify_commit
-					const u64 pos = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(sbase + j) & 127]), md.km_mod);
-					atomicAnd(cells + (pos >> 4), ~CELL_CLAIM((bin >> j) & 1u, bit_in_cell(pos)));
-				}
-		}
-		return;
-	}
 	if (threadIdx.x == 0) {
 		s_succ = 0;
 		s_pending[0] = 0;
@@ -1054,8 +1143,10 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 						const u32 b = bit_in_cell(pos);
 						atomicOr(cells + (pos >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
 					}
-				Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-				bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+				if (md.kmb_direct) {
+					Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
+					bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+				}
 			}
 		}
 		return;
@@ -1091,8 +1182,118 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 	}
 	bd.tile_cnt[pp ^ 1][i * KMX_NTILES + tile] = 0;                 // next round counts into the other buffer
 	if (tile == 0 && threadIdx.x == 0) {
+		bd.cl_ovf[i] = 0;
 		if (n > m) atomicAdd(bd.stats + ST_SUCCESSES, (u64)(n - m));
 		bd.n[pp ^ 1][i] = m;                                       // (the record counters are reset by the next check_claim)
+	}
+}
+
+// ------------------------------------------------------------------------------------------ partitioned bit-set
+// bs_block_emit: every thread of a 256-thread workgroup brings nt <= K bit addresses of the filter; they are counted per
+// bin in LDS, each bin's run is reserved with ONE global atomic, the tuples are sorted by bin in LDS and written out run
+// by run.  All threads must call it (barriers inside); the LDS arrays are the caller's.
+#define BS_LDS(K) __shared__ int s_bs_cnt[BS_BINS], s_bs_off[BS_BINS], s_bs_base[BS_BINS], s_bs_tmp[4]; __shared__ u64 s_bs_stage[256 * (K)]
+template <int K> __device__ __forceinline__ void bs_block_emit(const BitScatter &bs, const u64 *v, u32 valid, int *s_cnt, int *s_off, int *s_base, int *s_tmp, u64 *s_stage)
+{
+	s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	int rank[K];
+#pragma unroll
+	for (int j = 0; j < K; j++)
+		if ((valid >> j) & 1u) rank[j] = atomicAdd(&s_cnt[v[j] >> bs.wshift], 1);
+	__syncthreads();
+	int total;
+	{
+		const int c = s_cnt[threadIdx.x];
+		const int ex = block_excl_scan_256(c, s_tmp, &total);
+		s_off[threadIdx.x] = ex;
+		s_base[threadIdx.x] = c ? atomicAdd(bs.cnt + threadIdx.x, c) : 0;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int j = 0; j < K; j++)
+		if ((valid >> j) & 1u) {
+			const u32 b = (u32)(v[j] >> bs.wshift);
+			s_stage[s_off[b] + rank[j]] = ((u64)b << 32) | (u32)(v[j] - ((u64)b << bs.wshift));
+		}
+	__syncthreads();
+	for (int q = threadIdx.x; q < total; q += 256) {
+		const u64 e = s_stage[q];
+		const u32 b = (u32)(e >> 32), o = (u32)e;
+		const u32 g = (u32)s_base[b] + (u32)(q - s_off[b]);
+		if (g < bs.cap) bs.tup[(u64)b * bs.cap + g] = o;
+		else atomicOr(bs.words + (((u64)b << bs.wshift) >> 5) + (o >> 5), 1u << (o & 31));   // bin full: set the bit directly (exact either way)
+	}
+	__syncthreads();
+}
+
+// One workgroup per bin: the bin's slice of the filter is swept tile by tile (2^20 positions in LDS); a tile collects
+// its bits with LDS atomics and is OR-ed back with coalesced whole-word accesses.  Only this workgroup writes these
+// words during the launch (producers that met a full bin used atomics in EARLIER launches).
+__global__ __launch_bounds__(1024) void k_bs_apply(BitScatter bs)
+{
+	__shared__ u32 s_tile[BS_TILE_WORDS];
+	const u32 b = blockIdx.x;
+	u32 cnt = (u32)bs.cnt[b];
+	if (cnt == 0) return;                                            // uniform
+	if (cnt > bs.cap) cnt = bs.cap;
+	const u64 wpb = 1ULL << (bs.wshift - 5), word0 = (u64)b * wpb;
+	if (word0 >= bs.nwords) return;
+	const u32 nw = (u32)((bs.nwords - word0) < wpb ? (bs.nwords - word0) : wpb);
+	const u32 *tup = bs.tup + (u64)b * bs.cap;
+	u32 *words = bs.words + word0;
+	for (u32 t0 = 0; t0 < nw; t0 += BS_TILE_WORDS) {
+		const u32 tw = nw - t0 < BS_TILE_WORDS ? nw - t0 : BS_TILE_WORDS;
+		for (u32 w = threadIdx.x; w < tw; w += 1024) s_tile[w] = 0;
+		__syncthreads();
+		for (u32 q = threadIdx.x; q < cnt; q += 1024) {
+			const u32 o = tup[q], w = (o >> 5) - t0;
+			if (w < tw) atomicOr(&s_tile[w], 1u << (o & 31));         // (o >> 5) < t0 wraps to a huge value: skipped too
+		}
+		__syncthreads();
+		for (u32 w = threadIdx.x; w < tw; w += 1024) {
+			const u32 x = s_tile[w];
+			if (x) words[t0 + w] |= x;
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) bs.cnt[b] = 0;
+}
+
+// km_back insert of a round (kmodel.hpp:548-550), deferred: every slot the round decided as inserted -- by the parallel
+// commit or by the ordered path -- contributes the nh-2 positions of its (k-2)-mer to the BitScatter of km_back.
+// n_in_block >= 0: once per block instead -- every k-mer of the block that did not go to the rest table was inserted in
+// one of the rounds (the single-GPU build; in the multi-GPU ring a rank sees a list for one round only).
+template <int W, int NHM, int KPT> __global__ __launch_bounds__(256) void k_kmback_emit(ModelDev md, BlockDev bd, int pp, int n_in_block, BitScatter bs)
+{
+	constexpr int K = KPT * (NHM - 2);
+	BS_LDS(K);
+	const int i = blockIdx.y;
+	const bool whole = n_in_block >= 0;
+	int n = bd.n[pp][i];
+	if (whole) { n = n_in_block - i * (int)KMX_BUCKET; n = n < 0 ? 0 : (n > (int)KMX_BUCKET ? (int)KMX_BUCKET : n); }
+	const u64 row = (u64)i * KMX_BUCKET;
+	for (int base = blockIdx.x * 256 * KPT; base < n; base += gridDim.x * 256 * KPT) {   // uniform trip count per workgroup
+		u64 v[K];
+		u32 valid = 0;
+#pragma unroll
+		for (int q = 0; q < KPT; q++) {
+			const int x = base + q * 256 + (int)threadIdx.x;
+			if (x < n && (whole ? !bd.surv[row + x] : bd.status[row + x] == SLOT_INSERTED)) {
+				const u32 idx = whole ? (u32)x : bd.list[pp][row + x];
+				u64 km[W];
+				load_kmer<W>(bd.kmers, row + idx, km);
+				Premixed<W> pb = premix_string<W>(drop_first_base<W>(left_align<W>(km, md.k)), md.gback);
+#pragma unroll
+				for (int j = 0; j < NHM - 2; j++)
+					if (j < md.nh - 2) {
+						const u64 pos = mod_u64(murmur_seeded<W>(pb, md.gback, c_seeds[j]), md.km_back_mod);
+						v[q * (NHM - 2) + j] = ((pos >> 5) << 5) | bit_in_word32(pos);
+						valid |= 1u << (q * (NHM - 2) + j);
+					}
+			}
+		}
+		bs_block_emit<K>(bs, v, valid, s_bs_cnt, s_bs_off, s_bs_base, s_bs_tmp, s_bs_stage);
 	}
 }
 
@@ -1130,6 +1331,7 @@ template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev b
 	const int c = (int)bd.counts[row + idx];
 	store_kmer<W>(rest_kmers, p, v);
 	rest_counts[p] = c;
+	bd.surv[row + idx] = 1;
 	if (x == 0) { store_kmer<W>(stale_kmers, (u64)i, v); stale_counts[i] = c; }
 }
 
@@ -1752,11 +1954,15 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	const int gx = (KMX_BUCKET / 256) >> (t < 4 ? t : 4);
 	const dim3 grid(gx, nb), blk(256), sgrid(SLOW_BLOCKS, nb);
 	KPROF_BEGIN(prof, KC_CHECK_CLAIM, st);
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_claim<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_emit<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
 	KPROF_END(prof, st);
-	const u64 eb = (*epoch)++;                                 // verify_commit's reservations
+	KPROF_BEGIN(prof, KC_DETECT, st);
+	if (md.nh <= 8) hipLaunchKernelGGL((k_round_detect<8>), dim3(KMX_CL_BINS(8), nb), dim3(1024), 0, st, bd);
+	else hipLaunchKernelGGL((k_round_detect<16>), dim3(KMX_CL_BINS(16), nb), dim3(1024), 0, st, bd);
+	KPROF_END(prof, st);
+	const u64 eb = (*epoch)++;                                 // k_round_commit's reservations
 	KPROF_BEGIN(prof, KC_VERIFY_COMMIT, st);
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_verify_commit<W, NHM>), grid, blk, 0, st, md, bd, t, pp, eb));
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit<W, NHM>), grid, blk, 0, st, md, bd, t, pp, eb));
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_SLOW, st);
 	const bool legacy0 = flags & KMX_ROUND_RESOLVE_GATHER;      // test hook: the gathering resolve kernel for level 0 too
@@ -1772,7 +1978,7 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	const int force_global = (flags & KMX_ROUND_FIN_GLOBAL) ? 1 : 0;   // test hook: the finisher's global-memory path for every set
 	const u64 e0 = *epoch;
 	*epoch += (1ULL << 19);                                    // the finisher may use up to |U| <= 2^18 epochs
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb, 1 + KMX_FIN_HELPERS), dim3(1024), 0, st, md, bd, t, pp, nsub, eb, e0, force_global));
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb, 1), dim3(1024), 0, st, md, bd, t, pp, nsub, eb, e0, force_global));
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_REORDER, st);
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, nb), dim3(256), 0, st, md, bd, t, pp, nsub & 1));
@@ -1783,6 +1989,25 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 void rest_append(const ModelDev &md, const BlockDev &bd, int pp, int i0, int n_lists, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, u64 *feedback, hipStream_t st)
 {
 	DISPATCH_W(words(md), hipLaunchKernelGGL(k_rest_append<W>, dim3(KMX_BUCKET / 256, n_lists), dim3(256), 0, st, bd, pp, i0, rest_kmers, rest_counts, rest_n, stale_kmers, stale_counts, feedback));
+}
+
+// n_in_block < 0: the slots round t inserted (list[pp], status); >= 0: every k-mer of the block that is not a survivor
+void kmback_emit(const ModelDev &md, const BlockDev &bd, int t, int pp, int n_in_block, const BitScatter &bs, hipStream_t st)
+{
+	if (!md.km_back_mod.d) return;
+	const int gx = n_in_block >= 0 ? KMX_BUCKET / 1024 : (KMX_BUCKET / 1024) >> (t < 4 ? t : 4);   // 4 (2) slots per thread; lists shrink round by round
+	const dim3 grid(gx, md.nb), blk(256);
+	if (words(md) == 1) {
+		if (md.nh <= 8) hipLaunchKernelGGL((k_kmback_emit<1, 8, 4>), grid, blk, 0, st, md, bd, pp, n_in_block, bs);
+		else hipLaunchKernelGGL((k_kmback_emit<1, 16, 2>), grid, blk, 0, st, md, bd, pp, n_in_block, bs);
+	} else {
+		if (md.nh <= 8) hipLaunchKernelGGL((k_kmback_emit<2, 8, 4>), grid, blk, 0, st, md, bd, pp, n_in_block, bs);
+		else hipLaunchKernelGGL((k_kmback_emit<2, 16, 2>), grid, blk, 0, st, md, bd, pp, n_in_block, bs);
+	}
+}
+void bs_apply(const BitScatter &bs, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_bs_apply, dim3(BS_BINS), dim3(1024), 0, st, bs);
 }
 
 void ring_import(const ModelDev &md, const BlockDev &bd, const RingLists &rl, u64 *stg_kmers, u32 *stg_counts, hipStream_t st)

@@ -35,6 +35,8 @@ void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int
 void block_init(const BlockDev &, int, int, int, hipStream_t);
 void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *);
 void rest_append(const ModelDev &, const BlockDev &, int, int, int, u64 *, int *, unsigned long long *, u64 *, int *, u64 *, hipStream_t);
+void kmback_emit(const ModelDev &, const BlockDev &, int, int, int, const BitScatter &, hipStream_t);
+void bs_apply(const BitScatter &, hipStream_t);
 void ring_import(const ModelDev &, const BlockDev &, const RingLists &, u64 *, u32 *, hipStream_t);
 void ring_export(const ModelDev &, const BlockDev &, const RingLists &, hipStream_t);
 void or_words(u32 *, const u32 *, u64, hipStream_t);
@@ -184,6 +186,14 @@ struct kmx_model {
 	u64 *h_feedback = nullptr;                                 // pinned: ST_MAX_U0 as of some earlier block (heuristic input)
 	u64 *d_feedback = nullptr;                                 // the same words as the device sees them (k_rest_append writes them)
 	u64 epoch = 1, blocks = 0, rounds = 0;
+	// km_back insert as a partitioned bit-set (k_kmback_emit per round, k_bs_apply every few blocks)
+	BitScatter kmb;
+	u32 *d_kmb_tup = nullptr;
+	int *d_kmb_cnt = nullptr;
+	u64 kmb_tup_cap = 0;                                       // tuples allocated
+	u64 kmb_pending = 0, kmb_budget = 0;                       // upper bound of tuples emitted since the last apply / what the bins take
+	bool kmb_deferred = false;
+	bool dbg_kmb_direct = false;                               // KMX_KMB_DIRECT=1: the atomic path at every size (test hook)
 	bool ring = false;                                         // built by several GPUs (kmx_shard_begin): this handle holds ONE rank's share
 	int ring_rank = 0, ring_world = 1;
 	int nsub = 1;                                              // grid-wide ordered passes in round 0 (see process_block)
@@ -281,6 +291,9 @@ static void free_build_state(kmx_model *m)
 	hipFree(m->d_tile_off); m->d_tile_off = nullptr;
 	m->tile_cap = 0;
 	hipFree(m->d_total); m->d_total = nullptr;
+	hipFree(m->d_kmb_tup); m->d_kmb_tup = nullptr;
+	hipFree(m->d_kmb_cnt); m->d_kmb_cnt = nullptr;
+	m->kmb_tup_cap = 0;
 	m->stg_n = m->stg_cap = 0;
 }
 
@@ -336,10 +349,16 @@ static int kmx_create_impl(int ci, int cs, int nh, int nb, kmx_model **out)
 		m->dbg_nsub1 = env_int("KMX_NSUB1", -1);
 		m->dbg_flags = (env_int("KMX_FIN_GLOBAL", 0) ? KMX_ROUND_FIN_GLOBAL : 0) | (env_int("KMX_RESOLVE_GATHER", 0) ? KMX_ROUND_RESOLVE_GATHER : 0);
 		m->dbg_ctrl = env_int("KMX_CTRL_DEBUG", 0) != 0;
+		m->dbg_kmb_direct = env_int("KMX_KMB_DIRECT", 0) != 0;
 	}
 	HIPCHK(hipEventCreate(&m->ev0));
 	HIPCHK(hipEventCreate(&m->ev1));
-	HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+	{   // the side stream carries the order-free front end of later chunks underneath the ordered rounds: lowest priority, so that
+		// the rounds' workgroups (some need a whole CU: 1024 threads / 128 KB of LDS) are placed first whenever resources free up
+		int least = 0, greatest = 0;
+		HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+		HIPCHK(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, least));
+	}
 	HIPCHK(hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming));
 	HIPCHK(hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming));
 	m->prof.events = &m->prof_events; m->prof.spans = &m->prof_spans; m->prof.begin = prof_begin; m->prof.end = prof_end;
@@ -403,6 +422,7 @@ static void fill_model_dev(kmx_model *m)
 		md.bf_back[i] = m->d_bf_back[i]; md.bf_back_mod[i] = make_mod(i < m->bf_num ? m->byte_bf_back[i] * 8 : 0);
 	}
 	md.km_back = m->d_km_back; md.km_back_mod = make_mod(m->byte_km_back * 8);
+	md.kmb_direct = m->kmb_deferred ? 0 : 1;
 	for (int a = 0; a < m->nb; a++) md.cells[a] = m->d_cells[a];
 	md.km_mod = make_mod(m->km_byte_size * 8);
 	md.bin_of_occ = m->d_bin_of_occ; md.mean_of_bin = m->d_mean_of_bin;
@@ -426,6 +446,56 @@ static int alloc_arrays(kmx_model *m)
 	return KMX_OK;
 }
 
+// km_back as a partitioned bit-set: bins of a power-of-two number of positions, swept in tiles of 2^20.  Up to 8 tiles
+// per bin the sweep re-reads a bin's tuples once per tile out of L2; beyond that (km_back > 256 MB, i.e. more than
+// ~8*10^8 coupled k-mers at nh = 7) the direct atomic path stays.
+static int setup_kmback_scatter(kmx_model *m)
+{
+	m->kmb_deferred = false;
+	m->kmb_pending = 0;
+	const u64 nwords = (m->byte_km_back + 3) / 4;
+	if (m->dbg_kmb_direct || nwords == 0) return KMX_OK;
+	u32 wshift = 5;
+	while ((((u64)BS_BINS) << wshift) < nwords * 32) wshift++;
+	if (wshift > 20 + 3) return KMX_OK;                            // more than 8 tiles per bin
+	const u64 blk = (u64)m->nb * KMX_BUCKET, per_block = blk * (u64)(m->nh - 2);
+	const u64 cap = 1u << 18;                                      // tuples per bin (1 MB)
+	const u64 bins_used = (nwords * 32 + (1ULL << wshift) - 1) >> wshift;
+	if (!m->d_kmb_tup) {
+		TRY(dalloc(&m->d_kmb_tup, (u64)BS_BINS * cap, false, m->stream));
+		TRY(dalloc(&m->d_kmb_cnt, (u64)BS_BINS, true, m->stream));
+		m->kmb_tup_cap = (u64)BS_BINS * cap;
+	}
+	m->kmb.words = m->d_km_back; m->kmb.nwords = nwords; m->kmb.wshift = wshift; m->kmb.cap = (u32)cap;
+	m->kmb.tup = m->d_kmb_tup; m->kmb.cnt = m->d_kmb_cnt;
+	// positions are hashed uniformly over the used bins: keep the expected fill of a bin below 3/4 (a full bin is still exact)
+	m->kmb_budget = bins_used * cap * 3 / 4;
+	if (m->kmb_budget < per_block) return KMX_OK;                  // a single block would not fit: tiny filter, direct path
+	m->kmb_deferred = true;
+	return KMX_OK;
+}
+
+// sweep km_back with what the rounds have emitted so far
+static int kmback_flush(kmx_model *m)
+{
+	if (!m->kmb_deferred || !m->kmb_pending) return KMX_OK;
+	kmxk::bs_apply(m->kmb, m->stream);
+	m->kmb_pending = 0;
+	HIPCHK(hipGetLastError());
+	return KMX_OK;
+}
+// the (k-2)-mers of the successes -> bins: of round t (n_in_block < 0; the ring, where a rank holds a list for one round)
+// or of a whole block after its last round (n_in_block >= 0); `bound` = most k-mers that can have been inserted
+static int kmback_emit(kmx_model *m, int t, int pp, int n_in_block, u64 bound)
+{
+	if (!m->kmb_deferred) return KMX_OK;
+	const u64 add = bound * (u64)(m->nh - 2);
+	if (m->kmb_pending + add > m->kmb_budget) TRY(kmback_flush(m));
+	kmxk::kmback_emit(m->md, m->bd, t, pp, n_in_block, m->kmb, m->stream);
+	m->kmb_pending += add;
+	return KMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------ streamed build
 static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total)
 {
@@ -441,6 +511,7 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 	compute_sizes(m);
 	TRY(alloc_arrays(m));
 	m->rest = RestTable();
+	TRY(setup_kmback_scatter(m));
 	fill_model_dev(m);
 	const int nb = m->nb;
 	const u64 B = KMX_BUCKET, blk = (u64)nb * B;
@@ -460,6 +531,9 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 		for (int s2 = 0; s2 < KMX_NSLOW; s2++) o_U[s2] = carve(blk * 8 * (1 + m->W));
 		u64 o_Un = carve((u64)KMX_NSLOW * nb * KMX_CTR_STRIDE * 4), o_R = carve((u64)nb * KMX_RSIZE * 8);
 		u64 o_tc0 = carve((u64)nb * KMX_NTILES * 4), o_tc1 = carve((u64)nb * KMX_NTILES * 4);
+		const u64 cl_bins = m->nh <= 8 ? KMX_CL_BINS(8) : KMX_CL_BINS(16);
+		u64 o_surv = carve(blk);
+		u64 o_um = carve(blk * 2), o_cl_tup = carve((u64)nb * cl_bins * KMX_CL_CAP * 8), o_cl_cnt = carve((u64)nb * KMX_CL_MAXBINS * 4), o_cl_ovf = carve((u64)nb * 4);
 		HIPCHK(hipMalloc(&m->d_block_scratch, off));
 		HIPCHK(hipMemsetAsync(m->d_block_scratch, 0, off, m->stream));     // R starts at epoch 0; epochs only grow
 		m->scratch_bytes = off; m->scratch_nb = nb; m->scratch_W = m->W;
@@ -472,6 +546,9 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 		for (int s2 = 0; s2 < KMX_NSLOW; s2++) bd.Urec[s2] = (u64 *)(base + o_U[s2]);
 		bd.Un = (int *)(base + o_Un); bd.R = (u64 *)(base + o_R);
 		bd.tile_cnt[0] = (int *)(base + o_tc0); bd.tile_cnt[1] = (int *)(base + o_tc1);
+		bd.surv = (unsigned char *)(base + o_surv);
+		bd.um = (unsigned short *)(base + o_um); bd.cl_tup = (u64 *)(base + o_cl_tup);
+		bd.cl_cnt = (int *)(base + o_cl_cnt); bd.cl_ovf = (int *)(base + o_cl_ovf);      // zeroed with the slab; the kernels keep them zero between rounds
 		bd.stats = m->d_stats;
 		TRY(dalloc(&m->d_rest_n, 1, false, m->stream));
 		TRY(dalloc(&m->d_stale_kmers, (u64)nb * 2, false, m->stream));
@@ -594,6 +671,7 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 			                   (const int *)m->d_stale_counts, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stats);
 	}
 	kmxk::rest_append(m->md, m->bd, pp, 0, nb, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream);
+	TRY(kmback_emit(m, 0, pp, (int)n_in_block, n_in_block));     // km_back insert of everything the block inserted (kmodel.hpp:548-550)
 	m->blocks++;
 	HIPCHK(hipGetLastError());
 	return KMX_OK;
@@ -813,6 +891,7 @@ static int kmx_finish_impl(kmx_model *m)
 	HIPCHK(hipSetDevice(m->device));
 	if (m->stg_n) TRY(process_block(m, 0, m->stg_n, true));   // push_last_to_array; an empty tail is skipped (divergence D1)
 	m->stg_n = 0;
+	TRY(kmback_flush(m));
 	unsigned long long n_rest = 0;
 	HIPCHK(hipMemcpyAsync(m->h_stats, m->d_stats, ST_N * 8, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipMemcpyAsync(&n_rest, m->d_rest_n, 8, hipMemcpyDeviceToHost, m->stream));
@@ -823,9 +902,9 @@ static int kmx_finish_impl(kmx_model *m)
 	}
 	if (m->prof.on) {
 		double before = 0, after = 0;
-		for (int c = 0; c < KC_QUERY; c++) before += m->kc_seconds[c];
+		for (int c = 0; c < KC_N; c++) if (c != KC_QUERY) before += m->kc_seconds[c];
 		prof_collect(m);
-		for (int c = 0; c < KC_QUERY; c++) after += m->kc_seconds[c];
+		for (int c = 0; c < KC_N; c++) if (c != KC_QUERY) after += m->kc_seconds[c];
 		m->t_insert_kernels = after - before;                   // HIP-event time inside the insert kernels of this build
 	}
 	TRY(build_rest(m, n_rest));
@@ -1108,6 +1187,7 @@ static int kmx_ring_round_dev_impl(kmx_model *m, int t, const kmx_ring_list *lis
 	if (t == 0) steer_passes(m);
 	kmxk::ring_import(m->md, m->bd, rl, m->d_stg_kmers, m->d_stg_counts, m->stream);
 	kmxk::round(m->md, m->bd, t, 0, passes_of_round(m, t), &m->epoch, m->dbg_flags, m->stream, &m->prof);
+	TRY(kmback_emit(m, t, 0, -1, (u64)n_lists * KMX_BUCKET));
 	m->rounds++;
 	bool any_out = false;
 	for (int i = 0; i < nb; i++) any_out |= rl.e[i].active && rl.e[i].dst_msg;
@@ -1142,6 +1222,7 @@ static int kmx_shard_local_impl(kmx_model *m, kmx_stats *partial, void **d_rest_
 	if (!m || !partial) return fail(KMX_E_ARG, "null argument");
 	if (m->state != ST_BUILDING || !m->ring) return fail(KMX_E_STATE, "shard_local before shard_begin");
 	HIPCHK(hipSetDevice(m->device));
+	TRY(kmback_flush(m));
 	unsigned long long n_rest = 0;
 	HIPCHK(hipMemcpyAsync(m->h_stats, m->d_stats, ST_N * 8, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipMemcpyAsync(&n_rest, m->d_rest_n, 8, hipMemcpyDeviceToHost, m->stream));

@@ -11,6 +11,8 @@ struct ModelDev {
 	u32 *km_back;    ModU64 km_back_mod;       // back filter of the coupled arrays  (kmodel.hpp:267-269)
 	u64 *cells[KMX_MAX_NB];                    // coupled arrays, cell layout (device_common.h)
 	ModU64 km_mod;                             // bit_array_length                   (kmodel.hpp:33,445)
+	int kmb_direct;                            // 1: a success ORs its (k-2)-mer into km_back right away (atomics); 0: the bits are
+	                                           // scattered round by round through a BitScatter (k_kmback_emit / k_bs_apply)
 	const u32 *bin_of_occ;                     // occ -> bin  (occu_bin.hpp:67-77)
 	const u32 *mean_of_bin;                    // bin -> mean (occu_bin.hpp:79-83)
 	// exact rest table (rest.hpp), device form: suffixes as integers instead of byte rows
@@ -27,6 +29,21 @@ struct ModelDev {
 	                                           // reference's inclusive upper bound can still match), all-ones if none
 };
 
+// Partitioned bit-set into one order-free filter (set_bit is an OR, kmodel.hpp:576-581): producers append the bit
+// addresses they want set to BS_BINS position-range bins (LDS-staged runs, bs_block_emit); k_bs_apply then sweeps the
+// filter bin by bin, tile by tile: the bits of a tile are collected in LDS and the tile is OR-ed back with whole-word
+// coalesced accesses -- streaming traffic instead of one random read-modify-write per bit.
+#define BS_BINS 256
+#define BS_TILE_WORDS (1u << 15)               // 2^15 words = 128 KB of LDS = 2^20 positions per tile
+struct BitScatter {
+	u32 *words;              // the filter (32-bit words; bit p of the filter = bit bit_in_word32(p) of word p >> 5)
+	u64 nwords;
+	u32 wshift;              // log2(positions per bin): bin = address >> wshift (a power of two of words, at most 2^32 positions)
+	u32 cap;                 // tuples per bin; a producer that finds its bin full sets the bit with an atomic instead
+	u32 *tup;                // [BS_BINS][cap] bit offsets inside the bin: (word - bin start) << 5 | bit in word
+	int *cnt;                // [BS_BINS], reset by k_bs_apply
+};
+
 // device-side statistics (one u64 each)
 enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_MAX_U0, ST_MAX_UFIN, ST_N };
 
@@ -35,7 +52,6 @@ enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, 
 #define KMX_RSIZE (1u << KMX_RSIZE_LOG2)      // reservation slots per list (ordered slow path)
 #define KMX_FIN_RPT(NHM) ((NHM) <= 8 ? 2 : 1)      // records per finisher thread kept in registers (1024 threads)
 #define KMX_FIN_RANGES 8                        // the finisher takes up to this many register loads, in index ranges
-#define KMX_FIN_HELPERS 3                       // extra workgroups per list that drop the claim bits beside the finisher
 #define KMX_APPLY_WGS 8                         // extra workgroups per list in k_reorder that apply the finisher's decisions
 enum { KMX_ROUND_FIN_GLOBAL = 1, KMX_ROUND_RESOLVE_GATHER = 2 };   // test hooks of kmxk::round (older code paths)
 #define KMX_NSLOW 2                            // contended-record levels, ping-pong: pass s reads level s&1, defers to (s+1)&1
@@ -56,6 +72,7 @@ struct BlockDev {
 	int *n[2];               // n[pp][i] current list lengths (buff_real_n, kmodel.hpp:277)
 	int *tile_cnt[2];        // tile_cnt[pp][i*NTILES + tile] survivors (failed slots) per 1024-slot tile, counted as they fail
 	unsigned char *status;   // [nb*BUCKET] per slot: 0 undecided, 1 failed (survivor), 2 inserted
+	unsigned char *surv;     // [nb*BUCKET] per k-mer of the block: 1 = it went to the rest table (k_rest_append); the others were inserted
 	// contended k-mers; level (s & 1) = still undecided after s grid-wide resolve passes.  A record carries what the
 	// ordered slow path needs -- word 0 = slot | bin << 32, then the W packed k-mer words -- so that its latency-bound
 	// kernels reach the cells after ONE dependent load.
@@ -63,7 +80,19 @@ struct BlockDev {
 	int *Un;                 // [KMX_NSLOW*nb*KMX_CTR_STRIDE], use UN_IDX
 	u64 *R;                  // [nb*KMX_RSIZE] epoch-tagged reservations
 	u64 *stats;              // [ST_N]
+	// claims of a round as a partitioned stream (k_round_check_emit -> k_round_detect -> k_round_commit)
+	unsigned short *um;      // [nb*BUCKET] per slot: positions a candidate saw untagged (bit j = hash j)
+	u64 *cl_tup;             // [nb][bins][KMX_CL_CAP] claim tuples, hash-partitioned by position
+	int *cl_cnt;             // [nb][KMX_CL_MAXBINS] tuples per bin (reset by k_round_detect)
+	int *cl_ovf;             // [nb] a bin of the list overflowed: every candidate of the round takes the ordered path (reset by k_reorder)
 };
+
+// claim partition: bins per list and slots of the LDS table of one bin (kernels.hip, "claims as a partitioned stream")
+#define KMX_CL_BINS_LOG2(NHM) ((NHM) <= 8 ? 7 : 8)
+#define KMX_CL_BINS(NHM) (1 << KMX_CL_BINS_LOG2(NHM))
+#define KMX_CL_MAXBINS 256
+#define KMX_CL_CAP 20480                       // tuples per bin: 2^18 * nh / bins = 16384 at most on average, + 25 %
+#define KMX_CL_TBITS 15                        // 2^15 > KMX_CL_CAP slots: the table of a bin can always take every tuple
 
 #define LIST_HOLE 0x80000000u
 
@@ -79,10 +108,10 @@ struct RingList {
 };
 struct RingLists { RingList e[KMX_MAX_NB]; };
 
-enum { SLOT_UNDECIDED = 0, SLOT_FAILED = 1, SLOT_INSERTED = 2 };
+enum { SLOT_UNDECIDED = 0, SLOT_FAILED = 1, SLOT_INSERTED = 2, SLOT_CONTENDED = 3 };
 
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
-enum { KC_CLASSIFY = 0, KC_CHECK_CLAIM, KC_VERIFY_COMMIT, KC_SLOW, KC_REORDER, KC_REST, KC_QUERY, KC_N };
+enum { KC_CLASSIFY = 0, KC_CHECK_CLAIM, KC_VERIFY_COMMIT, KC_SLOW, KC_REORDER, KC_REST, KC_QUERY, KC_DETECT, KC_N };   // CHECK_CLAIM = check + emit, VERIFY_COMMIT = commit
 struct KernelProf {
 	bool on = false;
 	void *events = nullptr;      // std::vector<hipEvent_t>* owned by the host side

@@ -1,8 +1,8 @@
 """Print the kernel timeline of one mid-build block from a rocprofv3 kernel trace (csv)."""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+f = (glob.glob(sys.argv[1] + "/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
-ours = [r for r in rows if r["Kernel_Name"].startswith(("void k_", "k_"))]
+ours = [r for r in rows if r["Kernel_Name"].startswith(("void k_", "k_")) and "k_micro" not in r["Kernel_Name"]]
 ours.sort(key=lambda r: int(r["Start_Timestamp"]))
 t0 = int(ours[0]["Start_Timestamp"])
 idx = [i for i, r in enumerate(ours) if "k_block_init" in r["Kernel_Name"]]
