@@ -160,14 +160,80 @@ __global__ __launch_bounds__(256) void k_histogram(const u32 *counts, u64 n, int
 	if (bad) atomicAdd(stats + ST_BAD_COUNT, bad);
 }
 
+// block-wide exclusive scan of one int per thread (256 threads)
+__device__ __forceinline__ int block_excl_scan_256(int v, int *s_tmp, int *total)
+{
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	int incl = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		int t = __shfl_up(incl, d, 64);
+		if (lane >= d) incl += t;
+	}
+	if (lane == 63) s_tmp[wave] = incl;
+	__syncthreads();
+	int wbase = 0, tot = 0;
+#pragma unroll
+	for (int w = 0; w < 4; w++) {
+		int c = s_tmp[w];
+		if (w < wave) wbase += c;
+		tot += c;
+	}
+	__syncthreads();
+	if (total) *total = tot;
+	return wbase + incl - v;
+}
+
+// ------------------------------------------------------------------------------------------ partitioned bit-set
+// bs_block_emit: every thread of a 256-thread workgroup brings nt <= K bit addresses of the filter; they are counted per
+// bin in LDS, each bin's run is reserved with ONE global atomic, the tuples are sorted by bin in LDS and written out run
+// by run.  All threads must call it (barriers inside); the LDS arrays are the caller's.
+#define BS_LDS(K) __shared__ int s_bs_cnt[BS_BINS], s_bs_off[BS_BINS], s_bs_base[BS_BINS], s_bs_tmp[4]; __shared__ u64 s_bs_stage[256 * (K)]
+template <int K> __device__ __forceinline__ void bs_block_emit(const BitScatter &bs, const u64 *v, u32 valid, int *s_cnt, int *s_off, int *s_base, int *s_tmp, u64 *s_stage)
+{
+	s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	int rank[K];
+#pragma unroll
+	for (int j = 0; j < K; j++)
+		if ((valid >> j) & 1u) rank[j] = atomicAdd(&s_cnt[v[j] >> bs.wshift], 1);
+	__syncthreads();
+	int total;
+	{
+		const int c = s_cnt[threadIdx.x];
+		const int ex = block_excl_scan_256(c, s_tmp, &total);
+		s_off[threadIdx.x] = ex;
+		s_base[threadIdx.x] = c ? atomicAdd(bs.cnt + threadIdx.x, c) : 0;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int j = 0; j < K; j++)
+		if ((valid >> j) & 1u) {
+			const u32 b = (u32)(v[j] >> bs.wshift);
+			s_stage[s_off[b] + rank[j]] = ((u64)b << 32) | (u32)(v[j] - ((u64)b << bs.wshift));
+		}
+	__syncthreads();
+	for (int q = threadIdx.x; q < total; q += 256) {
+		const u64 e = s_stage[q];
+		const u32 b = (u32)(e >> 32), o = (u32)e;
+		const u32 g = (u32)s_base[b] + (u32)(q - s_off[b]);
+		if (g < bs.cap) bs.tup[(u64)b * bs.cap + g] = o;
+		else atomicOr(bs.words + (((u64)b << bs.wshift) >> 5) + (o >> 5), 1u << (o & 31));   // bin full: set the bit directly (exact either way)
+	}
+	__syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------ classification
 // Pass 2 front end (kmodel.hpp:70-73): Bloom-class k-mers are inserted right here (commutative ORs, any
 // order); coupled-array k-mers are compacted, in listing order, into the staging stream.
 #define CLS_TILE KMX_CLS_TILE
-template <int W> __global__ __launch_bounds__(256) void k_classify_count(ModelDev md, const u64 *kmers, const u32 *counts, u64 n, int *tile_cnt, u64 *stats)
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_classify_count(ModelDev md, const u64 *kmers, const u32 *counts, u64 n, int *tile_cnt, u64 *stats, BitScatter bs)
 {
-	__shared__ int s_cnt;
-	if (threadIdx.x == 0) s_cnt = 0;
+	constexpr int K = 2 * NHM - 3;                                   // (nh-1) + (nh-2) positions of one Bloom-class k-mer
+	BS_LDS(K);
+	__shared__ int s_cnt, s_nb;
+	__shared__ unsigned short s_bloom[CLS_TILE];                     // the tile's Bloom-class k-mers (offsets in the tile)
+	if (threadIdx.x == 0) { s_cnt = 0; s_nb = 0; }
 	__syncthreads();
 	int mine = 0;
 	u64 base = (u64)blockIdx.x * CLS_TILE;
@@ -177,19 +243,52 @@ template <int W> __global__ __launch_bounds__(256) void k_classify_count(ModelDe
 		u32 c = counts[i];
 		if (c < (u32)md.ci || c > (u32)md.cs) { atomicAdd(stats + ST_BAD_COUNT, 1ULL); continue; }
 		if (c < (u32)(md.ci + md.bf_num)) {
-			int f = (int)(c - (u32)md.ci);
-			u64 v[W];
-			load_kmer<W>(kmers, i, v);
-			Aligned<W> al = left_align<W>(v, md.k);
-			Premixed<W> pf = premix_string<W>(al, md.gfull);
-			bloom_insert_pm<W>(pf, md.gfull, md.bf[f], md.bf_mod[f], md.nh - 1);                 // kmodel.hpp:474
-			Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-			bloom_insert_pm<W>(pb, md.gback, md.bf_back[f], md.bf_back_mod[f], md.nh - 2);       // kmodel.hpp:475-476
+			if (md.bloom_direct) {
+				int f = (int)(c - (u32)md.ci);
+				u64 v[W];
+				load_kmer<W>(kmers, i, v);
+				Aligned<W> al = left_align<W>(v, md.k);
+				Premixed<W> pf = premix_string<W>(al, md.gfull);
+				bloom_insert_pm<W>(pf, md.gfull, md.bf[f], md.bf_mod[f], md.nh - 1);                 // kmodel.hpp:474
+				Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
+				bloom_insert_pm<W>(pb, md.gback, md.bf_back[f], md.bf_back_mod[f], md.nh - 2);       // kmodel.hpp:475-476
+			} else s_bloom[atomicAdd(&s_nb, 1)] = (unsigned short)(q * 256 + threadIdx.x);
 		} else mine++;
 	}
 	if (mine) atomicAdd(&s_cnt, mine);
 	__syncthreads();
 	if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_cnt;
+	if (md.bloom_direct) return;
+	// the Bloom-class k-mers of the tile, 256 at a time: their bit addresses in the slab go to the BitScatter
+	const int nbl = s_nb;
+	for (int c0 = 0; c0 < nbl; c0 += 256) {                          // uniform
+		u64 v[K];
+		u32 valid = 0;
+		if (c0 + (int)threadIdx.x < nbl) {
+			const u64 i = base + s_bloom[c0 + threadIdx.x];
+			const int f = (int)(counts[i] - (u32)md.ci);
+			u64 km[W];
+			load_kmer<W>(kmers, i, km);
+			Aligned<W> al = left_align<W>(km, md.k);
+			Premixed<W> pf = premix_string<W>(al, md.gfull);
+			Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
+#pragma unroll
+			for (int j = 0; j < NHM - 1; j++)
+				if (j < md.nh - 1 && md.bf_mod[f].d) {
+					const u64 pos = mod_u64(murmur_seeded<W>(pf, md.gfull, c_seeds[j]), md.bf_mod[f]);
+					v[j] = ((md.bf_woff[f] + (pos >> 5)) << 5) | bit_in_word32(pos);
+					valid |= 1u << j;
+				}
+#pragma unroll
+			for (int j = 0; j < NHM - 2; j++)
+				if (j < md.nh - 2 && md.bf_back_mod[f].d) {
+					const u64 pos = mod_u64(murmur_seeded<W>(pb, md.gback, c_seeds[j]), md.bf_back_mod[f]);
+					v[NHM - 1 + j] = ((md.bf_back_woff[f] + (pos >> 5)) << 5) | bit_in_word32(pos);
+					valid |= 1u << (NHM - 1 + j);
+				}
+		}
+		bs_block_emit<K>(bs, v, valid, s_bs_cnt, s_bs_off, s_bs_base, s_bs_tmp, s_bs_stage);
+	}
 }
 
 // exclusive scan of up to 2^20 tile counts by one workgroup; total -> *total_out
@@ -216,30 +315,6 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const int *cnt, int *off, i
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) *total_out = carry;
-}
-
-// block-wide exclusive scan of one int per thread (256 threads)
-__device__ __forceinline__ int block_excl_scan_256(int v, int *s_tmp, int *total)
-{
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	int incl = v;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		int t = __shfl_up(incl, d, 64);
-		if (lane >= d) incl += t;
-	}
-	if (lane == 63) s_tmp[wave] = incl;
-	__syncthreads();
-	int wbase = 0, tot = 0;
-#pragma unroll
-	for (int w = 0; w < 4; w++) {
-		int c = s_tmp[w];
-		if (w < wave) wbase += c;
-		tot += c;
-	}
-	__syncthreads();
-	if (total) *total = tot;
-	return wbase + incl - v;
 }
 
 template <int W> __global__ __launch_bounds__(256) void k_classify_scatter(ModelDev md, const u64 *kmers, const u32 *counts, u64 n, const int *tile_off, u64 *stg_kmers, u32 *stg_counts, u64 stg_base)
@@ -1188,45 +1263,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 	}
 }
 
-// ------------------------------------------------------------------------------------------ partitioned bit-set
-// bs_block_emit: every thread of a 256-thread workgroup brings nt <= K bit addresses of the filter; they are counted per
-// bin in LDS, each bin's run is reserved with ONE global atomic, the tuples are sorted by bin in LDS and written out run
-// by run.  All threads must call it (barriers inside); the LDS arrays are the caller's.
-#define BS_LDS(K) __shared__ int s_bs_cnt[BS_BINS], s_bs_off[BS_BINS], s_bs_base[BS_BINS], s_bs_tmp[4]; __shared__ u64 s_bs_stage[256 * (K)]
-template <int K> __device__ __forceinline__ void bs_block_emit(const BitScatter &bs, const u64 *v, u32 valid, int *s_cnt, int *s_off, int *s_base, int *s_tmp, u64 *s_stage)
-{
-	s_cnt[threadIdx.x] = 0;
-	__syncthreads();
-	int rank[K];
-#pragma unroll
-	for (int j = 0; j < K; j++)
-		if ((valid >> j) & 1u) rank[j] = atomicAdd(&s_cnt[v[j] >> bs.wshift], 1);
-	__syncthreads();
-	int total;
-	{
-		const int c = s_cnt[threadIdx.x];
-		const int ex = block_excl_scan_256(c, s_tmp, &total);
-		s_off[threadIdx.x] = ex;
-		s_base[threadIdx.x] = c ? atomicAdd(bs.cnt + threadIdx.x, c) : 0;
-	}
-	__syncthreads();
-#pragma unroll
-	for (int j = 0; j < K; j++)
-		if ((valid >> j) & 1u) {
-			const u32 b = (u32)(v[j] >> bs.wshift);
-			s_stage[s_off[b] + rank[j]] = ((u64)b << 32) | (u32)(v[j] - ((u64)b << bs.wshift));
-		}
-	__syncthreads();
-	for (int q = threadIdx.x; q < total; q += 256) {
-		const u64 e = s_stage[q];
-		const u32 b = (u32)(e >> 32), o = (u32)e;
-		const u32 g = (u32)s_base[b] + (u32)(q - s_off[b]);
-		if (g < bs.cap) bs.tup[(u64)b * bs.cap + g] = o;
-		else atomicOr(bs.words + (((u64)b << bs.wshift) >> 5) + (o >> 5), 1u << (o & 31));   // bin full: set the bit directly (exact either way)
-	}
-	__syncthreads();
-}
-
+// ------------------------------------------------------------------------------------------ partitioned bit-set: the sweep
 // One workgroup per bin: the bin's slice of the filter is swept tile by tile (2^20 positions in LDS); a tile collects
 // its bits with LDS atomics and is OR-ed back with coalesced whole-word accesses.  Only this workgroup writes these
 // words during the launch (producers that met a full bin used atomics in EARLIER launches).
@@ -1915,15 +1952,23 @@ void histogram(const u32 *counts, u64 n, int ci, int cs, int bf_num, u64 *n_bf, 
 // returns the number of classification tiles
 int classify_tiles(u64 n) { return (int)((n + CLS_TILE - 1) / CLS_TILE); }
 
-// Front end of `n` k-mers cut into chunks of `chunk` k-mers (a multiple of CLS_TILE): ONE launch inserts every
-// Bloom-class k-mer and counts the coupled-array k-mers per tile; one small scan per chunk turns the counts into
-// offsets relative to the chunk start and the chunk's total (totals[c]).
-void classify_count(const ModelDev &md, const u64 *kmers, const u32 *counts, u64 n, u64 chunk, int *tile_cnt, int *tile_off, int *totals, u64 *stats, hipStream_t st, KernelProf *prof)
+// Front end of `n` k-mers cut into chunks of `chunk` k-mers (a multiple of CLS_TILE): the Bloom-class k-mers are inserted
+// (directly, or half a chunk at a time through the BitScatter `bs`, swept right away) and the coupled-array k-mers are
+// counted per tile; one small scan per chunk turns the counts into offsets relative to the chunk start and the chunk's
+// total (totals[c]).
+void classify_count(const ModelDev &md, const u64 *kmers, const u32 *counts, u64 n, u64 chunk, int *tile_cnt, int *tile_off, int *totals, u64 *stats, const BitScatter &bs, hipStream_t st, KernelProf *prof)
 {
 	if (!n) return;
 	const int tiles = classify_tiles(n), tiles_per_chunk = (int)(chunk / CLS_TILE);
+	const int W_ = words(md);
 	KPROF_BEGIN(prof, KC_CLASSIFY, st);
-	DISPATCH_W(words(md), hipLaunchKernelGGL(k_classify_count<W>, dim3(tiles), dim3(256), 0, st, md, kmers, counts, n, tile_cnt, stats));
+	const u64 piece = md.bloom_direct ? n : chunk / 2;              // k-mers per launch: what the bins of the BitScatter take
+	for (u64 lo = 0; lo < n; lo += piece) {
+		const u64 c = n - lo < piece ? n - lo : piece;
+		const int t0 = (int)(lo / CLS_TILE), nt = classify_tiles(c);
+		DISPATCH_W_NH(W_, md.nh, hipLaunchKernelGGL((k_classify_count<W, NHM>), dim3(nt), dim3(256), 0, st, md, kmers + lo * W_, counts + lo, c, tile_cnt + t0, stats, bs));
+		if (!md.bloom_direct) hipLaunchKernelGGL(k_bs_apply, dim3(BS_BINS), dim3(1024), 0, st, bs);
+	}
 	KPROF_END(prof, st);
 	for (int c = 0, t0 = 0; t0 < tiles; c++, t0 += tiles_per_chunk) {
 		const int nt = tiles - t0 < tiles_per_chunk ? tiles - t0 : tiles_per_chunk;

@@ -30,7 +30,7 @@
 namespace kmxk {
 void histogram(const u32 *, u64, int, int, int, u64 *, u64 *, hipStream_t);
 int classify_tiles(u64 n);
-void classify_count(const ModelDev &, const u64 *, const u32 *, u64, u64, int *, int *, int *, u64 *, hipStream_t, KernelProf *);
+void classify_count(const ModelDev &, const u64 *, const u32 *, u64, u64, int *, int *, int *, u64 *, const BitScatter &, hipStream_t, KernelProf *);
 void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int *, u64 *, u32 *, u64, hipStream_t);
 void block_init(const BlockDev &, int, int, int, hipStream_t);
 void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *);
@@ -156,9 +156,11 @@ struct kmx_model {
 	u32 *d_bin_of_occ = nullptr, *d_mean_of_bin = nullptr;
 	u64 n_total = 0, n_km = 0, n_bf[3] = {0, 0, 0};
 	u64 byte_bf[3] = {0, 0, 0}, byte_bf_back[3] = {0, 0, 0}, km_byte_size = 0, byte_km_back = 0, ncells = 0;
+	u32 *d_bloom = nullptr;                                    // ONE slab for bf[i] / bf_back[i], back to back (d_bf / d_bf_back point into it)
+	u64 cap_bloom = 0, bloom_words = 0, bf_woff[3] = {0, 0, 0}, bf_back_woff[3] = {0, 0, 0};
 	u32 *d_bf[3] = {nullptr, nullptr, nullptr}, *d_bf_back[3] = {nullptr, nullptr, nullptr}, *d_km_back = nullptr;
 	u64 *d_cells[KMX_MAX_NB] = {nullptr};
-	u64 cap_bf[3] = {0, 0, 0}, cap_bf_back[3] = {0, 0, 0}, cap_km_back = 0, cap_cells[KMX_MAX_NB] = {0};   // bytes allocated
+	u64 cap_km_back = 0, cap_cells[KMX_MAX_NB] = {0};          // bytes allocated
 	RestTable rest;
 	ModelDev md;
 	// ---- build-time state
@@ -180,12 +182,15 @@ struct kmx_model {
 	u64 tile_cap = 0;                                          // tiles the two arrays above can hold
 	int *d_totals = nullptr, *h_totals = nullptr;              // per-chunk totals of one insert_batch call (h_: pinned)
 	u64 totals_cap = 0;
-	hipStream_t side = nullptr;                                // front-end (classification + Bloom insert) of later chunks
-	hipEvent_t ev_in = nullptr, ev_side = nullptr;
 	int *h_total = nullptr;                                    // pinned
 	u64 *h_feedback = nullptr;                                 // pinned: ST_MAX_U0 as of some earlier block (heuristic input)
 	u64 *d_feedback = nullptr;                                 // the same words as the device sees them (k_rest_append writes them)
 	u64 epoch = 1, blocks = 0, rounds = 0;
+	// Bloom-class k-mers of the front end as a partitioned bit-set over the slab (k_classify_count emits, k_bs_apply sweeps)
+	BitScatter blm;
+	u32 *d_blm_tup = nullptr;
+	int *d_blm_cnt = nullptr;
+	bool blm_deferred = false;
 	// km_back insert as a partitioned bit-set (k_kmback_emit per round, k_bs_apply every few blocks)
 	BitScatter kmb;
 	u32 *d_kmb_tup = nullptr;
@@ -291,6 +296,8 @@ static void free_build_state(kmx_model *m)
 	hipFree(m->d_tile_off); m->d_tile_off = nullptr;
 	m->tile_cap = 0;
 	hipFree(m->d_total); m->d_total = nullptr;
+	hipFree(m->d_blm_tup); m->d_blm_tup = nullptr;
+	hipFree(m->d_blm_cnt); m->d_blm_cnt = nullptr;
 	hipFree(m->d_kmb_tup); m->d_kmb_tup = nullptr;
 	hipFree(m->d_kmb_cnt); m->d_kmb_cnt = nullptr;
 	m->kmb_tup_cap = 0;
@@ -307,13 +314,10 @@ static void free_rest_dev(RestTable &r)
 
 static void free_arrays(kmx_model *m)
 {
-	for (int i = 0; i < 3; i++) {
-		hipFree(m->d_bf[i]); hipFree(m->d_bf_back[i]);
-		m->d_bf[i] = m->d_bf_back[i] = nullptr;
-	}
+	hipFree(m->d_bloom); m->d_bloom = nullptr; m->cap_bloom = 0;
+	for (int i = 0; i < 3; i++) m->d_bf[i] = m->d_bf_back[i] = nullptr;
 	hipFree(m->d_km_back); m->d_km_back = nullptr;
 	for (int a = 0; a < KMX_MAX_NB; a++) { hipFree(m->d_cells[a]); m->d_cells[a] = nullptr; m->cap_cells[a] = 0; }
-	for (int i = 0; i < 3; i++) m->cap_bf[i] = m->cap_bf_back[i] = 0;
 	m->cap_km_back = 0;
 	free_rest_dev(m->rest);
 }
@@ -353,14 +357,6 @@ static int kmx_create_impl(int ci, int cs, int nh, int nb, kmx_model **out)
 	}
 	HIPCHK(hipEventCreate(&m->ev0));
 	HIPCHK(hipEventCreate(&m->ev1));
-	{   // the side stream carries the order-free front end of later chunks underneath the ordered rounds: lowest priority, so that
-		// the rounds' workgroups (some need a whole CU: 1024 threads / 128 KB of LDS) are placed first whenever resources free up
-		int least = 0, greatest = 0;
-		HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-		HIPCHK(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, least));
-	}
-	HIPCHK(hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming));
-	HIPCHK(hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming));
 	m->prof.events = &m->prof_events; m->prof.spans = &m->prof_spans; m->prof.begin = prof_begin; m->prof.end = prof_end;
 	*out = m;
 	return KMX_OK;
@@ -378,9 +374,6 @@ static int kmx_destroy_impl(kmx_model *m)
 	if (m->h_feedback) hipHostFree(m->h_feedback);
 	if (m->ev0) hipEventDestroy(m->ev0);
 	if (m->ev1) hipEventDestroy(m->ev1);
-	if (m->ev_in) hipEventDestroy(m->ev_in);
-	if (m->ev_side) hipEventDestroy(m->ev_side);
-	if (m->side) { hipStreamSynchronize(m->side); hipStreamDestroy(m->side); }
 	hipFree(m->d_totals);
 	if (m->h_totals) hipHostFree(m->h_totals);
 	for (hipEvent_t e : m->prof_events) hipEventDestroy(e);
@@ -423,6 +416,8 @@ static void fill_model_dev(kmx_model *m)
 	}
 	md.km_back = m->d_km_back; md.km_back_mod = make_mod(m->byte_km_back * 8);
 	md.kmb_direct = m->kmb_deferred ? 0 : 1;
+	md.bloom_direct = m->blm_deferred ? 0 : 1;
+	for (int i = 0; i < 3; i++) { md.bf_woff[i] = m->bf_woff[i]; md.bf_back_woff[i] = m->bf_back_woff[i]; }
 	for (int a = 0; a < m->nb; a++) md.cells[a] = m->d_cells[a];
 	md.km_mod = make_mod(m->km_byte_size * 8);
 	md.bin_of_occ = m->d_bin_of_occ; md.mean_of_bin = m->d_mean_of_bin;
@@ -434,9 +429,18 @@ static void fill_model_dev(kmx_model *m)
 static int alloc_arrays(kmx_model *m)
 {
 	free_rest_dev(m->rest);
-	for (int i = 0; i < m->bf_num; i++) {
-		TRY(ensure(&m->d_bf[i], &m->cap_bf[i], ((m->byte_bf[i] + 3) / 4 + 1) * 4, true, m->stream));
-		TRY(ensure(&m->d_bf_back[i], &m->cap_bf_back[i], ((m->byte_bf_back[i] + 3) / 4 + 1) * 4, true, m->stream));
+	{   // the Bloom filters and their back filters live back to back in one slab (the BitScatter of the front end sweeps it)
+		u64 off = 0;
+		for (int i = 0; i < 3; i++) {
+			m->bf_woff[i] = off; off += i < m->bf_num ? (m->byte_bf[i] + 3) / 4 + 1 : 0;
+			m->bf_back_woff[i] = off; off += i < m->bf_num ? (m->byte_bf_back[i] + 3) / 4 + 1 : 0;
+		}
+		m->bloom_words = off;
+		TRY(ensure(&m->d_bloom, &m->cap_bloom, (off + 1) * 4, true, m->stream));
+		for (int i = 0; i < 3; i++) {
+			m->d_bf[i] = i < m->bf_num ? m->d_bloom + m->bf_woff[i] : nullptr;
+			m->d_bf_back[i] = i < m->bf_num ? m->d_bloom + m->bf_back_woff[i] : nullptr;
+		}
 	}
 	TRY(ensure(&m->d_km_back, &m->cap_km_back, ((m->byte_km_back + 3) / 4 + 1) * 4, true, m->stream));
 	// (hipMalloc of fresh device memory costs ~90 ms per GB on this stack, also from several threads at once:
@@ -472,6 +476,26 @@ static int setup_kmback_scatter(kmx_model *m)
 	m->kmb_budget = bins_used * cap * 3 / 4;
 	if (m->kmb_budget < per_block) return KMX_OK;                  // a single block would not fit: tiny filter, direct path
 	m->kmb_deferred = true;
+	return KMX_OK;
+}
+
+// The Bloom slab as a partitioned bit-set: the front end emits half a chunk (2^22 k-mers) and sweeps.  Same limit of
+// 8 tiles per bin; the bins take a half chunk of which ~2/3 is Bloom class (more falls back to atomics, bit by bit).
+static int setup_bloom_scatter(kmx_model *m)
+{
+	m->blm_deferred = false;
+	if (m->dbg_kmb_direct || m->bloom_words == 0) return KMX_OK;
+	u32 wshift = 5;
+	while ((((u64)BS_BINS) << wshift) < m->bloom_words * 32) wshift++;
+	if (wshift > 20 + 3) return KMX_OK;
+	const u64 cap = 1u << 18;
+	if (!m->d_blm_tup) {
+		TRY(dalloc(&m->d_blm_tup, (u64)BS_BINS * cap, false, m->stream));
+		TRY(dalloc(&m->d_blm_cnt, (u64)BS_BINS, true, m->stream));
+	}
+	m->blm.words = m->d_bloom; m->blm.nwords = m->bloom_words; m->blm.wshift = wshift; m->blm.cap = (u32)cap;
+	m->blm.tup = m->d_blm_tup; m->blm.cnt = m->d_blm_cnt;
+	m->blm_deferred = true;
 	return KMX_OK;
 }
 
@@ -512,6 +536,7 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 	TRY(alloc_arrays(m));
 	m->rest = RestTable();
 	TRY(setup_kmback_scatter(m));
+	TRY(setup_bloom_scatter(m));
 	fill_model_dev(m);
 	const int nb = m->nb;
 	const u64 B = KMX_BUCKET, blk = (u64)nb * B;
@@ -719,27 +744,14 @@ static int kmx_insert_batch_dev_impl(kmx_model *m, const uint64_t *d_kmers, cons
 	TRY(ensure_front_end(m, n));
 	const u64 *km0 = (const u64 *)d_kmers;
 	const u32 *ct0 = (const u32 *)d_counts;
-	const u64 c0 = std::min<u64>(kChunk, n);
-	const int tiles0 = kmxk::classify_tiles(c0);
-	kmxk::classify_count(m->md, km0, ct0, c0, kChunk, m->d_tile_cnt, m->d_tile_off, m->d_totals, m->d_stats, m->stream, &m->prof);
-	HIPCHK(hipMemcpyAsync(m->h_totals, m->d_totals, 4, hipMemcpyDeviceToHost, m->stream));
-	if (n_chunks > 1) {
-		HIPCHK(hipEventRecord(m->ev_in, m->stream));             // the input (and the zeroed filters) are ready
-		HIPCHK(hipStreamWaitEvent(m->side, m->ev_in, 0));
-		kmxk::classify_count(m->md, km0 + c0 * m->W, ct0 + c0, n - c0, kChunk, m->d_tile_cnt + tiles0, m->d_tile_off + tiles0,
-		                     m->d_totals + 1, m->d_stats, m->side, &m->prof);
-		HIPCHK(hipMemcpyAsync(m->h_totals + 1, m->d_totals + 1, (n_chunks - 1) * 4, hipMemcpyDeviceToHost, m->side));
-		HIPCHK(hipEventRecord(m->ev_side, m->side));
-	}
+	// the order-free front end of the whole batch first (classification, Bloom classes), then the ordered rounds chunk by chunk
+	kmxk::classify_count(m->md, km0, ct0, n, kChunk, m->d_tile_cnt, m->d_tile_off, m->d_totals, m->d_stats, m->blm, m->stream, &m->prof);
+	HIPCHK(hipMemcpyAsync(m->h_totals, m->d_totals, n_chunks * 4, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipStreamSynchronize(m->stream));
 	for (u64 ci = 0, done = 0; ci < n_chunks; ci++) {
 		const u64 c = std::min<u64>(kChunk, n - done);
 		const u64 *km = km0 + done * m->W;
 		const u32 *ct = ct0 + done;
-		if (ci == 1) {                                           // the side stream's results: wait once, in stream order too
-			HIPCHK(hipEventSynchronize(m->ev_side));
-			HIPCHK(hipStreamWaitEvent(m->stream, m->ev_side, 0));
-		}
 		const u64 add = (u64)m->h_totals[ci];
 		done += c;
 		if (m->km_byte_size == 0 && add) continue;               // divergence D2: no arrays to insert into
@@ -1143,7 +1155,7 @@ static int kmx_shard_classify_dev_impl(kmx_model *m, const uint64_t *d_kmers, co
 	HIPCHK(hipSetDevice(m->device));
 	TRY(ensure_front_end(m, n));
 	const u64 n_chunks = (n + kChunk - 1) / kChunk;
-	kmxk::classify_count(m->md, (const u64 *)d_kmers, (const u32 *)d_counts, n, kChunk, m->d_tile_cnt, m->d_tile_off, m->d_totals, m->d_stats, m->stream, &m->prof);
+	kmxk::classify_count(m->md, (const u64 *)d_kmers, (const u32 *)d_counts, n, kChunk, m->d_tile_cnt, m->d_tile_off, m->d_totals, m->d_stats, m->blm, m->stream, &m->prof);
 	HIPCHK(hipMemcpyAsync(m->h_totals, m->d_totals, n_chunks * 4, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipStreamSynchronize(m->stream));
 	u64 base = 0;

@@ -11,6 +11,8 @@ struct ModelDev {
 	u32 *km_back;    ModU64 km_back_mod;       // back filter of the coupled arrays  (kmodel.hpp:267-269)
 	u64 *cells[KMX_MAX_NB];                    // coupled arrays, cell layout (device_common.h)
 	ModU64 km_mod;                             // bit_array_length                   (kmodel.hpp:33,445)
+	int bloom_direct;                          // 1: Bloom-class k-mers OR their bits in right away; 0: through the BitScatter of the Bloom slab
+	u64 bf_woff[3], bf_back_woff[3];           // word offsets of the filters inside the slab (they are allocated back to back)
 	int kmb_direct;                            // 1: a success ORs its (k-2)-mer into km_back right away (atomics); 0: the bits are
 	                                           // scattered round by round through a BitScatter (k_kmback_emit / k_bs_apply)
 	const u32 *bin_of_occ;                     // occ -> bin  (occu_bin.hpp:67-77)
