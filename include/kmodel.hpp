@@ -1,7 +1,8 @@
 // include/kmodel.hpp -- drop-in C++ facade with the reference's own names over the C ABI (include/kmx.h).
 //
 // A program written against lzhLab/kmcEx's kmodel.hpp (README.md:64-93, main.cpp:143-149) compiles against
-// this header unchanged and links libkmx.so instead of pulling in the header-only CPU implementation:
+// this header and links libkmx.so instead of pulling in the header-only CPU implementation (tests/facade_query.cpp is
+// written the way those snippets are: unqualified std names, Tools::get_file_name, KModel() + load(dir)):
 //
 //     KModel* km = get_model(ci, cs, n_hash, n_bit);      // kmodel.hpp:674
 //     km->init(kmc_database);                              // kmodel.hpp:57   (README: init_KModel)
@@ -24,8 +25,23 @@
 
 #include "kmx.h"
 
+// The reference header leaks `using namespace std;` and its README snippets and main.cpp rely on it (unqualified string,
+// vector<string>, cout); a drop-in has to leak it too.
+using namespace std;
+
+// the one helper of tools.hpp that main.cpp uses outside the class (tools.hpp:102-105)
+class Tools {
+public:
+	static string get_file_name(string path)
+	{
+		const size_t pos = path.find_last_of('/');
+		return pos == string::npos ? path : path.substr(pos + 1);
+	}
+};
+
 class KModel {
 public:
+	KModel() : h_(nullptr) {}                                          // kmodel.hpp:43; fill it with load(dir)
 	explicit KModel(kmx_model *h) : h_(h) {}
 	~KModel() { kmx_destroy(h_); }
 	KModel(const KModel &) = delete;
@@ -71,6 +87,16 @@ public:
 
 	void save(std::string save_dir) { check(kmx_save(h_, save_dir.c_str())); }       // kmodel.hpp:173
 	void save_model(std::string save_dir) { save(save_dir); }                          // README.md:78
+
+	// kmodel.hpp:209 -- the model directory replaces whatever this object held (parameters come from its header)
+	void load(std::string save_dir)
+	{
+		kmx_model *h = nullptr;
+		check(kmx_load(save_dir.c_str(), &h));
+		kmx_destroy(h_);
+		h_ = h;
+	}
+	void load_model(std::string save_dir) { load(save_dir); }
 
 	// kmodel.hpp:118, :127 -- same table, figures from kmx_get_stats
 	void show_header_info()

@@ -72,8 +72,9 @@ def load_library():
         try:
             _build.build_lib()
         except Exception as e:  # noqa: BLE001
-            if not os.path.exists(path):
-                raise KmxError(-2, f"libkmx.so is missing and could not be built ({e}); there is no CPU fallback")
+            # never run against a library older than the sources: the numbers would describe code that is not in the tree
+            what = "is missing" if not os.path.exists(path) else "is older than its sources"
+            raise KmxError(-2, f"libkmx.so {what} and could not be built ({e}); there is no CPU fallback")
     # A process that also uses PyTorch-ROCm must end up with ONE HIP runtime: torch bundles its own libamdhip64
     # (same SONAME as /opt/rocm's).  Importing torch first makes libkmx.so bind to the copy torch already loaded;
     # the other order leaves torch unable to see the GPU ("No HIP GPUs are available").

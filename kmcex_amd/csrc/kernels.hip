@@ -1587,7 +1587,7 @@ __device__ __forceinline__ int occ_from_filters(const ModelDev &md, const StrGeo
 			}
 		}
 	}
-	return (int)md.mean_of_bin[bin];
+	return bin < (1 << md.nh) ? (int)md.mean_of_bin[bin] : 0;       // a Bloom-class count beyond the table: the reference's map yields 0 (occu_bin.hpp:79-83)
 }
 
 // get_candidates (kmodel.hpp:326-342) on a packed k-mer; returns -2 when the neighbour contributes nothing
@@ -1636,6 +1636,7 @@ template <int W> __global__ __launch_bounds__(256) void k_query(ModelDev md, con
 	if (q >= n) return;
 	u64 v[W];
 	load_kmer<W>(kmers, q, v);
+	if (md.k & 31) v[0] &= (1ULL << (2 * (md.k & 31))) - 1;          // bits above 2k are not part of a packed k-mer (a caller's stray bits would index past the tables)
 	min_kmer<W>(v, md.k);
 	int occ = rest_check<W>(md, v);
 	if (occ != 0) { out[q] = occ; return; }
@@ -1784,6 +1785,42 @@ template <int W> __global__ __launch_bounds__(256) void k_query_ascii(ModelDev m
 		}
 		return nc;
 	});
+}
+
+// ------------------------------------------------------------------------------------------ KMC listing on the device
+// CKMCFile::ReadNextKmer (kmc_file.cpp:428-515) for a whole batch of records at once: the host only moves the raw record
+// bytes (pinned hipMemcpyAsync); prefix lookup, byte swaps and packing happen here.  Every record of the batch must be
+// listed (count within the header's [min_count, max_count]); the caller checks that in pass 1.
+__device__ __forceinline__ u64 lut_last_le(const u64 *lut, u64 lo, u64 hi, u64 rec)      // largest idx in [lo, hi] with lut[idx] <= rec
+{
+	while (lo < hi) {
+		const u64 mid = lo + (hi - lo + 1) / 2;
+		if (lut[mid] <= rec) lo = mid; else hi = mid - 1;
+	}
+	return lo;
+}
+template <int W> __global__ __launch_bounds__(256) void k_kmc_decode(KmcDecode d, u64 rec0, u64 n, u64 *kmers, u32 *counts)
+{
+	__shared__ u64 s_lo, s_hi;
+	const u64 j0 = (u64)blockIdx.x * 256;
+	if (threadIdx.x < 2) {                                           // the LUT entries of the workgroup's first and last record
+		u64 j = j0 + (threadIdx.x ? 255 : 0);
+		if (j >= n) j = n - 1;
+		const u64 idx = lut_last_le(d.lut, 0, d.n_lut - 1, rec0 + j);
+		if (threadIdx.x) s_hi = idx; else s_lo = idx;
+	}
+	__syncthreads();
+	const u64 j = j0 + threadIdx.x;
+	if (j >= n) return;
+	const u64 prefix = lut_last_le(d.lut, s_lo, s_hi, rec0 + j) & d.prefix_mask;
+	const unsigned char *r = d.recs + j * d.rec_bytes;
+	u32 c = 0;
+	for (u32 b = 0; b < d.cnt_bytes; b++) c |= (u32)r[d.suf_bytes + b] << (8 * b);
+	u64 hi = 0, lo = prefix;
+	for (u32 b = 0; b < d.suf_bytes; b++) { hi = (hi << 8) | (lo >> 56); lo = (lo << 8) | r[b]; }
+	if (W == 1) kmers[j] = lo;
+	else { kmers[2 * j] = hi; kmers[2 * j + 1] = lo; }
+	counts[j] = c;
 }
 
 // ------------------------------------------------------------------------------------------ layout conversion
@@ -2053,6 +2090,12 @@ void kmback_emit(const ModelDev &md, const BlockDev &bd, int t, int pp, int n_in
 void bs_apply(const BitScatter &bs, hipStream_t st)
 {
 	hipLaunchKernelGGL(k_bs_apply, dim3(BS_BINS), dim3(1024), 0, st, bs);
+}
+
+void kmc_decode(const KmcDecode &d, int W_, u64 rec0, u64 n, u64 *kmers, u32 *counts, hipStream_t st)
+{
+	if (!n) return;
+	DISPATCH_W(W_, hipLaunchKernelGGL(k_kmc_decode<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, rec0, n, kmers, counts));
 }
 
 void ring_import(const ModelDev &md, const BlockDev &bd, const RingLists &rl, u64 *stg_kmers, u32 *stg_counts, hipStream_t st)

@@ -206,25 +206,55 @@ size_t KmcListing::next_batch(uint64_t *kmers, uint32_t *counts, size_t max_n)
 	return out;
 }
 
-void KmcListing::count_classes(uint32_t ci, uint32_t cs, int bf_num, uint64_t n_bf[3], uint64_t *out_of_range) const
+void KmcListing::copy_records(uint64_t rec0, uint64_t n, unsigned char *dst) const
+{
+	if (!map_ || rec0 >= avail_ || !n) return;
+	n = std::min<uint64_t>(n, avail_ - rec0);
+	const unsigned char *src = map_ + 4 + rec0 * rec_bytes_;
+	const uint64_t bytes = n * rec_bytes_;
+	const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)threads_, bytes / (1u << 20) + 1));
+	if (T == 1) { memcpy(dst, src, bytes); return; }
+	std::vector<std::thread> th;
+	const uint64_t per = ((bytes + T - 1) / T + 4095) & ~uint64_t(4095);
+	for (int t = 0; t < T; t++)
+		th.emplace_back([=] {
+			const uint64_t lo = (uint64_t)t * per, hi = std::min(bytes, lo + per);
+			if (lo < hi) memcpy(dst + lo, src + lo, hi - lo);
+		});
+	for (auto &x : th) x.join();
+}
+
+void KmcListing::count_classes(uint32_t ci, uint32_t cs, int bf_num, uint64_t n_bf[3], uint64_t *out_of_range, uint64_t *not_listed) const
 {
 	n_bf[0] = n_bf[1] = n_bf[2] = 0;
 	*out_of_range = 0;
+	if (not_listed) *not_listed = 0;
 	if (!map_) return;
 	const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)threads_, avail_ / 65536 + 1));
 	std::vector<uint64_t> acc((size_t)T * 8, 0);
 	auto work = [&](int t) {
 		const uint64_t per = (avail_ + T - 1) / T, lo = (uint64_t)t * per, hi = std::min(avail_, lo + per);
-		uint64_t a[4] = {0, 0, 0, 0};
-		for (uint64_t r = lo; r < hi; r++) {
-			const unsigned char *p = map_ + 4 + r * rec_bytes_ + suf_bytes_;
-			uint32_t c = 0;
-			for (uint32_t b = 0; b < counter_size_; b++) c |= (uint32_t)p[b] << (8 * b);
-			if (c < min_count_ || c > max_count_) continue;              // not listed
+		uint64_t a[5] = {0, 0, 0, 0, 0};
+		const uint32_t cnt_mask = counter_size_ == 4 ? 0xFFFFFFFFu : ((1u << (8 * counter_size_)) - 1);
+		const uint64_t hi_fast = hi > lo + 2 ? hi - 2 : lo;               // the 4-byte load may reach past the last record's counter
+		uint64_t r = lo;
+		for (; r < hi_fast; r++) {                                          // one unaligned load per record
+			uint32_t c;
+			memcpy(&c, map_ + 4 + r * rec_bytes_ + suf_bytes_, 4);
+			c &= cnt_mask;
+			if (c < min_count_ || c > max_count_) { a[4]++; continue; }   // not listed
 			if (c < ci || c > cs) a[3]++;
 			else if (c < ci + (uint32_t)bf_num) a[c - ci]++;
 		}
-		for (int q = 0; q < 4; q++) acc[(size_t)t * 8 + q] = a[q];
+		for (; r < hi; r++) {
+			const unsigned char *p = map_ + 4 + r * rec_bytes_ + suf_bytes_;
+			uint32_t c = 0;
+			for (uint32_t b = 0; b < counter_size_; b++) c |= (uint32_t)p[b] << (8 * b);
+			if (c < min_count_ || c > max_count_) { a[4]++; continue; }   // not listed
+			if (c < ci || c > cs) a[3]++;
+			else if (c < ci + (uint32_t)bf_num) a[c - ci]++;
+		}
+		for (int q = 0; q < 5; q++) acc[(size_t)t * 8 + q] = a[q];
 	};
 	if (T == 1) work(0);
 	else {
@@ -235,6 +265,7 @@ void KmcListing::count_classes(uint32_t ci, uint32_t cs, int bf_num, uint64_t n_
 	for (int t = 0; t < T; t++) {
 		for (int q = 0; q < 3; q++) n_bf[q] += acc[(size_t)t * 8 + q];
 		*out_of_range += acc[(size_t)t * 8 + 3];
+		if (not_listed) *not_listed += acc[(size_t)t * 8 + 4];
 	}
 }
 

@@ -31,8 +31,19 @@ public:
 	void set_threads(int t) { threads_ = t < 1 ? 1 : t; }       // decode threads per batch (records are fixed-size)
 	// Pass 1 of KModel::init (kmodel.hpp:423-428) without materialising k-mers: number of listed k-mers per count
 	// ci+i (i < bf_num) and the number of listed counts outside [ci, cs].  Does not move the listing cursor.
-	void count_classes(uint32_t ci, uint32_t cs, int bf_num, uint64_t n_bf[3], uint64_t *out_of_range) const;
+	// `not_listed` (optional): records whose count lies outside the header's [min_count, max_count] (ReadNextKmer skips them).
+	void count_classes(uint32_t ci, uint32_t cs, int bf_num, uint64_t n_bf[3], uint64_t *out_of_range, uint64_t *not_listed = nullptr) const;
 	const std::string &error() const { return err_; }
+	// Raw access for a decoder that runs elsewhere (the GPU: k_kmc_decode): fixed-size records [suffix bytes, big-endian |
+	// counter bytes, little-endian], the concatenated LUT(s) with a sentinel (record r belongs to LUT entry idx with
+	// lut[idx] <= r < lut[idx+1]; its prefix is idx & prefix_mask), and a parallel memcpy of a record range.
+	uint64_t records() const { return avail_; }
+	uint32_t record_bytes() const { return rec_bytes_; }
+	uint32_t suffix_bytes() const { return suf_bytes_; }
+	uint32_t counter_bytes() const { return counter_size_; }
+	uint64_t prefix_mask() const { return prefix_mask_; }
+	const std::vector<uint64_t> &lut() const { return lut_; }
+	void copy_records(uint64_t rec0, uint64_t n, unsigned char *dst) const;
 
 private:
 	size_t decode_range(const unsigned char *recs, uint64_t rec0, size_t n_recs, uint64_t *kmers, uint32_t *counts) const;

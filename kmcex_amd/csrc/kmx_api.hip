@@ -73,6 +73,24 @@ static int fail(int code, const char *fmt, ...)
 
 extern "C" const char *kmx_last_error(void) { return g_err; }
 
+// temporaries of one call: freed on every way out
+struct DevMem {
+	void *p = nullptr;
+	DevMem() = default;
+	DevMem(const DevMem &) = delete;
+	DevMem &operator=(const DevMem &) = delete;
+	~DevMem() { if (p) hipFree(p); }
+	hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+	template <typename T> T *as() const { return (T *)p; }
+	void *release() { void *q = p; p = nullptr; return q; }
+};
+template <typename F> struct ScopeExit {
+	F f;
+	explicit ScopeExit(F g) : f(g) {}
+	~ScopeExit() { f(); }
+};
+template <typename F> static ScopeExit<F> scope_exit(F f) { return ScopeExit<F>(f); }
+
 static int kmx_device_count_impl(void)
 {
 	int n = 0;
@@ -199,6 +217,16 @@ struct kmx_model {
 	u64 kmb_pending = 0, kmb_budget = 0;                       // upper bound of tuples emitted since the last apply / what the bins take
 	bool kmb_deferred = false;
 	bool dbg_kmb_direct = false;                               // KMX_KMB_DIRECT=1: the atomic path at every size (test hook)
+	// feed of KModel::init(db): pinned slots, device buffers, copy stream -- kept across calls on the handle (allocating and
+	// freeing ~300 MB of pinned + device memory costs ~30 ms per call on this stack)
+	struct KmcFeed {
+		unsigned char *raw[2] = {nullptr, nullptr}, *draw[2] = {nullptr, nullptr};
+		u64 *km[2] = {nullptr, nullptr}, *dk[2] = {nullptr, nullptr}, *d_lut = nullptr;
+		u32 *cnt[2] = {nullptr, nullptr}, *dc[2] = {nullptr, nullptr};
+		size_t raw_cap = 0, km_cap = 0, dk_cap = 0, lut_cap = 0;   // bytes / bytes / k-mer words / entries
+		hipStream_t copy = nullptr;
+		hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+	} feed;
 	bool ring = false;                                         // built by several GPUs (kmx_shard_begin): this handle holds ONE rank's share
 	int ring_rank = 0, ring_world = 1;
 	int nsub = 1;                                              // grid-wide ordered passes in round 0 (see process_block)
@@ -322,6 +350,8 @@ static void free_arrays(kmx_model *m)
 	free_rest_dev(m->rest);
 }
 
+static int create_device_side(kmx_model *m);
+static int kmx_destroy_impl(kmx_model *m);
 static int kmx_create_impl(int ci, int cs, int nh, int nb, kmx_model **out)
 {
 	if (!out) return fail(KMX_E_ARG, "null out");
@@ -335,6 +365,14 @@ static int kmx_create_impl(int ci, int cs, int nh, int nb, kmx_model **out)
 	m->ci = ci; m->cs = cs; m->nh = nh; m->nb = nb;
 	m->bf_num = ci == 1 ? 1 : 3;                               // kmodel.hpp:50
 	if (occubin_tables(cs, nh, m->h_bin_of_occ, m->h_mean_of_bin)) { delete m; return fail(KMX_E_ARG, "cs=%d too small for nh=%d", cs, nh); }
+	const int rc = create_device_side(m);
+	if (rc) { kmx_destroy_impl(m); return rc; }                // whatever was allocated so far goes with the handle
+	*out = m;
+	return KMX_OK;
+}
+
+static int create_device_side(kmx_model *m)
+{
 	HIPCHK(hipGetDevice(&m->device));
 	HIPCHK(hipMalloc((void **)&m->d_bin_of_occ, m->h_bin_of_occ.size() * 4));
 	HIPCHK(hipMalloc((void **)&m->d_mean_of_bin, m->h_mean_of_bin.size() * 4));
@@ -358,8 +396,25 @@ static int kmx_create_impl(int ci, int cs, int nh, int nb, kmx_model **out)
 	HIPCHK(hipEventCreate(&m->ev0));
 	HIPCHK(hipEventCreate(&m->ev1));
 	m->prof.events = &m->prof_events; m->prof.spans = &m->prof_spans; m->prof.begin = prof_begin; m->prof.end = prof_end;
-	*out = m;
 	return KMX_OK;
+}
+
+static void free_feed(kmx_model *m)
+{
+	auto &f = m->feed;
+	if (f.copy) { hipStreamSynchronize(f.copy); hipStreamDestroy(f.copy); f.copy = nullptr; }
+	for (int s = 0; s < 2; s++) {
+		if (f.raw[s]) hipHostFree(f.raw[s]);
+		if (f.km[s]) hipHostFree(f.km[s]);
+		if (f.cnt[s]) hipHostFree(f.cnt[s]);
+		hipFree(f.draw[s]); hipFree(f.dk[s]); hipFree(f.dc[s]);
+		if (f.ev_copied[s]) hipEventDestroy(f.ev_copied[s]);
+		if (f.ev_free[s]) hipEventDestroy(f.ev_free[s]);
+		f.raw[s] = f.draw[s] = nullptr; f.km[s] = f.dk[s] = nullptr; f.cnt[s] = f.dc[s] = nullptr;
+		f.ev_copied[s] = f.ev_free[s] = nullptr;
+	}
+	hipFree(f.d_lut); f.d_lut = nullptr;
+	f.raw_cap = f.km_cap = f.dk_cap = f.lut_cap = 0;
 }
 
 static int kmx_destroy_impl(kmx_model *m)
@@ -376,6 +431,7 @@ static int kmx_destroy_impl(kmx_model *m)
 	if (m->ev1) hipEventDestroy(m->ev1);
 	hipFree(m->d_totals);
 	if (m->h_totals) hipHostFree(m->h_totals);
+	free_feed(m);
 	for (hipEvent_t e : m->prof_events) hipEventDestroy(e);
 	delete m;
 	return KMX_OK;
@@ -624,15 +680,14 @@ static int ensure_rest_capacity(kmx_model *m, u64 add)
 	m->rest_upper = actual;
 	if (m->rest_upper + add > m->rest_cap) {
 		u64 ncap = std::max<u64>(m->rest_cap * 2, m->rest_upper + add);
-		u64 *nk = nullptr;
-		int *nc = nullptr;
-		HIPCHK(hipMalloc((void **)&nk, ncap * m->W * 8));
-		HIPCHK(hipMalloc((void **)&nc, ncap * 4));
-		HIPCHK(hipMemcpyAsync(nk, m->d_rest_kmers, actual * m->W * 8, hipMemcpyDeviceToDevice, m->stream));
-		HIPCHK(hipMemcpyAsync(nc, m->d_rest_counts, actual * 4, hipMemcpyDeviceToDevice, m->stream));
+		DevMem nk, nc;
+		HIPCHK(nk.alloc(ncap * m->W * 8));
+		HIPCHK(nc.alloc(ncap * 4));
+		HIPCHK(hipMemcpyAsync(nk.p, m->d_rest_kmers, actual * m->W * 8, hipMemcpyDeviceToDevice, m->stream));
+		HIPCHK(hipMemcpyAsync(nc.p, m->d_rest_counts, actual * 4, hipMemcpyDeviceToDevice, m->stream));
 		HIPCHK(hipStreamSynchronize(m->stream));
 		hipFree(m->d_rest_kmers); hipFree(m->d_rest_counts);
-		m->d_rest_kmers = nk; m->d_rest_counts = nc; m->rest_cap = ncap;
+		m->d_rest_kmers = (u64 *)nk.release(); m->d_rest_counts = (int *)nc.release(); m->rest_cap = ncap;
 	}
 	m->rest_upper += add;
 	return KMX_OK;
@@ -776,26 +831,83 @@ static int kmx_insert_batch_dev_impl(kmx_model *m, const uint64_t *d_kmers, cons
 	return KMX_OK;
 }
 
+// Host buffers reach the device the way the KMC feed does: two pinned slots filled by a parallel memcpy, a copy stream
+// that moves slot b+1 (hipMemcpyAsync) while the model's stream inserts batch b.  The buffers live on the handle.
+static int ensure_host_feed(kmx_model *m, size_t B, int W)
+{
+	auto &F = m->feed;
+	if (!F.copy) HIPCHK(hipStreamCreateWithFlags(&F.copy, hipStreamNonBlocking));
+	for (int s = 0; s < 2; s++) {
+		if (!F.ev_copied[s]) { HIPCHK(hipEventCreateWithFlags(&F.ev_copied[s], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&F.ev_free[s], hipEventDisableTiming)); }
+		if (F.km_cap < B * (size_t)W) {
+			if (F.km[s]) hipHostFree(F.km[s]);
+			if (F.cnt[s]) hipHostFree(F.cnt[s]);
+			F.km[s] = nullptr; F.cnt[s] = nullptr;
+			HIPCHK(hipHostMalloc((void **)&F.km[s], B * W * 8));
+			HIPCHK(hipHostMalloc((void **)&F.cnt[s], B * 4));
+		}
+		if (F.dk_cap < B * (size_t)W) {
+			hipFree(F.dk[s]); hipFree(F.dc[s]);
+			F.dk[s] = nullptr; F.dc[s] = nullptr;
+			HIPCHK(hipMalloc((void **)&F.dk[s], B * W * 8));
+			HIPCHK(hipMalloc((void **)&F.dc[s], B * 4));
+		}
+	}
+	F.km_cap = std::max(F.km_cap, B * (size_t)W);
+	F.dk_cap = std::max(F.dk_cap, B * (size_t)W);
+	return KMX_OK;
+}
+
+static void parallel_copy(void *dst, const void *src, size_t bytes)
+{
+	const unsigned hw = std::thread::hardware_concurrency();
+	const int T = (int)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(hw ? hw : 1, 16), bytes / (4u << 20) + 1));
+	if (T == 1) { memcpy(dst, src, bytes); return; }
+	std::vector<std::thread> th;
+	const size_t per = ((bytes + T - 1) / T + 4095) & ~size_t(4095);
+	for (int t = 0; t < T; t++)
+		th.emplace_back([=] {
+			const size_t lo = (size_t)t * per, hi = std::min(bytes, lo + per);
+			if (lo < hi) memcpy((char *)dst + lo, (const char *)src + lo, hi - lo);
+		});
+	for (auto &x : th) x.join();
+}
+
 static int kmx_insert_batch_impl(kmx_model *m, const uint64_t *kmers, const uint32_t *counts, uint64_t n)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (m->state != ST_BUILDING) return fail(KMX_E_STATE, "insert_batch before begin");
+	if (!n) return KMX_OK;
+	if (!kmers || !counts) return fail(KMX_E_ARG, "null argument");
 	HIPCHK(hipSetDevice(m->device));
-	u64 *dk = nullptr;
-	u32 *dc = nullptr;
-	const u64 step = std::min<u64>(kChunk, n ? n : 1);
-	HIPCHK(hipMalloc((void **)&dk, step * m->W * 8));
-	HIPCHK(hipMalloc((void **)&dc, step * 4));
-	int rc = KMX_OK;
-	for (u64 done = 0; done < n && !rc; done += step) {
-		const u64 c = std::min<u64>(step, n - done);
-		if (hipMemcpyAsync(dk, kmers + done * m->W, c * m->W * 8, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
-		    hipMemcpyAsync(dc, counts + done, c * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess) { rc = fail(KMX_E_NODEVICE, "H2D copy failed"); break; }
-		rc = kmx_insert_batch_dev(m, (const uint64_t *)dk, dc, c);
+	const size_t B = size_t(1) << 23;
+	const int W = m->W;
+	TRY(ensure_host_feed(m, B, W));
+	auto &F = m->feed;
+	auto drain = scope_exit([&] { hipStreamSynchronize(F.copy); hipStreamSynchronize(m->stream); });   // the caller's buffers and the slots are free on return
+	HIPCHK(hipEventRecord(F.ev_free[0], m->stream));
+	HIPCHK(hipEventRecord(F.ev_free[1], m->stream));
+	auto stage = [&](int s, uint64_t lo, uint64_t c) -> int {        // host -> pinned slot s -> device buffers s, on the copy stream
+		HIPCHK(hipEventSynchronize(F.ev_copied[s]));                 // the previous copy out of this slot (a fresh event is complete)
+		parallel_copy(F.km[s], kmers + lo * W, c * W * 8);
+		parallel_copy(F.cnt[s], counts + lo, c * 4);
+		HIPCHK(hipStreamWaitEvent(F.copy, F.ev_free[s], 0));        // the insert that read the device buffers two batches ago
+		HIPCHK(hipMemcpyAsync(F.dk[s], F.km[s], c * W * 8, hipMemcpyHostToDevice, F.copy));
+		HIPCHK(hipMemcpyAsync(F.dc[s], F.cnt[s], c * 4, hipMemcpyHostToDevice, F.copy));
+		HIPCHK(hipEventRecord(F.ev_copied[s], F.copy));
+		return KMX_OK;
+	};
+	TRY(stage(0, 0, std::min<uint64_t>(B, n)));
+	int s = 0;
+	for (uint64_t done = 0; done < n; s ^= 1) {
+		const uint64_t c = std::min<uint64_t>(B, n - done), next = done + c;
+		if (next < n) TRY(stage(s ^ 1, next, std::min<uint64_t>(B, n - next)));      // copied under this batch's rounds
+		HIPCHK(hipStreamWaitEvent(m->stream, F.ev_copied[s], 0));
+		TRY(kmx_insert_batch_dev(m, (const uint64_t *)F.dk[s], F.dc[s], c));
+		HIPCHK(hipEventRecord(F.ev_free[s], m->stream));
+		done = next;
 	}
-	hipStreamSynchronize(m->stream);
-	hipFree(dk); hipFree(dc);
-	return rc;
+	return KMX_OK;
 }
 
 // KRestData::build (rest.hpp:95-135,157-161) on the device: radix sort of the survivors + index kernels
@@ -968,104 +1080,190 @@ static int kmx_build_host_impl(kmx_model *m, int k, const uint64_t *kmers, const
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (k < 3 || k > 64) return fail(KMX_E_ARG, "k=%d out of range [3,64]", k);
+	if (n && (!kmers || !counts)) return fail(KMX_E_ARG, "null argument");
 	HIPCHK(hipSetDevice(m->device));
-	const int W = (k + 31) / 32;
-	u64 *dk = nullptr;
-	u32 *dc = nullptr;
-	HIPCHK(hipMalloc((void **)&dk, (n ? n : 1) * W * 8));
-	HIPCHK(hipMalloc((void **)&dc, (n ? n : 1) * 4));
-	HIPCHK(hipMemcpy(dk, kmers, n * W * 8, hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(dc, counts, n * 4, hipMemcpyHostToDevice));
-	int rc = build_common(m, k, dk, dc, n, n);
-	hipFree(dk); hipFree(dc);
-	return rc;
+	HIPCHK(hipEventRecord(m->ev0, m->stream));
+	// pass 1 on the host cores (kmodel.hpp:423-428): the class histogram of the caller's counts, in parallel
+	u64 nbf[3] = {0, 0, 0}, bad = 0;
+	{
+		const unsigned hw = std::thread::hardware_concurrency();
+		const int T = (int)std::max<u64>(1, std::min<u64>(std::min<unsigned>(hw ? hw : 1, 16), n / 1000000 + 1));
+		std::vector<u64> acc((size_t)T * 8, 0);
+		auto work = [&](int t) {
+			const u64 per = (n + T - 1) / T, lo = (u64)t * per, hi = std::min<u64>(n, lo + per);
+			u64 a[4] = {0, 0, 0, 0};
+			for (u64 i = lo; i < hi; i++) {
+				const u32 c = counts[i];
+				if (c < (u32)m->ci || c > (u32)m->cs) a[3]++;
+				else if (c < (u32)(m->ci + m->bf_num)) a[c - (u32)m->ci]++;
+			}
+			for (int q = 0; q < 4; q++) acc[(size_t)t * 8 + q] = a[q];
+		};
+		if (T == 1) work(0);
+		else {
+			std::vector<std::thread> th;
+			for (int t = 0; t < T; t++) th.emplace_back(work, t);
+			for (auto &x : th) x.join();
+		}
+		for (int t = 0; t < T; t++) { for (int q = 0; q < 3; q++) nbf[q] += acc[(size_t)t * 8 + q]; bad += acc[(size_t)t * 8 + 3]; }
+	}
+	if (bad) return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)bad, m->ci, m->cs);
+	TRY(kmx_begin(m, k, (const uint64_t *)nbf, n));
+	TRY(kmx_insert_batch(m, kmers, counts, n));                  // pinned double-buffered hipMemcpyAsync under the rounds
+	TRY(kmx_finish(m));
+	HIPCHK(hipEventRecord(m->ev1, m->stream));
+	HIPCHK(hipEventSynchronize(m->ev1));
+	float ms = 0;
+	HIPCHK(hipEventElapsedTime(&ms, m->ev0, m->ev1));
+	m->t_total = ms * 1e-3;
+	return KMX_OK;
 }
 
-// KModel::init(db_file) (kmodel.hpp:57-86).  Pass 1 counts the Bloom classes while listing (kmodel.hpp:423-428);
-// pass 2 streams the listing to the GPU: a producer thread decodes batches (parallel record decode, kmc_reader.cpp)
-// into two pinned buffers while the previous batch is copied (hipMemcpyAsync) and inserted, so the host feed
-// overlaps the kernels.
+// KModel::init(db_file) (kmodel.hpp:57-87).  The host does I/O only: it counts the classes over the record file (pass 1,
+// kmodel.hpp:423-428: one parallel scan of the counter bytes) while a producer thread already copies the RAW records of
+// the first batches into pinned slots; a copy stream moves a slot to the device (hipMemcpyAsync) while the model's stream
+// is still inserting the previous batch; the records are decoded there (k_kmc_decode: prefix lookup, byte swaps,
+// packing) and inserted.  ONE decode of the database, none of it on the host.  Databases that hold records outside the
+// header's [min_count, max_count] (ReadNextKmer skips those; KMC itself never writes them) take the host decoder
+// instead, and so does KMX_KMC_HOST_DECODE=1 (test hook).
+namespace kmxk { void kmc_decode(const KmcDecode &, int, u64, u64, u64 *, u32 *, hipStream_t); }
 namespace {
 struct FeedSlot {
-	u64 *km = nullptr;
+	unsigned char *raw = nullptr;     // GPU decode: record bytes
+	u64 *km = nullptr;                // host decode: packed k-mers / counts
 	u32 *cnt = nullptr;
 	size_t n = 0;
+	uint64_t rec0 = 0;
 	bool full = false, last = false;
 };
 }   // namespace
 
-// KModel::init(db_file) (kmodel.hpp:57-87).  Pass 1 counts the classes on the host (parallel, counts only).  Pass 2 is a
-// three-stage pipeline: a producer thread decodes the listing into two pinned slots; a copy stream moves a slot into
-// one of two device buffers while the model's stream is still inserting the previous batch; the insert itself.
 static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 {
 	if (!m || !db_prefix) return fail(KMX_E_ARG, "null argument");
+	const char *tr = getenv("KMX_INIT_TRACE");                       // wall-clock phase times on stderr (no extra synchronisation)
+	const bool trace = tr && atoi(tr);
+	const auto t_start = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) { if (trace) fprintf(stderr, "[kmx] init(db) %-28s at %7.2f ms\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() * 1e3); };
 	kmx::KmcListing db;
 	if (!db.open(db_prefix)) return fail(KMX_E_IO, "can't open the kmer_data_base %s: %s", db_prefix, db.error().c_str());
 	unsigned hw = std::thread::hardware_concurrency();
-	db.set_threads(hw > 16 ? 16 : (hw ? (int)hw : 1));
+	const int T = hw > 32 ? 16 : (hw > 1 ? (int)hw / 2 : 1);          // per activity: pass 1 and the producer run side by side
+	db.set_threads(T);
 	const int k = (int)db.kmer_length(), W = db.words();
-	const size_t B = size_t(1) << 22;
+	const size_t B = size_t(1) << 23;
+	const size_t rb = db.record_bytes();
 	HIPCHK(hipSetDevice(m->device));
+	lap("database open");
+	const char *force_host = getenv("KMX_KMC_HOST_DECODE");
+	bool gpu_decode = !(force_host && atoi(force_host));
 	FeedSlot slot[2];
-	u64 *dk[2] = {nullptr, nullptr};
-	u32 *dc[2] = {nullptr, nullptr};
-	hipStream_t copy = nullptr;
-	hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+	auto &F = m->feed;
+	std::mutex mu;
+	std::condition_variable cv;
+	bool stop = false;
+	std::thread producer, allocator;
 	auto cleanup = [&] {
-		if (copy) { hipStreamSynchronize(copy); hipStreamDestroy(copy); }
+		{ std::lock_guard<std::mutex> lk(mu); stop = true; for (auto &sl : slot) sl.full = false; }
+		cv.notify_all();
+		if (producer.joinable()) producer.join();
+		if (allocator.joinable()) allocator.join();
+		if (F.copy) hipStreamSynchronize(F.copy);
 		hipStreamSynchronize(m->stream);
-		for (int s = 0; s < 2; s++) {
-			if (slot[s].km) hipHostFree(slot[s].km);
-			if (slot[s].cnt) hipHostFree(slot[s].cnt);
-			hipFree(dk[s]); hipFree(dc[s]);
-			if (ev_copied[s]) hipEventDestroy(ev_copied[s]);
-			if (ev_free[s]) hipEventDestroy(ev_free[s]);
-		}
 	};
+	auto guard = scope_exit(cleanup);                                // also when something throws (bad_alloc in pass 1): threads are joined before the frame goes
 	hipEventRecord(m->ev0, m->stream);
-	// the buffers of pass 2 are allocated beside pass 1 (pinned allocations take ~10 ms)
+	// the buffers of pass 2 are (re)allocated beside pass 1 when this database needs larger ones than the handle holds
 	bool ok = false;
-	std::thread allocator([&] {
+	allocator = std::thread([&] {
 		if (hipSetDevice(m->device) != hipSuccess) return;
-		bool good = hipStreamCreateWithFlags(&copy, hipStreamNonBlocking) == hipSuccess;
-		for (int s = 0; s < 2 && good; s++)
-			good = hipHostMalloc((void **)&slot[s].km, B * W * 8) == hipSuccess && hipHostMalloc((void **)&slot[s].cnt, B * 4) == hipSuccess &&
-			       hipMalloc((void **)&dk[s], B * W * 8) == hipSuccess && hipMalloc((void **)&dc[s], B * 4) == hipSuccess &&
-			       hipEventCreateWithFlags(&ev_copied[s], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev_free[s], hipEventDisableTiming) == hipSuccess;
+		bool good = F.copy || hipStreamCreateWithFlags(&F.copy, hipStreamNonBlocking) == hipSuccess;
+		for (int s = 0; s < 2 && good; s++) {
+			if (!F.ev_copied[s]) good = hipEventCreateWithFlags(&F.ev_copied[s], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&F.ev_free[s], hipEventDisableTiming) == hipSuccess;
+			if (good && F.raw_cap < B * rb + 16) {
+				if (F.raw[s]) hipHostFree(F.raw[s]);
+				hipFree(F.draw[s]);
+				F.raw[s] = nullptr; F.draw[s] = nullptr;
+				good = hipHostMalloc((void **)&F.raw[s], B * rb + 16) == hipSuccess && hipMalloc((void **)&F.draw[s], B * rb + 16) == hipSuccess;
+			}
+			if (good && F.dk_cap < B * (size_t)W) {
+				hipFree(F.dk[s]); hipFree(F.dc[s]);
+				F.dk[s] = nullptr; F.dc[s] = nullptr;
+				good = hipMalloc((void **)&F.dk[s], B * W * 8) == hipSuccess && hipMalloc((void **)&F.dc[s], B * 4) == hipSuccess;
+			}
+		}
+		if (good) { F.raw_cap = std::max(F.raw_cap, B * rb + 16); F.dk_cap = std::max(F.dk_cap, B * (size_t)W); }
+		const std::vector<uint64_t> &lut = db.lut();
+		if (good && F.lut_cap < lut.size()) {
+			hipFree(F.d_lut); F.d_lut = nullptr;
+			good = hipMalloc((void **)&F.d_lut, lut.size() * 8) == hipSuccess;
+			if (good) F.lut_cap = lut.size();
+		}
+		if (good) good = hipMemcpy(F.d_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+		if (!good) F.raw_cap = F.dk_cap = 0;                         // whatever is half there is replaced next time
 		ok = good;
 	});
-	uint64_t nbf[3] = {0, 0, 0};
+	uint64_t nbf[3] = {0, 0, 0}, bad = 0, not_listed = 0;
 	int rc = KMX_OK;
-	uint64_t bad = 0;
 	const auto t_p1 = std::chrono::steady_clock::now();
-	db.count_classes((u32)m->ci, (u32)m->cs, m->bf_num, nbf, &bad);          // pass 1 (kmodel.hpp:423-428), parallel, counts only
+	db.count_classes((u32)m->ci, (u32)m->cs, m->bf_num, nbf, &bad, &not_listed);      // pass 1 (kmodel.hpp:423-428), counts only
 	const double s_p1 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_p1).count();
+	lap("pass 1 done");
 	allocator.join();
-	if (!ok) { cleanup(); return fail(KMX_E_NOMEM, "pinned / device buffers for the listing feed could not be allocated"); }
-	if (bad) rc = fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)bad, m->ci, m->cs);
-	if (!rc) rc = kmx_begin(m, k, nbf, db.kmer_count());
-	double s_wait = 0;
-	if (!rc) {
-		db.restart();                                                          // kmodel.hpp:430
-		std::mutex mu;
-		std::condition_variable cv;
-		std::thread producer([&] {
+	lap("buffers ready");
+	if (!ok) return fail(KMX_E_NOMEM, "pinned / device buffers for the listing feed could not be allocated");
+	if (not_listed) gpu_decode = false;
+	if (!gpu_decode && F.km_cap < B * (size_t)W) {                   // host decoder: pinned k-mer / count slots
+		for (int s = 0; s < 2 && !rc; s++) {
+			if (F.km[s]) hipHostFree(F.km[s]);
+			if (F.cnt[s]) hipHostFree(F.cnt[s]);
+			F.km[s] = nullptr; F.cnt[s] = nullptr;
+			if (hipHostMalloc((void **)&F.km[s], B * W * 8) != hipSuccess || hipHostMalloc((void **)&F.cnt[s], B * 4) != hipSuccess) rc = fail(KMX_E_NOMEM, "pinned buffers for the listing feed could not be allocated");
+		}
+		F.km_cap = rc ? 0 : B * (size_t)W;
+	}
+	for (int s = 0; s < 2; s++) { slot[s].raw = F.raw[s]; slot[s].km = F.km[s]; slot[s].cnt = F.cnt[s]; }
+	// the producer fills the two slots in turn: raw records (a parallel memcpy out of the page cache) or, in host mode, decoded k-mers
+	if (!rc)
+		producer = std::thread([&] {
+			uint64_t rec = 0;
+			db.restart();                                                    // kmodel.hpp:430
 			for (int s = 0;; s ^= 1) {
-				{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !slot[s].full; }); }
-				const size_t got = db.next_batch((uint64_t *)slot[s].km, slot[s].cnt, B);
-				{ std::lock_guard<std::mutex> lk(mu); slot[s].n = got; slot[s].last = got == 0; slot[s].full = true; }
+				{
+					std::unique_lock<std::mutex> lk(mu);
+					cv.wait(lk, [&] { return !slot[s].full || stop; });
+					if (stop) return;
+				}
+				size_t got;
+				const uint64_t rec0 = rec;
+				if (gpu_decode) {
+					got = (size_t)std::min<uint64_t>(B, db.records() > rec ? db.records() - rec : 0);
+					if (got) db.copy_records(rec, got, slot[s].raw);
+					rec += got;
+				} else got = db.next_batch((uint64_t *)slot[s].km, slot[s].cnt, B);
+				{ std::lock_guard<std::mutex> lk(mu); slot[s].n = got; slot[s].rec0 = rec0; slot[s].last = got == 0; slot[s].full = true; }
 				cv.notify_all();
-				if (!got) break;
+				if (!got) return;
 			}
 		});
-		// pass 2 (kmodel.hpp:68-74).  Batch b travels through slot b%2 and device buffer b%2; its copy is enqueued one
+	if (!rc && bad) rc = fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)bad, m->ci, m->cs);
+	if (!rc) rc = kmx_begin(m, k, nbf, db.kmer_count());
+	lap("begin returned");
+	double s_wait = 0;
+	if (!rc) {
+		KmcDecode kd;
+		kd.lut = F.d_lut; kd.n_lut = db.lut().size() - 1; kd.prefix_mask = db.prefix_mask();
+		kd.rec_bytes = (u32)rb; kd.suf_bytes = db.suffix_bytes(); kd.cnt_bytes = db.counter_bytes();
+		// pass 2 (kmodel.hpp:68-74).  Batch b travels through slot b%2 and device buffers b%2; its copy is enqueued one
 		// batch ahead of its insert, so it runs under the rounds of batch b-1.
 		auto enqueue_copy = [&](int s) -> bool {                               // slot s is full
-			if (hipStreamWaitEvent(copy, ev_free[s], 0) != hipSuccess) return false;      // the insert that read dk[s] two batches ago
-			if (hipMemcpyAsync(dk[s], slot[s].km, slot[s].n * W * 8, hipMemcpyHostToDevice, copy) != hipSuccess) return false;
-			if (hipMemcpyAsync(dc[s], slot[s].cnt, slot[s].n * 4, hipMemcpyHostToDevice, copy) != hipSuccess) return false;
-			return hipEventRecord(ev_copied[s], copy) == hipSuccess;
+			if (hipStreamWaitEvent(F.copy, F.ev_free[s], 0) != hipSuccess) return false;      // the insert that read the device buffers two batches ago
+			if (gpu_decode) { if (hipMemcpyAsync(F.draw[s], slot[s].raw, slot[s].n * rb, hipMemcpyHostToDevice, F.copy) != hipSuccess) return false; }
+			else {
+				if (hipMemcpyAsync(F.dk[s], slot[s].km, slot[s].n * W * 8, hipMemcpyHostToDevice, F.copy) != hipSuccess) return false;
+				if (hipMemcpyAsync(F.dc[s], slot[s].cnt, slot[s].n * 4, hipMemcpyHostToDevice, F.copy) != hipSuccess) return false;
+			}
+			return hipEventRecord(F.ev_copied[s], F.copy) == hipSuccess;
 		};
 		auto wait_full = [&](int s) {
 			const auto t0 = std::chrono::steady_clock::now();
@@ -1077,38 +1275,39 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 			{ std::lock_guard<std::mutex> lk(mu); slot[s].full = false; }
 			cv.notify_all();
 		};
-		hipEventRecord(ev_free[0], m->stream);
-		hipEventRecord(ev_free[1], m->stream);
+		hipEventRecord(F.ev_free[0], m->stream);
+		hipEventRecord(F.ev_free[1], m->stream);
 		wait_full(0);
 		bool copied = !slot[0].last && enqueue_copy(0);
 		if (!slot[0].last && !copied) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
 		for (int s = 0; !slot[s].last; s ^= 1) {
 			const size_t n = slot[s].n;
-			// the next batch: decoded meanwhile by the producer, copied under this batch's rounds
+			// the next batch: produced meanwhile, copied under this batch's rounds
 			wait_full(s ^ 1);
 			if (!rc && !slot[s ^ 1].last && !enqueue_copy(s ^ 1)) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
 			if (!rc) {
-				if (hipStreamWaitEvent(m->stream, ev_copied[s], 0) != hipSuccess) rc = fail(KMX_E_NODEVICE, "stream wait failed");
-				else rc = kmx_insert_batch_dev(m, (const uint64_t *)dk[s], dc[s], n);
-				hipEventRecord(ev_free[s], m->stream);                       // everything that reads dk[s] is enqueued by now
+				if (hipStreamWaitEvent(m->stream, F.ev_copied[s], 0) != hipSuccess) rc = fail(KMX_E_NODEVICE, "stream wait failed");
+				else {
+					if (gpu_decode) { kd.recs = F.draw[s]; kmxk::kmc_decode(kd, W, slot[s].rec0, n, F.dk[s], F.dc[s], m->stream); }
+					rc = kmx_insert_batch_dev(m, (const uint64_t *)F.dk[s], F.dc[s], n);
+				}
+				hipEventRecord(F.ev_free[s], m->stream);                       // everything that reads the device buffers of s is enqueued by now
 			}
-			hipEventSynchronize(ev_copied[s]);                               // the pinned slot has been read
+			hipEventSynchronize(F.ev_copied[s]);                               // the pinned slot has been read
 			release(s);
 		}
-		// let the producer run to its end on every path
-		for (int s = 0; s < 2; s++) release(s);
-		producer.join();
 	}
+	lap("all batches enqueued");
 	if (!rc) rc = kmx_finish(m);
+	lap("finish returned");
 	if (!rc) {
 		hipEventRecord(m->ev1, m->stream);
 		hipEventSynchronize(m->ev1);
 		float ms = 0;
 		hipEventElapsedTime(&ms, m->ev0, m->ev1);
 		m->t_total = ms * 1e-3;
-		if (m->dbg_ctrl) fprintf(stderr, "[kmx] init(db): pass 1 %.1f ms, waited %.1f ms for the listing in pass 2, total %.1f ms\n", s_p1 * 1e3, s_wait * 1e3, (double)ms);
+		if (m->dbg_ctrl) fprintf(stderr, "[kmx] init(db): pass 1 %.1f ms, waited %.1f ms for the listing in pass 2, total %.1f ms (%s decode)\n", s_p1 * 1e3, s_wait * 1e3, (double)ms, gpu_decode ? "GPU" : "host");
 	}
-	cleanup();
 	return rc;
 }
 
@@ -1350,15 +1549,13 @@ static int kmx_query_packed_impl(kmx_model *m, const uint64_t *kmers, uint64_t n
 	if (m->state != ST_READY) return fail(KMX_E_STATE, "query before the model is built or loaded");
 	if (!n) return KMX_OK;
 	HIPCHK(hipSetDevice(m->device));
-	u64 *dk = nullptr;
-	int *dout = nullptr;
-	HIPCHK(hipMalloc((void **)&dk, n * m->W * 8));
-	HIPCHK(hipMalloc((void **)&dout, n * 4));
-	HIPCHK(hipMemcpyAsync(dk, kmers, n * m->W * 8, hipMemcpyHostToDevice, m->stream));
-	int rc = kmx_query_packed_dev(m, (const uint64_t *)dk, n, dout);
-	if (!rc && hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "D2H copy failed");
-	hipStreamSynchronize(m->stream);
-	hipFree(dk); hipFree(dout);
+	DevMem dk, dout;
+	HIPCHK(dk.alloc(n * m->W * 8));
+	HIPCHK(dout.alloc(n * 4));
+	int rc = hipMemcpyAsync(dk.p, kmers, n * m->W * 8, hipMemcpyHostToDevice, m->stream) == hipSuccess ? KMX_OK : fail(KMX_E_NODEVICE, "H2D copy failed");
+	if (!rc) rc = kmx_query_packed_dev(m, dk.as<uint64_t>(), n, dout.as<int32_t>());
+	if (!rc && hipMemcpyAsync(out, dout.p, n * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "D2H copy failed");
+	if (hipStreamSynchronize(m->stream) != hipSuccess && !rc) rc = fail(KMX_E_NODEVICE, "query failed");
 	return rc;
 }
 
@@ -1417,20 +1614,18 @@ static int query_text(kmx_model *m, PTR ptr_of, const char *flat, int len, int s
 		stride = len;
 	}
 	HIPCHK(hipSetDevice(m->device));
-	unsigned char *ds = nullptr;
-	int *dout = nullptr;
+	DevMem ds, dout;
 	const u64 bytes = (n - 1) * (u64)stride + (u64)len;
-	HIPCHK(hipMalloc((void **)&ds, bytes));
-	HIPCHK(hipMalloc((void **)&dout, n * 4));
+	HIPCHK(ds.alloc(bytes));
+	HIPCHK(dout.alloc(n * 4));
 	int rc = KMX_OK;
-	if (hipMemcpyAsync(ds, flat, bytes, hipMemcpyHostToDevice, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
+	if (hipMemcpyAsync(ds.p, flat, bytes, hipMemcpyHostToDevice, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
 	if (!rc) {
-		kmxk::query_ascii(m->md, len, ds, stride, n, dout, m->stream);
-		if (hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "D2H copy failed");
+		kmxk::query_ascii(m->md, len, ds.as<unsigned char>(), stride, n, dout.as<int>(), m->stream);
+		if (hipMemcpyAsync(out, dout.p, n * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "D2H copy failed");
 	}
 	hipStreamSynchronize(m->stream);
 	if (!rc && hipGetLastError() != hipSuccess) rc = fail(KMX_E_NODEVICE, "query kernel failed");
-	hipFree(ds); hipFree(dout);
 	return rc;
 }
 
@@ -1463,13 +1658,11 @@ static int download_array(kmx_model *m, int which, int index, std::vector<unsign
 	const u64 nbytes = m->km_byte_size;
 	out.resize(nbytes);
 	if (!nbytes) return KMX_OK;
-	unsigned char *tmp = nullptr;
-	HIPCHK(hipMalloc((void **)&tmp, m->ncells * 2));
-	kmxk::cells_to_disk(m->d_cells[index], m->ncells, nbytes, which - 3, tmp, m->stream);
-	hipError_t e = hipMemcpyAsync(out.data(), tmp, nbytes, hipMemcpyDeviceToHost, m->stream);
-	hipStreamSynchronize(m->stream);
-	hipFree(tmp);
-	if (e != hipSuccess) return fail(KMX_E_NODEVICE, "D2H copy failed");
+	DevMem tmp;
+	HIPCHK(tmp.alloc(m->ncells * 2));
+	kmxk::cells_to_disk(m->d_cells[index], m->ncells, nbytes, which - 3, tmp.as<unsigned char>(), m->stream);
+	hipError_t e = hipMemcpyAsync(out.data(), tmp.p, nbytes, hipMemcpyDeviceToHost, m->stream);
+	if (hipStreamSynchronize(m->stream) != hipSuccess || e != hipSuccess) return fail(KMX_E_NODEVICE, "D2H copy failed");
 	return KMX_OK;
 }
 
@@ -1590,8 +1783,8 @@ static int kmx_save_impl(kmx_model *m, const char *dir)
 	std::string d(dir);
 	FILE *f = fopen((d + "/header").c_str(), "w");
 	if (!f) return fail(KMX_E_IO, "cannot write %s/header", dir);
-	fprintf(f, "number_hash %d\nnumber_bit %d\nci %d\ncs %d\n", m->nh, m->nb, m->ci, m->cs);
-	fclose(f);
+	const bool header_ok = fprintf(f, "number_hash %d\nnumber_bit %d\nci %d\ncs %d\n", m->nh, m->nb, m->ci, m->cs) > 0;
+	if ((fclose(f) != 0) | !header_ok) return fail(KMX_E_IO, "short write to %s/header", dir);
 	const auto t0 = std::chrono::steady_clock::now();
 	TRY(save_km_bin(m, d + "/km.bin"));
 	const auto t1 = std::chrono::steady_clock::now();
@@ -1600,14 +1793,12 @@ static int kmx_save_impl(kmx_model *m, const char *dir)
 	const RestTable &r = m->rest;
 	if (!(f = fopen((d + "/rest.bin").c_str(), "wb"))) return fail(KMX_E_IO, "cannot write %s/rest.bin", dir);
 	int h[4] = {r.k, r.pre_len, r.map_size, r.pre_buffer_size};
-	fwrite(h, 4, 4, f);
-	fwrite(&r.suff_bin_size, 8, 1, f);
-	fwrite(&r.entries, 8, 1, f);
-	fwrite(r.hash2index.data(), 4, r.hash2index.size(), f);
-	fwrite(r.pre_buffer.data(), 4, r.pre_buffer.size(), f);
-	fwrite(r.suffix_bin.data(), 1, r.suffix_bin.size(), f);
-	fwrite(r.count_bin.data(), 4, r.count_bin.size(), f);
-	fclose(f);
+	bool w_ok = fwrite(h, 4, 4, f) == 4 && fwrite(&r.suff_bin_size, 8, 1, f) == 1 && fwrite(&r.entries, 8, 1, f) == 1;
+	w_ok = w_ok && fwrite(r.hash2index.data(), 4, r.hash2index.size(), f) == r.hash2index.size();
+	w_ok = w_ok && fwrite(r.pre_buffer.data(), 4, r.pre_buffer.size(), f) == r.pre_buffer.size();
+	w_ok = w_ok && fwrite(r.suffix_bin.data(), 1, r.suffix_bin.size(), f) == r.suffix_bin.size();
+	w_ok = w_ok && fwrite(r.count_bin.data(), 4, r.count_bin.size(), f) == r.count_bin.size();
+	if ((fclose(f) != 0) | !w_ok) return fail(KMX_E_IO, "short write to %s/rest.bin", dir);
 	if (m->dbg_ctrl) {
 		const auto t3 = std::chrono::steady_clock::now();
 		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count() * 1e3; };
@@ -1654,6 +1845,15 @@ static int kmx_load_impl(const char *dir, kmx_model **out)
 		     fread(r.count_bin.data(), 4, r.entries, f) == r.entries;
 	}
 	fclose(f);
+	if (ok) {   // the device lookup indexes with these: a corrupt file must end as KMX_E_IO, not as an out-of-bounds read
+		ok = r.pre_buffer[0] == 0 && (u64)r.pre_buffer[r.pre_buffer_size - 1] == r.entries && r.pre_buffer_size - 1 <= r.map_size;
+		for (int g = 1; g < r.pre_buffer_size && ok; g++) ok = r.pre_buffer[g] >= r.pre_buffer[g - 1];
+		int next_group = 0;                                         // groups are numbered in ascending prefix order (rest.hpp:113-127)
+		for (int q = 0; q < r.map_size && ok; q++)
+			if (r.hash2index[q] != -1) ok = r.hash2index[q] == next_group++;
+		ok = ok && next_group == r.pre_buffer_size - 1;
+		for (u64 e = 0; e < r.entries && ok; e++) ok = r.count_bin[e] >= ci && r.count_bin[e] <= cs;
+	}
 	if (!ok) return bail(fail(KMX_E_IO, "malformed %s/rest.bin", dir));
 	m->k = r.k; m->W = (r.k + 31) / 32;
 	// km.bin is mapped and copied to the device section by section, without a staging read
@@ -1737,16 +1937,14 @@ static int kmx_debug_hash_impl(int k, const uint64_t *kmers, uint64_t n, const u
 {
 	if (k < 3 || k > 64 || n_seeds < 1) return fail(KMX_E_ARG, "bad arguments");
 	const int W = (k + 31) / 32;
-	u64 *dk = nullptr, *dh = nullptr;
-	u32 *ds = nullptr;
-	HIPCHK(hipMalloc((void **)&dk, n * W * 8 + 8));
-	HIPCHK(hipMalloc((void **)&dh, n * n_seeds * 8 + 8));
-	HIPCHK(hipMalloc((void **)&ds, n_seeds * 4));
-	HIPCHK(hipMemcpy(dk, kmers, n * W * 8, hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(ds, seeds, n_seeds * 4, hipMemcpyHostToDevice));
-	kmxk::debug_hash(k, dk, n, ds, n_seeds, whole, dh, nullptr);
-	HIPCHK(hipMemcpy(hashes, dh, n * n_seeds * 8, hipMemcpyDeviceToHost));
-	hipFree(dk); hipFree(dh); hipFree(ds);
+	DevMem dk, dh, ds;
+	HIPCHK(dk.alloc(n * W * 8 + 8));
+	HIPCHK(dh.alloc(n * n_seeds * 8 + 8));
+	HIPCHK(ds.alloc(n_seeds * 4));
+	HIPCHK(hipMemcpy(dk.p, kmers, n * W * 8, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(ds.p, seeds, n_seeds * 4, hipMemcpyHostToDevice));
+	kmxk::debug_hash(k, dk.as<u64>(), n, ds.as<u32>(), n_seeds, whole, dh.as<u64>(), nullptr);
+	HIPCHK(hipMemcpy(hashes, dh.p, n * n_seeds * 8, hipMemcpyDeviceToHost));
 	return KMX_OK;
 }
 
@@ -1754,38 +1952,38 @@ static int kmx_debug_min_kmer_impl(int k, const uint64_t *kmers, uint64_t n, uin
 {
 	if (k < 3 || k > 64) return fail(KMX_E_ARG, "bad arguments");
 	const int W = (k + 31) / 32;
-	u64 *dk = nullptr, *dout = nullptr;
-	HIPCHK(hipMalloc((void **)&dk, n * W * 8 + 8));
-	HIPCHK(hipMalloc((void **)&dout, n * W * 8 + 8));
-	HIPCHK(hipMemcpy(dk, kmers, n * W * 8, hipMemcpyHostToDevice));
-	kmxk::debug_min_kmer(k, dk, n, dout, nullptr);
-	HIPCHK(hipMemcpy(out, dout, n * W * 8, hipMemcpyDeviceToHost));
-	hipFree(dk); hipFree(dout);
+	DevMem dk, dout;
+	HIPCHK(dk.alloc(n * W * 8 + 8));
+	HIPCHK(dout.alloc(n * W * 8 + 8));
+	HIPCHK(hipMemcpy(dk.p, kmers, n * W * 8, hipMemcpyHostToDevice));
+	kmxk::debug_min_kmer(k, dk.as<u64>(), n, dout.as<u64>(), nullptr);
+	HIPCHK(hipMemcpy(out, dout.p, n * W * 8, hipMemcpyDeviceToHost));
 	return KMX_OK;
 }
 
 static int kmx_debug_mod_impl(const uint64_t *h, uint64_t n, uint64_t d, uint64_t *out)
 {
 	if (!d || !n) return fail(KMX_E_ARG, "bad arguments");
-	u64 *dh = nullptr, *dout = nullptr;
-	HIPCHK(hipMalloc((void **)&dh, n * 8));
-	HIPCHK(hipMalloc((void **)&dout, n * 8));
-	HIPCHK(hipMemcpy(dh, h, n * 8, hipMemcpyHostToDevice));
-	kmxk::debug_mod(dh, n, d, dout, nullptr);
-	HIPCHK(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
-	hipFree(dh); hipFree(dout);
+	DevMem dh, dout;
+	HIPCHK(dh.alloc(n * 8));
+	HIPCHK(dout.alloc(n * 8));
+	HIPCHK(hipMemcpy(dh.p, h, n * 8, hipMemcpyHostToDevice));
+	kmxk::debug_mod(dh.as<u64>(), n, d, dout.as<u64>(), nullptr);
+	HIPCHK(hipMemcpy(out, dout.p, n * 8, hipMemcpyDeviceToHost));
 	return KMX_OK;
 }
 
 static int kmx_microbench_impl(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds)
 {
 	if (bytes < 4096 || touches < 8 || iters < 1 || !seconds) return fail(KMX_E_ARG, "bad arguments");
-	u64 *buf = nullptr, *sink = nullptr;
+	DevMem bufm, sinkm;
 	const u64 ncell = bytes / 8, lanes = touches / 8;
-	HIPCHK(hipMalloc((void **)&buf, ncell * 8));
-	HIPCHK(hipMalloc((void **)&sink, 8));
+	HIPCHK(bufm.alloc(ncell * 8));
+	HIPCHK(sinkm.alloc(8));
+	u64 *buf = bufm.as<u64>(), *sink = sinkm.as<u64>();
 	HIPCHK(hipMemset(buf, 0, ncell * 8));
-	hipEvent_t e0, e1;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	auto ev_guard = scope_exit([&] { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); });
 	HIPCHK(hipEventCreate(&e0));
 	HIPCHK(hipEventCreate(&e1));
 	kmxk::micro(mode, buf, ncell, lanes, 12345, sink, nullptr);            // warm-up
@@ -1796,8 +1994,6 @@ static int kmx_microbench_impl(int mode, uint64_t bytes, uint64_t touches, int i
 	float ms = 0;
 	HIPCHK(hipEventElapsedTime(&ms, e0, e1));
 	*seconds = ms * 1e-3 / iters;
-	hipEventDestroy(e0); hipEventDestroy(e1);
-	hipFree(buf); hipFree(sink);
 	return KMX_OK;
 }
 

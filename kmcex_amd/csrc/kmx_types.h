@@ -46,6 +46,15 @@ struct BitScatter {
 	int *cnt;                // [BS_BINS], reset by k_bs_apply
 };
 
+// Raw KMC records on the device (k_kmc_decode): fixed-size [suffix bytes big-endian | counter bytes little-endian];
+// record r carries the prefix idx & prefix_mask of the LUT entry with lut[idx] <= r < lut[idx + 1] (kmc_file.cpp:439-478).
+struct KmcDecode {
+	const unsigned char *recs;   // records of this batch
+	const u64 *lut;              // n_lut entries + sentinel
+	u64 n_lut, prefix_mask;
+	u32 rec_bytes, suf_bytes, cnt_bytes;
+};
+
 // device-side statistics (one u64 each)
 enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_MAX_U0, ST_MAX_UFIN, ST_N };
 

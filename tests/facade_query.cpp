@@ -26,5 +26,18 @@ int main(int argc, char **argv)
 	for (size_t i = 0; i < mixed.size(); i++)
 		if (i % 3 != 1 && m2[i] != occ[i]) return 4;
 	delete km;
+	// written the way the reference's README and main.cpp are: std names unqualified (the reference header leaks
+	// `using namespace std;`), Tools::get_file_name (main.cpp:146), a default-constructed KModel filled by load (kmodel.hpp:43, :209)
+	string dir = argv[1];
+	if (Tools::get_file_name("/a/b/" + Tools::get_file_name(dir)) != Tools::get_file_name(dir)) return 5;
+	KModel fresh;
+	fresh.load(dir);
+	vector<string> few(q.begin(), q.begin() + (q.size() < 100 ? q.size() : 100));
+	vector<int> again = fresh.kmer_to_occ(few);
+	for (size_t i = 0; i < few.size(); i++)
+		if (again[i] != occ[i]) return 6;
+	fresh.load_model(dir);                                            // a second load replaces the first
+	if (fresh.kmer_to_occ(few[0]) != occ[0]) return 7;
+	cout.flush();
 	return 0;
 }

@@ -1,7 +1,11 @@
-"""GPU, BASELINE.json's full single-GPU size (configs[1]: 10^8 synthetic 31-mers, nh=7 nb=5 ci=1): the oracle would take
-minutes there, so the hot path is checked through size-independent properties; a 2*10^7 build is still compared with the
-oracle byte for byte."""
+"""GPU, BASELINE.json's full single-GPU sizes.  configs[1] (10^8 synthetic 31-mers, nh=7 nb=5 ci=1) and configs[2]
+(HC14 scale, 2.5*10^9 31-mers, ci=1 cs=1023): the oracle would take minutes to a quarter of an hour there, so the hot path
+is checked through size-independent properties, and at HC14 scale against array digests pinned from ONE oracle-verified
+run (tests/golden/hc14_scale.json, written by tools/bigscale.py --oracle --golden).  A 2*10^7 build (k=31) and a 2*10^7
+build of configs[4]'s shape (k=55 nh=9 nb=6 cs=4095) are still compared with the oracle byte for byte."""
 import hashlib
+import json
+import os
 
 import numpy as np
 import pytest
@@ -84,3 +88,69 @@ def test_hundred_million_properties():
     m.kmer_to_occ_dev(absent.data_ptr(), absent.numel(), out3.data_ptr())
     torch.cuda.synchronize()
     assert int((out3 != 0).sum()) < 0.02 * absent.numel()
+
+
+def test_k55_twenty_million_matches_oracle_bytes():
+    """configs[4]'s shape on one GPU: two-word k-mers, nh = 9 (the wide-template kernels), nb = 6, cs = 4095; 12 blocks."""
+    k, ci, cs, nh, nb = 55, 1, 4095, 9, 6
+    km, cnt = synth.make_stream(20_000_000, k, ci, cs)
+    m = KModel(ci, cs, nh, nb)
+    m.build_packed(k, km, cnt)
+    o = O.OracleModel(ci, cs, nh, nb)
+    o.build(k, km, cnt)
+    st, so = m.stats(), o.stats()
+    assert (st.attempts, st.successes, st.rest_entries) == (so.attempts, so.successes, so.rest_entries)
+    assert st.blocks >= 12
+    for a in range(nb):
+        assert _sha(m.download("tag", a)) == _sha(o.array_bytes("tag", a))
+        assert _sha(m.download("value", a)) == _sha(o.array_bytes("value", a))
+    assert _sha(m.download("km_back")) == _sha(o.array_bytes("km_back"))
+    assert _sha(m.download("bf", 0)) == _sha(o.array_bytes("bf", 0)) and _sha(m.download("bf_back", 0)) == _sha(o.array_bytes("bf_back", 0))
+    q = np.concatenate([km[::7], synth.revcomp(km[1::11], k), synth.random_kmers(200_000, k, seed_k=0xABCDEF0123)])
+    assert np.array_equal(m.kmer_to_occ_packed(q), o.query_packed(k, q, threads=32))
+
+
+HC14_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hc14_scale.json")
+
+
+def test_hc14_scale_properties():
+    """BASELINE configs[2]: 2.5*10^9 synthetic 31-mers, ci=1 cs=1023 nh=7 nb=5 on ONE GPU (7.6*10^9 positions per array,
+    beyond 2^32).  Conservation, tag/value invariant, encode -> query round trip, strand symmetry, false-positive bound; the
+    statistics and the digests of all ten arrays + km_back + the Bloom filter equal the ones pinned from the oracle-verified run."""
+    dev = torch.device("cuda", 0)
+    km, cnt = synth_torch.make_stream(2_500_000_000, K, CI, CS, dev)
+    n = km.numel()
+    torch.cuda.empty_cache()
+    m = KModel(CI, CS, NH, NB)
+    m.build_dev(K, km.data_ptr(), cnt.data_ptr(), n)
+    st = m.stats()
+    assert st.km_byte_size * 8 > 2 ** 32
+    assert st.successes + st.rest_entries >= st.n_km and st.successes + st.rest_entries - st.n_km < NB
+    assert st.attempts >= st.n_km and st.fast_commits + st.contended >= st.successes
+    digests = {}
+    for a in range(NB):
+        tag, val = m.download("tag", a), m.download("value", a)
+        assert not (val & ~tag).any()
+        digests[f"tag{a}"], digests[f"value{a}"] = _sha(tag), _sha(val)
+        del tag, val
+    digests["km_back"], digests["bf0"], digests["bf_back0"] = _sha(m.download("km_back")), _sha(m.download("bf", 0)), _sha(m.download("bf_back", 0))
+    sample = km[:: 25]                                                   # 10^8 of the inserted k-mers
+    out = torch.empty(sample.numel(), dtype=torch.int32, device=dev)
+    m.kmer_to_occ_dev(sample.data_ptr(), sample.numel(), out.data_ptr())
+    torch.cuda.synchronize()
+    assert int((out != 0).sum()) >= sample.numel() - sample.numel() // 200
+    rc = synth_torch.revcomp(sample[: 5_000_000], K)
+    out2 = torch.empty(rc.numel(), dtype=torch.int32, device=dev)
+    m.kmer_to_occ_dev(rc.data_ptr(), rc.numel(), out2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out[: 5_000_000])
+    absent = synth_torch.random_kmers(5_000_000, K, 0xABCDEF0123, dev)
+    out3 = torch.empty(absent.numel(), dtype=torch.int32, device=dev)
+    m.kmer_to_occ_dev(absent.data_ptr(), absent.numel(), out3.data_ptr())
+    torch.cuda.synchronize()
+    assert int((out3 != 0).sum()) < 0.02 * absent.numel()
+    assert os.path.exists(HC14_GOLDEN), "tests/golden/hc14_scale.json is missing (tools/bigscale.py 2.5e9 --oracle --golden)"
+    g = json.load(open(HC14_GOLDEN))
+    assert n == g["n_kmers"]
+    assert (st.n_km, st.attempts, st.successes, st.rest_entries) == (g["stats"]["n_km"], g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
+    assert digests == g["sha256"]

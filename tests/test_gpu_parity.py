@@ -137,6 +137,51 @@ def test_init_from_kmc_database(golden, tmp_path):
         assert sha_file(os.path.join(out, f)) == sha_file(os.path.join(d, f)), f
 
 
+@pytest.mark.parametrize("host_decode", [0, 1], ids=["gpu_decode", "host_decode"])
+def test_init_decoders_agree(host_decode, monkeypatch, tmp_path):
+    """KModel::init(db): the raw-record feed decoded on the GPU (k_kmc_decode) and the host decoder (kept for databases
+    with unlisted records; forced here by KMX_KMC_HOST_DECODE=1) give the resident build's arrays -- KMC1 and KMC2 layouts,
+    one- and two-word k-mers, several batches of 2^22 records."""
+    monkeypatch.setenv("KMX_KMC_HOST_DECODE", str(host_decode))
+    for k, ci, cs, nh, nb, n, layout in ((31, 1, 1023, 7, 5, 9_000_000, "kmc1"), (55, 2, 4095, 9, 6, 300_000, "kmc2"), (23, 1, 255, 6, 3, 50_000, "kmc2")):
+        km, cnt = synth.make_stream(n, k, ci, cs, seed_k=31, seed_c=32)
+        db = str(tmp_path / f"db_{k}")
+        if layout == "kmc1":
+            kmcdb.write_kmc1(db, km, cnt, k, ci, cs)
+            lk, lc = km, cnt
+        else:
+            order = kmcdb.write_kmc2(db, km, cnt, k, ci, cs, n_bins=5)
+            lk, lc = km[order], cnt[order]
+        m = KModel(ci, cs, nh, nb)
+        m.init(db)
+        r = KModel(ci, cs, nh, nb)
+        r.build_packed(k, lk, lc)
+        for a in range(nb):
+            assert np.array_equal(m.download("tag", a), r.download("tag", a)) and np.array_equal(m.download("value", a), r.download("value", a))
+        assert np.array_equal(m.download("km_back"), r.download("km_back")) and np.array_equal(m.download("bf", 0), r.download("bf", 0))
+        sm, sr = m.stats(), r.stats()
+        assert (sm.attempts, sm.successes, sm.rest_entries) == (sr.attempts, sr.successes, sr.rest_entries)
+        m.close(); r.close()
+    monkeypatch.delenv("KMX_KMC_HOST_DECODE")
+
+
+def test_init_skips_records_outside_the_header_range(tmp_path):
+    """ReadNextKmer skips records whose count lies outside the header's [min_count, max_count] (kmc_file.cpp:513); KMC
+    never writes such a file, but a listing must not contain them.  Header says min_count = 3, a third of the records hold less."""
+    k, cs, nh, nb = 31, 1023, 7, 5
+    km, cnt = synth.make_stream(400_000, k, 1, cs, seed_k=41, seed_c=42)
+    db = str(tmp_path / "db")
+    kmcdb.write_kmc1(db, km, cnt, k, 3, cs)                    # every record is written, the header announces counts >= 3
+    keep = cnt >= 3
+    assert 0 < keep.sum() < len(cnt)
+    m = KModel(3, cs, nh, nb)
+    m.init(db)
+    o = O.OracleModel(3, cs, nh, nb)
+    o.build(k, km[keep], cnt[keep], total=len(cnt))          # KmerCount() is the header's total, listed or not (kmodel.hpp:429)
+    _check_arrays(m, o, nb, 3)
+    assert m.stats().rest_entries == o.stats().rest_entries
+
+
 def test_streamed_ragged_batches_equal_one_shot():
     """kmx_begin / insert_batch / finish with ragged (incl. empty) batches == one-shot build."""
     name = "k31_ci2_200k"

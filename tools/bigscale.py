@@ -1,5 +1,7 @@
-"""One-off large-scale parity run: positions beyond 2^32 bits per array (N ~ 1.5*10^9 31-mers), GPU vs CPU oracle."""
-import hashlib, os, sys, threading, time
+"""One-off large-scale parity run: positions beyond 2^32 bits per array (N ~ 1.5*10^9 31-mers), GPU vs CPU oracle.
+--oracle compares with the CPU oracle; with --golden <file> the oracle's statistics and array digests are written as the
+pinned reference of tests/test_gpu_fullsize.py::test_hc14_scale_properties (only after the comparison has passed)."""
+import hashlib, json, os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -42,7 +44,7 @@ print(f"query 2e8 present k-mers: {2e8/dq/1e6:.1f} M/s, nonzero {(out != 0).floa
 print(f"device memory in use after build: {(torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 2**30:.1f} GiB", flush=True)
 if light:
     sys.exit(0)
-def sha(a): return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+def sha(a): return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 gh = {}
 for a in range(NB):
     tag, val = m.download("tag", a), m.download("value", a)
@@ -51,7 +53,7 @@ for a in range(NB):
     # how far up the array do set bits reach?  (positions above 2^32 must be in use)
     nz = np.flatnonzero(tag)
     gh[a] = (sha(tag), sha(val), int(nz[-1]) * 8)
-    print(f"array {a}: tag sha {gh[a][0]} value sha {gh[a][1]} highest set bit near position {gh[a][2]}", flush=True)
+    print(f"array {a}: tag sha {gh[a][0][:16]} value sha {gh[a][1][:16]} highest set bit near position {gh[a][2]}", flush=True)
     assert gh[a][2] > 2**32 or st.km_byte_size * 8 <= 2**32
 gkb = sha(m.download("km_back"))
 if with_oracle:
@@ -67,3 +69,13 @@ if with_oracle:
     got = m.kmer_to_occ_packed(q)
     assert np.array_equal(got, o.query_packed(K, q, threads=64))
     print("BIT-EXACT vs oracle at this scale (arrays, km_back, stats, sampled queries)", flush=True)
+    if "--golden" in sys.argv:
+        d = {f"tag{a}": sha(o.array_bytes("tag", a)) for a in range(NB)}
+        d.update({f"value{a}": sha(o.array_bytes("value", a)) for a in range(NB)})
+        d.update(km_back=sha(o.array_bytes("km_back")), bf0=sha(o.array_bytes("bf", 0)), bf_back0=sha(o.array_bytes("bf_back", 0)))
+        assert d["bf0"] == sha(m.download("bf", 0)) and d["bf_back0"] == sha(m.download("bf_back", 0))
+        g = {"what": "CPU oracle (oracle/kmx_oracle.c, pinned to the compiled reference) on synth_torch.make_stream(n_draws, 31, 1, 1023), nh=7 nb=5; the GPU build of the same run was identical",
+             "n_draws": n_draw, "n_kmers": n, "k": K, "ci": CI, "cs": CS, "nh": NH, "nb": NB,
+             "stats": {"n_km": int(so.n_km), "attempts": int(so.attempts), "successes": int(so.successes), "rest_entries": int(so.rest_entries)}, "sha256": d}
+        json.dump(g, open(sys.argv[sys.argv.index("--golden") + 1], "w"), indent=1)
+        print("golden written", flush=True)
