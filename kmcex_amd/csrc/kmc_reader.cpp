@@ -5,7 +5,6 @@
 #include <thread>
 
 #include <fcntl.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -87,7 +86,6 @@ bool KmcListing::open(const std::string &prefix)
 	prefix_mask_ = (uint64_t(1) << (2 * p_)) - 1;
 	suf_bytes_ = (k_ - p_) / 4;
 	rec_bytes_ = suf_bytes_ + counter_size_;
-	// the record file is mapped, not read: decode threads pull straight from the page cache
 	const int fd = ::open((prefix + ".kmc_suf").c_str(), O_RDONLY);
 	struct stat sb;
 	if (fd < 0 || fstat(fd, &sb) != 0 || sb.st_size < 8) {
@@ -96,15 +94,12 @@ bool KmcListing::open(const std::string &prefix)
 		close();
 		return false;
 	}
-	map_len_ = (size_t)sb.st_size;
-	void *mp = mmap(nullptr, map_len_, PROT_READ, MAP_SHARED, fd, 0);
-	::close(fd);
-	if (mp == MAP_FAILED) { map_ = nullptr; err_ = "cannot map " + prefix + ".kmc_suf"; close(); return false; }
-	map_ = (const unsigned char *)mp;
-	madvise(mp, map_len_, MADV_SEQUENTIAL);
-	if (memcmp(map_, "KMCS", 4)) { err_ = prefix + ".kmc_suf has no KMCS marker"; close(); return false; }
+	fd_ = fd;
+	file_len_ = (size_t)sb.st_size;
+	char marker[4];
+	if (!read_at(0, marker, 4) || memcmp(marker, "KMCS", 4)) { err_ = prefix + ".kmc_suf has no KMCS marker"; close(); return false; }
 	// a truncated file ends the listing early, like the reference's EOF
-	const uint64_t recs_in_file = (map_len_ - 4 >= 4 ? map_len_ - 8 : 0) / rec_bytes_;
+	const uint64_t recs_in_file = (file_len_ - 4 >= 4 ? file_len_ - 8 : 0) / rec_bytes_;
 	avail_ = std::min<uint64_t>(total_, recs_in_file);
 	restart();
 	return true;
@@ -112,10 +107,22 @@ bool KmcListing::open(const std::string &prefix)
 
 void KmcListing::close()
 {
-	if (map_) munmap((void *)map_, map_len_);
-	map_ = nullptr;
-	map_len_ = 0;
+	if (fd_ >= 0) ::close(fd_);
+	fd_ = -1;
+	file_len_ = 0;
 	lut_.clear();
+	stage_.clear();
+}
+
+bool KmcListing::read_at(uint64_t off, void *dst, size_t bytes) const
+{
+	char *p = (char *)dst;
+	while (bytes) {
+		const ssize_t got = pread(fd_, p, bytes, (off_t)off);
+		if (got <= 0) return false;
+		p += got; off += (uint64_t)got; bytes -= (size_t)got;
+	}
+	return true;
 }
 
 void KmcListing::restart() { rec_ = 0; }
@@ -174,10 +181,12 @@ size_t KmcListing::decode_range(const unsigned char *recs, uint64_t rec0, size_t
 
 size_t KmcListing::next_batch(uint64_t *kmers, uint32_t *counts, size_t max_n)
 {
-	if (!map_ || rec_ >= avail_ || !max_n) return 0;
+	if (fd_ < 0 || rec_ >= avail_ || !max_n) return 0;
 	const int W = words();
 	const size_t got = (size_t)std::min<uint64_t>(max_n, avail_ - rec_);
-	const unsigned char *recs = map_ + 4 + rec_ * rec_bytes_;
+	stage_.resize(got * rec_bytes_ + 16);                            // the decoders' 8-byte loads may reach past the last field
+	copy_records(rec_, got, stage_.data());
+	const unsigned char *recs = stage_.data();
 	const uint64_t rec0 = rec_;
 	rec_ += got;
 	int T = threads_;
@@ -208,18 +217,18 @@ size_t KmcListing::next_batch(uint64_t *kmers, uint32_t *counts, size_t max_n)
 
 void KmcListing::copy_records(uint64_t rec0, uint64_t n, unsigned char *dst) const
 {
-	if (!map_ || rec0 >= avail_ || !n) return;
+	if (fd_ < 0 || rec0 >= avail_ || !n) return;
 	n = std::min<uint64_t>(n, avail_ - rec0);
-	const unsigned char *src = map_ + 4 + rec0 * rec_bytes_;
+	const uint64_t src = 4 + rec0 * rec_bytes_;
 	const uint64_t bytes = n * rec_bytes_;
 	const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)threads_, bytes / (1u << 20) + 1));
-	if (T == 1) { memcpy(dst, src, bytes); return; }
+	if (T == 1) { read_at(src, dst, bytes); return; }
 	std::vector<std::thread> th;
 	const uint64_t per = ((bytes + T - 1) / T + 4095) & ~uint64_t(4095);
 	for (int t = 0; t < T; t++)
 		th.emplace_back([=] {
 			const uint64_t lo = (uint64_t)t * per, hi = std::min(bytes, lo + per);
-			if (lo < hi) memcpy(dst + lo, src + lo, hi - lo);
+			if (lo < hi) read_at(src + lo, dst + lo, hi - lo);
 		});
 	for (auto &x : th) x.join();
 }
@@ -229,30 +238,26 @@ void KmcListing::count_classes(uint32_t ci, uint32_t cs, int bf_num, uint64_t n_
 	n_bf[0] = n_bf[1] = n_bf[2] = 0;
 	*out_of_range = 0;
 	if (not_listed) *not_listed = 0;
-	if (!map_) return;
+	if (fd_ < 0) return;
 	const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)threads_, avail_ / 65536 + 1));
 	std::vector<uint64_t> acc((size_t)T * 8, 0);
 	auto work = [&](int t) {
 		const uint64_t per = (avail_ + T - 1) / T, lo = (uint64_t)t * per, hi = std::min(avail_, lo + per);
 		uint64_t a[5] = {0, 0, 0, 0, 0};
 		const uint32_t cnt_mask = counter_size_ == 4 ? 0xFFFFFFFFu : ((1u << (8 * counter_size_)) - 1);
-		const uint64_t hi_fast = hi > lo + 2 ? hi - 2 : lo;               // the 4-byte load may reach past the last record's counter
-		uint64_t r = lo;
-		for (; r < hi_fast; r++) {                                          // one unaligned load per record
-			uint32_t c;
-			memcpy(&c, map_ + 4 + r * rec_bytes_ + suf_bytes_, 4);
-			c &= cnt_mask;
-			if (c < min_count_ || c > max_count_) { a[4]++; continue; }   // not listed
-			if (c < ci || c > cs) a[3]++;
-			else if (c < ci + (uint32_t)bf_num) a[c - ci]++;
-		}
-		for (; r < hi; r++) {
-			const unsigned char *p = map_ + 4 + r * rec_bytes_ + suf_bytes_;
-			uint32_t c = 0;
-			for (uint32_t b = 0; b < counter_size_; b++) c |= (uint32_t)p[b] << (8 * b);
-			if (c < min_count_ || c > max_count_) { a[4]++; continue; }   // not listed
-			if (c < ci || c > cs) a[3]++;
-			else if (c < ci + (uint32_t)bf_num) a[c - ci]++;
+		const uint64_t chunk = (4u << 20) / rec_bytes_;                      // records per read: ~4 MB
+		std::vector<unsigned char> buf(chunk * rec_bytes_ + 8);
+		for (uint64_t r0 = lo; r0 < hi; r0 += chunk) {
+			const uint64_t nr = std::min(chunk, hi - r0);
+			if (!read_at(4 + r0 * rec_bytes_, buf.data(), nr * rec_bytes_)) break;
+			for (uint64_t r = 0; r < nr; r++) {                              // one unaligned load per record (the buffer has 8 spare bytes)
+				uint32_t c;
+				memcpy(&c, buf.data() + r * rec_bytes_ + suf_bytes_, 4);
+				c &= cnt_mask;
+				if (c < min_count_ || c > max_count_) { a[4]++; continue; }   // not listed
+				if (c < ci || c > cs) a[3]++;
+				else if (c < ci + (uint32_t)bf_num) a[c - ci]++;
+			}
 		}
 		for (int q = 0; q < 5; q++) acc[(size_t)t * 8 + q] = a[q];
 	};

@@ -48,8 +48,12 @@ public:
 private:
 	size_t decode_range(const unsigned char *recs, uint64_t rec0, size_t n_recs, uint64_t *kmers, uint32_t *counts) const;
 	int threads_ = 1;
-	const unsigned char *map_ = nullptr;    // the whole .kmc_suf, mapped read-only; records start at map_ + 4
-	size_t map_len_ = 0;
+	// The record file is read with pread (page cache -> destination, no mapping: on a 0.8 GB file the first-touch
+	// faults of a fresh mapping cost pass 1 ~6 ms and its munmap another ~12 ms); records start at byte 4.
+	int fd_ = -1;
+	size_t file_len_ = 0;
+	bool read_at(uint64_t off, void *dst, size_t bytes) const;
+	std::vector<unsigned char> stage_;       // raw bytes of the batch next_batch is decoding (host decoder only)
 	std::vector<uint64_t> lut_;      // concatenated LUT(s); lut_[size] sentinel = total
 	uint64_t rec_ = 0, avail_ = 0, total_ = 0, max_count_ = 0, prefix_mask_ = 0;
 	uint32_t k_ = 0, mode_ = 0, counter_size_ = 0, p_ = 0, min_count_ = 0, version_ = 0;
