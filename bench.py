@@ -323,10 +323,10 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": per_launch,
                 "avg_launch_us": classes[dom]["avg_launch_us"], "launches": dv["launches"]}
         # the random-access ceiling of this chip for 8-byte touches over a footprint like the coupled arrays'
-        foot = max(int(st.km_byte_size) * 4 * a.nb, 1 << 26)
-        tg = api.microbench(0, foot, 1 << 27, 3)
-        ta = api.microbench(1, foot, 1 << 27, 3)
-        roof["random_access_ceiling_GBps_at_32B"] = (1 << 27) * G / tg / 1e9     # measured 8-byte gather rate, priced at G per touch
+        foot = max(int(st.km_byte_size) * 2 * a.nb, 1 << 26)              # the cells of all arrays (4 bytes per 16 positions)
+        tg = api.microbench(8, foot, 1 << 27, 3)                           # 4-byte random loads: what check_emit issues
+        ta = api.microbench(5, foot, 1 << 27, 3)                           # 32-bit random atomic ORs: what commit issues
+        roof["random_access_ceiling_GBps_at_32B"] = (1 << 27) * G / tg / 1e9     # measured 4-byte gather rate, priced at G per touch
         roof["frac_of_random_access_ceiling"] = ach / roof["random_access_ceiling_GBps_at_32B"]
         extra = {"kernel_classes": classes,
                  "insert_alg_bytes_per_kmer": total_insert_alg / n,

@@ -156,7 +156,8 @@ int kmx_occubin(int cs, int nh, uint32_t *bin_of_occ, uint32_t *mean_of_bin);
 /* Random-access ceiling of the memory system for this access pattern: `touches` random touches over
  * `bytes` of device memory, 8 per lane like one k-mer on one array; seconds per launch out.  mode: 0 8-byte loads,
  * 1 64-bit atomic OR (agent scope, what the insert uses), 2 byte stores, 3 byte loads, 4 8-byte stores,
- * 5 32-bit atomic OR, 6 64-bit atomic OR at workgroup scope, 7 64-bit atomic OR returning the old word.       */
+ * 5 32-bit atomic OR (what the insert uses on its 4-byte cells), 6 64-bit atomic OR at workgroup scope, 7 64-bit atomic OR
+ * returning the old word, 8 4-byte loads (what the insert's check uses).                                        */
 int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds);
 
 /* Per-kernel-class timing with HIP events recorded on the model's stream around each launch (off by default).

@@ -147,14 +147,14 @@ __device__ __forceinline__ u32 bit_in_word32(u64 pos) { return (u32)(8 * ((pos >
 __device__ __forceinline__ void bloom_set(u32 *bits, u64 pos) { atomicOr(bits + (pos >> 5), 1u << bit_in_word32(pos)); }
 __device__ __forceinline__ bool bloom_get(const u32 *bits, u64 pos) { return (bits[pos >> 5] >> bit_in_word32(pos)) & 1u; }
 
-// Coupled arrays live in HBM as one u64 "cell" per 16 positions (= 2 on-disk bytes of each array):
+// Coupled arrays live in HBM as one 32-bit "cell" per 16 positions (= 2 on-disk bytes of each array):
 //   bits  0..15 value (bit_array_1)   bits 16..31 tag (bit_array_2)
-//   bits 32..47 claim "wants 0"       bits 48..63 claim "wants 1"   (insert-time scratch, zero between rounds)
-// so one 8-byte access reads, claims or commits a position.  save() de-interleaves to the on-disk layout.
+// so one 4-byte access reads or commits a position (tag and value travel together).  save() de-interleaves to the on-disk
+// layout.  (Round 1 kept two 16-bit claim fields in an upper half; claims are a partitioned stream now, kernels.hip.)
+typedef u32 cell_t;
 __device__ __forceinline__ u32 bit_in_cell(u64 pos) { return (u32)(8 * ((pos >> 3) & 1) + 7 - (pos & 7)); }
-#define CELL_VAL(bit)      (1ULL << (bit))
-#define CELL_TAG(bit)      (1ULL << (16 + (bit)))
-#define CELL_CLAIM(w, bit) (1ULL << (32 + 16 * (w) + (bit)))
+#define CELL_VAL(bit)      (1u << (bit))
+#define CELL_TAG(bit)      (1u << (16 + (bit)))
 
 // ---------------------------------------------------------------- canonicalisation (A.7)
 __device__ __forceinline__ u64 rev2_u64(u64 x)

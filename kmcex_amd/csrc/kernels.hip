@@ -89,7 +89,7 @@ template <typename T> __device__ __forceinline__ T wave_append_slot(T *ctr, bool
 // wait until every vector-memory operation of this wave (loads, stores, atomics) has been acknowledged
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-__device__ __forceinline__ u64 cell_load_coherent(const u64 *p)
+template <typename T> __device__ __forceinline__ T cell_load_coherent(const T *p)
 {
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // global_load sc1: bypasses this CU's L1
 }
@@ -97,13 +97,13 @@ __device__ __forceinline__ u64 cell_load_coherent(const u64 *p)
 // The nh touches of one k-mer on one coupled array.
 template <int NHM> struct Touches {
 	u64 pos[NHM];
-	u64 cell[NHM];
+	cell_t cell[NHM];
 };
 
 template <int W, int NHM, bool COHERENT>
 __device__ __forceinline__ void gather_touches(const ModelDev &md, const Premixed<W> &pm, int a, Touches<NHM> &t)
 {
-	const u64 *cells = md.cells[a];
+	const cell_t *cells = md.cells[a];
 	const int sbase = a * md.nh;
 #pragma unroll
 	for (int j = 0; j < NHM; j++)
@@ -131,13 +131,13 @@ template <int NHM> __device__ __forceinline__ bool touches_conflict(const ModelD
 template <int W, int NHM>
 __device__ __forceinline__ void commit_touches(const ModelDev &md, const Touches<NHM> &t, u32 bin, int a, const Aligned<W> &al)
 {
-	u64 *cells = md.cells[a];
+	cell_t *cells = md.cells[a];
 #pragma unroll
 	for (int j = 0; j < NHM; j++)
 		if (j < md.nh) {
 			u32 b = bit_in_cell(t.pos[j]);
-			if (!((t.cell[j] >> (16 + b)) & 1ULL))          // already tagged => already carries this value
-				atomicOr(cells + (t.pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
+			if (!((t.cell[j] >> (16 + b)) & 1u))          // already tagged => already carries this value
+				atomicOr(cells + (t.pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0u));
 		}
 	if (md.kmb_direct) {
 		Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
@@ -447,7 +447,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_e
 				for (int j = 0; j < NHM; j++)
 					if (j < md.nh) {
 						const u32 b = bit_in_cell(tc.pos[j]);
-						if (!((tc.cell[j] >> (16 + b)) & 1ULL)) {
+						if (!((tc.cell[j] >> (16 + b)) & 1u)) {
 							um |= 1u << j;
 							rank[j] = atomicAdd(&s_cnt[cl_bin<NHM>(cl_hash(tc.pos[j]))], 1);
 						}
@@ -562,7 +562,7 @@ template <int NHM> __device__ __forceinline__ void reserve_untagged(const ModelD
 	for (int j = 0; j < NHM; j++)
 		if (j < md.nh) {
 			u32 b = bit_in_cell(tc.pos[j]);
-			if (!((tc.cell[j] >> (16 + b)) & 1ULL)) atomicMax(resv_slot(bd, i, tc.pos[j]), key);
+			if (!((tc.cell[j] >> (16 + b)) & 1u)) atomicMax(resv_slot(bd, i, tc.pos[j]), key);
 		}
 }
 // A k-mer owns its outcome when it does not conflict with what is committed by now and holds the reservation of every
@@ -576,7 +576,7 @@ __device__ __forceinline__ bool owns_outcome(const ModelDev &md, const BlockDev 
 	for (int j = 0; j < NHM; j++)
 		if (j < md.nh) {
 			u32 b = bit_in_cell(tc.pos[j]);
-			if (!((tc.cell[j] >> (16 + b)) & 1ULL)) {
+			if (!((tc.cell[j] >> (16 + b)) & 1u)) {
 				const u64 r = COHERENT ? cell_load_coherent(resv_slot(bd, i, tc.pos[j])) : *resv_slot(bd, i, tc.pos[j]);
 				mine &= (r == key);
 			}
@@ -618,7 +618,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit(
 	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;
 	const int sbase = a * md.nh;
-	u64 *cells = md.cells[a];
+	cell_t *cells = md.cells[a];
 	const bool all_contended = bd.cl_ovf[i] != 0;
 	for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
 		if (threadIdx.x == 0) s_cnt = 0;
@@ -644,7 +644,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit(
 					if (contended) atomicMax(resv_slot(bd, i, pos), key);
 					else {
 						const u32 b = bit_in_cell(pos);
-						atomicOr(cells + (pos >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
+						atomicOr(cells + (pos >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0u));
 					}
 				}
 			if (!contended) {
@@ -738,7 +738,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0
 	const int cnt = bd.Un[UN_IDX(0, i, md.nb)];
 	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;
-	u64 *cells = md.cells[a];
+	cell_t *cells = md.cells[a];
 	const int sbase = a * md.nh;
 	if (threadIdx.x == 0) {
 		s_succ = 0;
@@ -772,7 +772,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0
 				for (int j = 0; j < NHM; j++)
 					if (j < md.nh && ((um >> j) & 1u)) {
 						const u32 b = bit_in_cell(pos[j]);
-						atomicOr(cells + (pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
+						atomicOr(cells + (pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0u));
 					}
 				if (md.kmb_direct) {
 					Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
@@ -836,7 +836,7 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 {
 	// the n records are Urec[lv][s_list[0..n)], or Urec[lv][0..n) when s_list is null; the tables are empty on entry and on exit
 	const u64 row = (u64)i * KMX_BUCKET;
-	u64 *cells = md.cells[a];
+	cell_t *cells = md.cells[a];
 	const int sbase = a * md.nh;
 	u32 x[RPT], bin[RPT], rec[RPT], um[RPT], ghost[RPT], cidx[RPT][NHM];   // ghost: won, but these positions are not published yet
 	u64 bits[RPT];                                                   // bit_in_cell of position j in nibble j
@@ -878,7 +878,7 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 				if (live[g0 + g]) {
 #pragma unroll
 					for (int j = 0; j < NHM; j++)
-						if (j < md.nh) w[g][j] = __hip_atomic_load((const u32 *)(cells + cidx[g0 + g][j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if (j < md.nh) w[g][j] = __hip_atomic_load(cells + cidx[g0 + g][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
 #pragma unroll
 			for (int g = 0; g < G; g++) {
@@ -983,7 +983,7 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 					for (int j = 0; j < NHM; j++)
 						if (j < md.nh && ((resv[r] >> j) & 1u)) {
 							const u32 b = FIN_BIT(r, j);
-							atomicOr(cells + cidx[r][j], CELL_TAG(b) | (((bin[r] >> j) & 1u) ? CELL_VAL(b) : 0ULL));
+							atomicOr(cells + cidx[r][j], CELL_TAG(b) | (((bin[r] >> j) & 1u) ? CELL_VAL(b) : 0u));
 						}
 				}
 				bd.status[row + x[r]] = SLOT_INSERTED;
@@ -1210,13 +1210,13 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 				rec_load<W>(bd.Urec[lv], row + u, x, bin, v);
 				Aligned<W> al = left_align<W>(v, md.k);
 				Premixed<W> pm = premix_string<W>(al, md.gfull);
-				u64 *cells = md.cells[a];
+				cell_t *cells = md.cells[a];
 #pragma unroll
 				for (int j = 0; j < NHM; j++)
 					if (j < md.nh) {
 						const u64 pos = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(a * md.nh + j) & 127]), md.km_mod);
 						const u32 b = bit_in_cell(pos);
-						atomicOr(cells + (pos >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0ULL));
+						atomicOr(cells + (pos >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0u));
 					}
 				if (md.kmb_direct) {
 					Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
@@ -1518,15 +1518,15 @@ template <int PW> __device__ __forceinline__ int check_all_bf(const ModelDev &md
 template <int PW> __device__ __forceinline__ int decode_array(const ModelDev &md, const StrGeom gf, const Premixed<PW> &pf, int a)
 {
 	if (!md.km_mod.d) return -1;
-	const u64 *cells = md.cells[a];
+	const cell_t *cells = md.cells[a];
 	int v = 0;
 	bool ok = true;
 	for (int j = 0; j < md.nh && ok; j++) {
 		u64 pos = mod_u64(murmur_seeded<PW>(pf, gf, c_seeds[(a * md.nh + j) & 127]), md.km_mod);
-		u64 cell = cells[pos >> 4];
+		const cell_t cell = cells[pos >> 4];
 		u32 b = bit_in_cell(pos);
-		ok = (cell >> (16 + b)) & 1ULL;
-		v |= (int)((cell >> b) & 1ULL) << j;
+		ok = (cell >> (16 + b)) & 1u;
+		v |= (int)((cell >> b) & 1u) << j;
 	}
 	return ok ? v : -1;
 }
@@ -1825,23 +1825,22 @@ template <int W> __global__ __launch_bounds__(256) void k_kmc_decode(KmcDecode d
 
 // ------------------------------------------------------------------------------------------ layout conversion
 // on-disk value/tag bytes <-> cells (kmodel.hpp:199-201, :227-229).  One thread per cell (2 bytes of each).
-__global__ __launch_bounds__(256) void k_cells_from_disk(const unsigned char *val, const unsigned char *tag, u64 nbytes, u64 *cells, u64 ncells)
+__global__ __launch_bounds__(256) void k_cells_from_disk(const unsigned char *val, const unsigned char *tag, u64 nbytes, cell_t *cells, u64 ncells)
 {
 	u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
 	if (c >= ncells) return;
 	u64 b0 = 2 * c, b1 = 2 * c + 1;
-	u64 v = (u64)val[b0] | (b1 < nbytes ? (u64)val[b1] << 8 : 0);
-	u64 t = (u64)tag[b0] | (b1 < nbytes ? (u64)tag[b1] << 8 : 0);
+	u32 v = (u32)val[b0] | (b1 < nbytes ? (u32)val[b1] << 8 : 0);
+	u32 t = (u32)tag[b0] | (b1 < nbytes ? (u32)tag[b1] << 8 : 0);
 	cells[c] = v | (t << 16);
 }
-// which: 0 value, 1 tag, 2 claims on untagged positions (must be zero between rounds)
-__global__ __launch_bounds__(256) void k_cells_to_disk(const u64 *cells, u64 ncells, u64 nbytes, int which, unsigned char *out)
+// which: 0 value, 1 tag, 2 insert-time scratch left in the model (there is none any more: always zero)
+__global__ __launch_bounds__(256) void k_cells_to_disk(const cell_t *cells, u64 ncells, u64 nbytes, int which, unsigned char *out)
 {
 	u64 c = (u64)blockIdx.x * 256 + threadIdx.x;
 	if (c >= ncells) return;
-	u64 cell = cells[c];
-	u32 x = which == 0 ? (u32)(cell & 0xFFFF) : which == 1 ? (u32)((cell >> 16) & 0xFFFF)
-	                   : (u32)(((cell >> 32) | (cell >> 48)) & 0xFFFF & ~(cell >> 16));
+	const cell_t cell = cells[c];
+	u32 x = which == 0 ? (cell & 0xFFFF) : which == 1 ? (cell >> 16) : 0;
 	out[2 * c] = (unsigned char)(x & 0xFF);
 	if (2 * c + 1 < nbytes) out[2 * c + 1] = (unsigned char)(x >> 8);
 }
@@ -1893,6 +1892,15 @@ __global__ __launch_bounds__(256) void k_micro_gather(const u64 *buf, u64 ncell,
 #pragma unroll
 	for (int j = 0; j < 8; j++) acc ^= buf[splitmix(i * 8 + j + salt) % ncell];
 	if (acc == 0x123456789ULL) *sink = acc;
+}
+__global__ __launch_bounds__(256) void k_micro_gather32(const u32 *buf, u64 nword, u64 n_lanes, u64 salt, u64 *sink)
+{
+	u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_lanes) return;
+	u32 acc = 0;
+#pragma unroll
+	for (int j = 0; j < 8; j++) acc ^= buf[splitmix(i * 8 + j + salt) % nword];
+	if (acc == 0x12345678u) *sink = acc;
 }
 __global__ __launch_bounds__(256) void k_micro_atomic_or(u64 *buf, u64 ncell, u64 n_lanes, u64 salt)
 {
@@ -2129,12 +2137,12 @@ void query_ascii(const ModelDev &md, int L, const unsigned char *strs, int strid
 	DISPATCH_W(words(md), hipLaunchKernelGGL(k_query_ascii<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, md, gf, gb, L, strs, stride, n, out));
 }
 
-void cells_from_disk(const unsigned char *val, const unsigned char *tag, u64 nbytes, u64 *cells, u64 ncells, hipStream_t st)
+void cells_from_disk(const unsigned char *val, const unsigned char *tag, u64 nbytes, cell_t *cells, u64 ncells, hipStream_t st)
 {
 	if (!ncells) return;
 	hipLaunchKernelGGL(k_cells_from_disk, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st, val, tag, nbytes, cells, ncells);
 }
-void cells_to_disk(const u64 *cells, u64 ncells, u64 nbytes, int which, unsigned char *out, hipStream_t st)
+void cells_to_disk(const cell_t *cells, u64 ncells, u64 nbytes, int which, unsigned char *out, hipStream_t st)
 {
 	if (!ncells) return;
 	hipLaunchKernelGGL(k_cells_to_disk, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, st, cells, ncells, nbytes, which, out);
@@ -2163,6 +2171,7 @@ void micro(int mode, u64 *buf, u64 ncell, u64 n_lanes, u64 salt, u64 *sink, hipS
 	else if (mode == 4) hipLaunchKernelGGL(k_micro_store8, grid, dim3(256), 0, st, buf, ncell, n_lanes, salt);
 	else if (mode == 5) hipLaunchKernelGGL(k_micro_atomic_or32, grid, dim3(256), 0, st, (u32 *)buf, ncell * 2, n_lanes, salt);
 	else if (mode == 6) hipLaunchKernelGGL(k_micro_atomic_or_wg, grid, dim3(256), 0, st, buf, ncell, n_lanes, salt);
+	else if (mode == 8) hipLaunchKernelGGL(k_micro_gather32, grid, dim3(256), 0, st, (const u32 *)buf, ncell * 2, n_lanes, salt, sink);
 	else hipLaunchKernelGGL(k_micro_atomic_or_ret, grid, dim3(256), 0, st, buf, ncell, n_lanes, salt, sink);
 }
 

@@ -42,8 +42,8 @@ void ring_export(const ModelDev &, const BlockDev &, const RingLists &, hipStrea
 void or_words(u32 *, const u32 *, u64, hipStream_t);
 void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *);
 void query_ascii(const ModelDev &, int, const unsigned char *, int, u64, int *, hipStream_t);
-void cells_from_disk(const unsigned char *, const unsigned char *, u64, u64 *, u64, hipStream_t);
-void cells_to_disk(const u64 *, u64, u64, int, unsigned char *, hipStream_t);
+void cells_from_disk(const unsigned char *, const unsigned char *, u64, cell_t *, u64, hipStream_t);
+void cells_to_disk(const cell_t *, u64, u64, int, unsigned char *, hipStream_t);
 void debug_hash(int, const u64 *, u64, const u32 *, int, int, u64 *, hipStream_t);
 void debug_min_kmer(int, const u64 *, u64, u64 *, hipStream_t);
 void debug_mod(const u64 *, u64, u64, u64 *, hipStream_t);
@@ -177,7 +177,7 @@ struct kmx_model {
 	u32 *d_bloom = nullptr;                                    // ONE slab for bf[i] / bf_back[i], back to back (d_bf / d_bf_back point into it)
 	u64 cap_bloom = 0, bloom_words = 0, bf_woff[3] = {0, 0, 0}, bf_back_woff[3] = {0, 0, 0};
 	u32 *d_bf[3] = {nullptr, nullptr, nullptr}, *d_bf_back[3] = {nullptr, nullptr, nullptr}, *d_km_back = nullptr;
-	u64 *d_cells[KMX_MAX_NB] = {nullptr};
+	cell_t *d_cells[KMX_MAX_NB] = {nullptr};
 	u64 cap_km_back = 0, cap_cells[KMX_MAX_NB] = {0};          // bytes allocated
 	RestTable rest;
 	ModelDev md;
@@ -501,7 +501,7 @@ static int alloc_arrays(kmx_model *m)
 	TRY(ensure(&m->d_km_back, &m->cap_km_back, ((m->byte_km_back + 3) / 4 + 1) * 4, true, m->stream));
 	// (hipMalloc of fresh device memory costs ~90 ms per GB on this stack, also from several threads at once:
 	// a cold build of 2.5e9 k-mers spends 2.3 s here, a rebuild on the same handle nothing)
-	const u64 need = (m->ncells + 1) * 8;
+	const u64 need = (m->ncells + 1) * sizeof(cell_t);
 	for (int a = 0; a < m->nb; a++) TRY(ensure(&m->d_cells[a], &m->cap_cells[a], need, true, m->stream));
 	return KMX_OK;
 }
@@ -1494,7 +1494,7 @@ static int kmx_dev_view_impl(kmx_model *m, int which, int index, void **ptr, uin
 	case 0: *ptr = m->d_bf[index]; *bytes = words(m->byte_bf[index]); break;
 	case 1: *ptr = m->d_bf_back[index]; *bytes = words(m->byte_bf_back[index]); break;
 	case 2: *ptr = m->d_km_back; *bytes = words(m->byte_km_back); break;
-	case 3: *ptr = m->d_cells[index]; *bytes = m->ncells * 8; break;
+	case 3: *ptr = m->d_cells[index]; *bytes = m->ncells * sizeof(cell_t); break;
 	default: return fail(KMX_E_ARG, "bad selector");
 	}
 	return KMX_OK;

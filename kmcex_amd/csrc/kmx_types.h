@@ -9,7 +9,7 @@ struct ModelDev {
 	u32 *bf[3];      ModU64 bf_mod[3];         // Bloom filters, on-disk byte layout (kmodel.hpp:250,253)
 	u32 *bf_back[3]; ModU64 bf_back_mod[3];    // their (k-2)-mer back filters       (kmodel.hpp:251,255)
 	u32 *km_back;    ModU64 km_back_mod;       // back filter of the coupled arrays  (kmodel.hpp:267-269)
-	u64 *cells[KMX_MAX_NB];                    // coupled arrays, cell layout (device_common.h)
+	cell_t *cells[KMX_MAX_NB];                 // coupled arrays, cell layout (device_common.h)
 	ModU64 km_mod;                             // bit_array_length                   (kmodel.hpp:33,445)
 	int bloom_direct;                          // 1: Bloom-class k-mers OR their bits in right away; 0: through the BitScatter of the Bloom slab
 	u64 bf_woff[3], bf_back_woff[3];           // word offsets of the filters inside the slab (they are allocated back to back)

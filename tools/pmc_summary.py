@@ -35,6 +35,14 @@ if "k_micro_atomic_or" in mw:
     cal["bytes_written_per_random_64bit_atomic"] = v * 1024 / n / TOUCHES
     n2, v2 = mf.get("k_micro_atomic_or", [1, 0.0])
     cal["bytes_fetched_per_random_64bit_atomic"] = v2 * 1024 / n2 / TOUCHES
+if "k_micro_gather32" in mf:
+    n, v = mf["k_micro_gather32"]
+    cal["bytes_fetched_per_random_4B_load"] = v * 1024 / n / TOUCHES
+if "k_micro_atomic_or32" in mw:
+    n, v = mw["k_micro_atomic_or32"]
+    cal["bytes_written_per_random_32bit_atomic"] = v * 1024 / n / TOUCHES
+    n2, v2 = mf.get("k_micro_atomic_or32", [1, 0.0])
+    cal["bytes_fetched_per_random_32bit_atomic"] = v2 * 1024 / n2 / TOUCHES
 if "k_micro_store8" in mw:
     n, v = mw["k_micro_store8"]
     cal["bytes_written_per_random_8B_store"] = v * 1024 / n / TOUCHES
