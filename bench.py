@@ -292,12 +292,12 @@ def main():
         W8 = 8 * ((a.k + 31) // 32) + 4
         alg = {  # algorithmic bytes of ONE step per kernel class (SURVEY.md §8d formula, split by kernel)
             "check": G * A * a.nh + A * W8,                              # reads: every attempt looks at its nh positions
-            "commit": G * (S * a.nh + 2 * S * (a.nh - 2)),              # write-backs + km_back read-modify-write
+            "commit": G * S * a.nh,                                      # write-backs (km_back's 2*S*(nh-2) term is k_kmback_emit + k_bs_apply now)
             "classify": G * 2 * nbf * ((a.nh - 1) + (a.nh - 2)) + n * W8,
         }
         per_q = G * (a.nb * a.nh + (a.nh - 2) + 2 + 6) + W8      # §8d: ~48 touches per query
         alg["query"] = q.numel() * per_q
-        total_insert_alg = alg["check"] + alg["commit"] + alg["classify"]
+        total_insert_alg = alg["check"] + alg["commit"] + G * 2 * S * (a.nh - 2) + alg["classify"]     # the §8d formula, whole insert
         classes = {}
         for name, v in kt.items():
             if v["launches"]:
@@ -311,16 +311,21 @@ def main():
         ach = per_launch / (dv["seconds"] / max(dv["launches"], 1)) / 1e9
         # HBM bytes per launch of that kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # runs of this same command, tools/pmc_summary.py); only valid for the default workload they were taken on
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_head, q_pmc = None, None, None, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic_default_workload.json")
         kname = {"check": "k_round_check_emit", "commit": "k_round_commit", "classify": "k_classify_count"}.get(dom)
         if a.n == 100_000_000 and (a.k, a.nh, a.nb, a.ci, a.cs) == (31, 7, 5, 1, 1023) and os.path.exists(pmc_file) and kname:
             pm = json.load(open(pmc_file))
+            traffic_head = pm.get("head")                          # the commit the counters were taken at (staleness is visible in the line)
             for kn, kv in pm["kernels"].items():
                 if kn.startswith(kname):
                     traffic, traffic_src = kv["hbm_bytes_per_launch"], "profiles/pmc_traffic_default_workload.json"
+                if kn.startswith("k_query<"):                      # probes counted by the memory system: fetched bytes / calibrated bytes per random load
+                    per_load = pm.get("calibration", {}).get("bytes_fetched_per_random_4B_load") or pm.get("calibration", {}).get("bytes_fetched_per_random_8B_load")
+                    if per_load and pm.get("n_queries"):
+                        q_pmc = kv["fetch_bytes_total"] / max(kv["launches"], 1) / per_load / pm["n_queries"]
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": per_launch,
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_head": traffic_head, "alg_bytes_per_launch": per_launch,
                 "avg_launch_us": classes[dom]["avg_launch_us"], "launches": dv["launches"]}
         # the random-access ceiling of this chip for 8-byte touches over a footprint like the coupled arrays'
         foot = max(int(st.km_byte_size) * 2 * a.nb, 1 << 26)              # the cells of all arrays (4 bytes per 16 positions)
@@ -333,7 +338,9 @@ def main():
                  "insert_alg_GBps_whole_step": total_insert_alg / (t_ins / a.steps) / 1e9,
                  "insert_frac_of_8TBps": total_insert_alg / (t_ins / a.steps) / 8e12,
                  "query_alg_GBps": alg["query"] / (t_q / a.steps) / 1e9,
-                 "query_frac_of_8TBps": alg["query"] / (t_q / a.steps) / 8e12,
+                 "query_frac_of_8TBps": alg["query"] / (t_q / a.steps) / 8e12,           # SURVEY §8d formula: 48 touches priced per query
+                 "query_touches_per_query_pmc": q_pmc,                                    # what the counters saw (early exits)
+                 "query_frac_of_8TBps_counted": (q_pmc * G * q.numel() / (t_q / a.steps) / 8e12) if q_pmc else None,
                  "random_access_ceiling": {"footprint_bytes": foot, "gather_Gtouch_s": (1 << 27) / tg / 1e9,
                                            "atomic_or_Gtouch_s": (1 << 27) / ta / 1e9,
                                            "gather_GBps_at_32B": (1 << 27) * G / tg / 1e9,

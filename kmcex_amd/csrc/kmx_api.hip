@@ -506,9 +506,12 @@ static int alloc_arrays(kmx_model *m)
 	return KMX_OK;
 }
 
-// km_back as a partitioned bit-set: bins of a power-of-two number of positions, swept in tiles of 2^20.  Up to 8 tiles
-// per bin the sweep re-reads a bin's tuples once per tile out of L2; beyond that (km_back > 256 MB, i.e. more than
-// ~8*10^8 coupled k-mers at nh = 7) the direct atomic path stays.
+// km_back as a partitioned bit-set: bins of a power-of-two number of positions, swept in tiles of 2^20.  The sweep re-reads
+// a bin's tuples once per tile and the whole filter once per sweep: up to 8 tiles per bin (a filter of 256 MB: ~8*10^8
+// coupled k-mers at nh = 7) that is far cheaper than one memory-side atomic per bit; with 32 tiles it LOSES (measured at
+// 2.5*10^9 k-mers: warm build 2.66 s -> 4.14 s, the sweeps of a 680 MB km_back and a 550 MB Bloom slab cost more than the
+// atomics they replace), so larger filters keep the direct atomic path until a second partition level exists.
+static const u32 kBsMaxTileShift = 3;
 static int setup_kmback_scatter(kmx_model *m)
 {
 	m->kmb_deferred = false;
@@ -517,11 +520,16 @@ static int setup_kmback_scatter(kmx_model *m)
 	if (m->dbg_kmb_direct || nwords == 0) return KMX_OK;
 	u32 wshift = 5;
 	while ((((u64)BS_BINS) << wshift) < nwords * 32) wshift++;
-	if (wshift > 20 + 3) return KMX_OK;                            // more than 8 tiles per bin
+	if (wshift > 20 + kBsMaxTileShift) return KMX_OK;              // too many tiles per bin
 	const u64 blk = (u64)m->nb * KMX_BUCKET, per_block = blk * (u64)(m->nh - 2);
-	const u64 cap = 1u << 18;                                      // tuples per bin (1 MB)
+	// tuples per bin: 1 MB while a bin is a few tiles; more when the sweep re-reads the tuples tile after tile, so that
+	// a sweep of the whole filter is shared by more blocks
+	const u64 cap = wshift <= 22 ? (1u << 18) : (wshift == 23 ? (1u << 19) : (1u << 20));
 	const u64 bins_used = (nwords * 32 + (1ULL << wshift) - 1) >> wshift;
-	if (!m->d_kmb_tup) {
+	if (!m->d_kmb_tup || m->kmb_tup_cap < (u64)BS_BINS * cap) {
+		HIPCHK(hipStreamSynchronize(m->stream));
+		hipFree(m->d_kmb_tup); hipFree(m->d_kmb_cnt);
+		m->d_kmb_tup = nullptr; m->d_kmb_cnt = nullptr; m->kmb_tup_cap = 0;
 		TRY(dalloc(&m->d_kmb_tup, (u64)BS_BINS * cap, false, m->stream));
 		TRY(dalloc(&m->d_kmb_cnt, (u64)BS_BINS, true, m->stream));
 		m->kmb_tup_cap = (u64)BS_BINS * cap;
@@ -543,7 +551,7 @@ static int setup_bloom_scatter(kmx_model *m)
 	if (m->dbg_kmb_direct || m->bloom_words == 0) return KMX_OK;
 	u32 wshift = 5;
 	while ((((u64)BS_BINS) << wshift) < m->bloom_words * 32) wshift++;
-	if (wshift > 20 + 3) return KMX_OK;
+	if (wshift > 20 + kBsMaxTileShift) return KMX_OK;
 	const u64 cap = 1u << 18;
 	if (!m->d_blm_tup) {
 		TRY(dalloc(&m->d_blm_tup, (u64)BS_BINS * cap, false, m->stream));

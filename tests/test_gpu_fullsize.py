@@ -134,7 +134,7 @@ def test_hc14_scale_properties():
         digests[f"tag{a}"], digests[f"value{a}"] = _sha(tag), _sha(val)
         del tag, val
     digests["km_back"], digests["bf0"], digests["bf_back0"] = _sha(m.download("km_back")), _sha(m.download("bf", 0)), _sha(m.download("bf_back", 0))
-    sample = km[:: 25]                                                   # 10^8 of the inserted k-mers
+    sample = km[:: 25].contiguous()                                      # 10^8 of the inserted k-mers
     out = torch.empty(sample.numel(), dtype=torch.int32, device=dev)
     m.kmer_to_occ_dev(sample.data_ptr(), sample.numel(), out.data_ptr())
     torch.cuda.synchronize()

@@ -16,6 +16,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
   echo "microbench under $C done"
 done
 cd "$root"
-python tools/pmc_summary.py "$out" "gpurun_out/${tag}_pmc_traffic.json" "$tag" > "gpurun_out/${tag}_pmc_summary.txt"
+nq=$(python -c "import json,re,sys; d=json.loads(open('$out/bench_FETCH_SIZE.json').read().strip().splitlines()[-1]); print(re.search(r'\((\d+) queries', d['config']['workload']).group(1))")
+cp "$out/bench_FETCH_SIZE.json" "gpurun_out/${tag}_pmc_bench_line.json"
+python tools/pmc_summary.py "$out" "gpurun_out/${tag}_pmc_traffic.json" "$tag" "$nq" > "gpurun_out/${tag}_pmc_summary.txt"
 rm -rf "$out"/pmc_* "$out"/pmcmicro_*
 cat "gpurun_out/${tag}_pmc_summary.txt"

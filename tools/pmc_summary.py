@@ -1,6 +1,6 @@
 """Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) into per-kernel HBM traffic.
 
-usage: pmc_summary.py <dir with pmc_FETCH_SIZE/ pmc_WRITE_SIZE/ pmcmicro_FETCH_SIZE/ pmcmicro_WRITE_SIZE/> <out.json> [label]
+usage: pmc_summary.py <dir with pmc_FETCH_SIZE/ pmc_WRITE_SIZE/ pmcmicro_FETCH_SIZE/ pmcmicro_WRITE_SIZE/> <out.json> [label] [queries per k_query launch]
 Units/corrections (MI355X_MICROARCH.md §HBM): counters are in KiB.  The wide-streaming x2 read correction does not
 apply to this pattern, so the absolute scale is calibrated on kmx_microbench kernels with a known touch count
 (k_micro_gather: 2^28 random 8-byte loads per dispatch; k_micro_atomic_or: 2^28 random 64-bit atomics).
@@ -47,6 +47,8 @@ if "k_micro_store8" in mw:
     n, v = mw["k_micro_store8"]
     cal["bytes_written_per_random_8B_store"] = v * 1024 / n / TOUCHES
 res["calibration"] = cal
+if len(sys.argv) > 4:
+    res["n_queries"] = int(sys.argv[4])      # queries per k_query launch of the profiled bench.py run (for the counted touches per query)
 for k in sorted(set(f) | set(w)):
     if not k.startswith("k_"):
         continue
