@@ -1902,6 +1902,34 @@ __global__ __launch_bounds__(256) void k_micro_gather32(const u32 *buf, u64 nwor
 	for (int j = 0; j < 8; j++) acc ^= buf[splitmix(i * 8 + j + salt) % nword];
 	if (acc == 0x12345678u) *sink = acc;
 }
+// variants of the 4-byte gather: 1 non-temporal (no allocation in the caches on the way), 2 agent-scope relaxed
+// (global_load sc1: bypasses this CU's L1), 3 plain with 16 loads in flight per lane instead of 8
+template <int V> __global__ __launch_bounds__(256) void k_micro_gather32v(const u32 *buf, u64 nword, u64 n_lanes, u64 salt, u64 *sink)
+{
+	u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_lanes) return;
+	u32 acc = 0;
+	constexpr int N = V == 3 ? 16 : 8;
+	if (V == 3 && (i & 1)) return;                                  // half the lanes, twice the loads: same number of touches
+#pragma unroll
+	for (int j = 0; j < N; j++) {
+		const u32 *p = buf + splitmix(i * 8 + j + salt) % nword;
+		acc ^= V == 1 ? __builtin_nontemporal_load(p) : (V == 2 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p);
+	}
+	if (acc == 0x12345678u) *sink = acc;
+}
+// 32-bit atomic ORs with only ~3/8 of the lanes active in each instruction (what a commit looks like: a lane is a list
+// slot, 55 % are candidates, 74 % of their positions untagged); touches = 3/8 of the nominal count
+__global__ __launch_bounds__(256) void k_micro_atomic_or32_sparse(u32 *buf, u64 nword, u64 n_lanes, u64 salt)
+{
+	u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_lanes) return;
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		u64 r = splitmix(i * 8 + j + salt);
+		if (((r >> 40) & 7) < 3) atomicOr(buf + r % nword, 1u << (r >> 59));
+	}
+}
 __global__ __launch_bounds__(256) void k_micro_atomic_or(u64 *buf, u64 ncell, u64 n_lanes, u64 salt)
 {
 	u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -2172,6 +2200,10 @@ void micro(int mode, u64 *buf, u64 ncell, u64 n_lanes, u64 salt, u64 *sink, hipS
 	else if (mode == 5) hipLaunchKernelGGL(k_micro_atomic_or32, grid, dim3(256), 0, st, (u32 *)buf, ncell * 2, n_lanes, salt);
 	else if (mode == 6) hipLaunchKernelGGL(k_micro_atomic_or_wg, grid, dim3(256), 0, st, buf, ncell, n_lanes, salt);
 	else if (mode == 8) hipLaunchKernelGGL(k_micro_gather32, grid, dim3(256), 0, st, (const u32 *)buf, ncell * 2, n_lanes, salt, sink);
+	else if (mode == 9) hipLaunchKernelGGL(k_micro_gather32v<1>, grid, dim3(256), 0, st, (const u32 *)buf, ncell * 2, n_lanes, salt, sink);
+	else if (mode == 10) hipLaunchKernelGGL(k_micro_gather32v<2>, grid, dim3(256), 0, st, (const u32 *)buf, ncell * 2, n_lanes, salt, sink);
+	else if (mode == 11) hipLaunchKernelGGL(k_micro_gather32v<3>, grid, dim3(256), 0, st, (const u32 *)buf, ncell * 2, n_lanes, salt, sink);
+	else if (mode == 12) hipLaunchKernelGGL(k_micro_atomic_or32_sparse, grid, dim3(256), 0, st, (u32 *)buf, ncell * 2, n_lanes, salt);
 	else hipLaunchKernelGGL(k_micro_atomic_or_ret, grid, dim3(256), 0, st, buf, ncell, n_lanes, salt, sink);
 }
 
