@@ -141,7 +141,7 @@ int kmx_get_stats(kmx_model *m, kmx_stats *st);
 
 /* Raw on-disk-layout views for byte-level parity checks (kmodel.hpp:183-202).
  * which: 0 bf[i], 1 bf_back[i], 2 km_back, 3 value array i (bit_array_1), 4 tag array i (bit_array_2),
- *        5 claim bits of array i (must be all zero between rounds; internal invariant).             */
+ *        5 insert-time scratch left in array i (none any more: always zero; kept for the tests' invariant).   */
 int kmx_download(kmx_model *m, int which, int index, uint8_t *dst, uint64_t capacity, uint64_t *written);
 
 /* Primitive known-answer surface, evaluated ON THE DEVICE (tools.hpp:16-50, :160-167).

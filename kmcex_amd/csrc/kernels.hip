@@ -2,18 +2,20 @@
 //
 // One lane = one k-mer.  Wave64; 256-thread workgroups; grids of >= 1024 workgroups on the hot kernels.
 // The path is HBM random-access bound (1-bit gathers/scatters addressed by MurmurHash64A), so there is
-// no MFMA anywhere: the levers are (i) one 8-byte cell per touched position (tag+value+claims
-// co-located), (ii) all nh touches of a k-mer in flight at once, (iii) no host round trips inside a
-// block: list lengths, contended sets and statistics stay in HBM and every kernel reads them there.
+// no MFMA anywhere: the levers are (i) one 4-byte cell per touched position (tag + value co-located), (ii) all nh
+// touches of a k-mer in flight at once, (iii) everything that needs no order -- the claims of a round, the km_back and
+// Bloom bits -- travels as LDS-staged, partitioned streams instead of one memory-side atomic per item, (iv) no host round
+// trips inside a block: list lengths, contended sets and statistics stay in HBM and every kernel reads them there.
 //
 // Insert (reference: kmodel.hpp:543-622, sequential greedy) is reproduced bit for bit:
 //   round = nb independent (buffer i, array (i+t)%nb) pairs.  Per pair the reference walks the buffer
 //   in order; a k-mer fits iff no set tag carries a different value bit.  Here:
-//   A  check_claim   every k-mer checks the committed state; the ones that fit ("candidates") set a
-//                    claim bit (per wanted value) on every still-untagged position they touch;
-//   B  verify_commit a candidate that sees no OPPOSITE claim on its untagged positions cannot interact
-//                    with any other candidate of the list, so it commits (atomic OR) in parallel;
-//                    the others form the contended set U;
+//   A  check_emit    every k-mer checks the committed state; the ones that fit ("candidates") emit one claim tuple
+//                    (position, wanted value, slot) per still-untagged position into hash-partitioned bins;
+//   D  detect        bin by bin, an LDS table finds the positions wanted with both values and marks the candidates
+//                    involved as contended;
+//   B  commit        an unmarked candidate cannot interact with any other candidate of the list, so it commits
+//                    (atomic OR per untagged position) in parallel; the marked ones form the contended set U;
 //   S  slow path     U is resolved in list order by priority reservations: a k-mer that holds the smallest
 //                    index on all its slots has no earlier undecided k-mer touching them, so its outcome is
 //                    the sequential one.  A single-workgroup finisher per list decides in LDS (k_slow_finish);
@@ -584,7 +586,7 @@ __device__ __forceinline__ bool owns_outcome(const ModelDev &md, const BlockDev 
 	return mine;
 }
 
-// record of a contended k-mer: list index | REC_WON | bin << 32 | (positions that were untagged when verify_commit looked) << 48
+// record of a contended k-mer: list index | REC_WON | bin << 32 | (positions that were untagged when check_emit looked) << 48
 #define REC_WON (1ULL << 31)       // set by the finisher: decided to fit, k_reorder applies it
 template <int W> __device__ __forceinline__ void rec_store(u64 *rec, u64 slot, u32 x, u32 bin, const u64 *v, u32 untagged = 0)
 {
@@ -683,8 +685,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_reserve(
 	}
 }
 
-// resolve pass of level s: winners commit, the rest move to level s+1.  Level 0 holds verify_commit's reservations
-// and still carries the claim bits, which are dropped here.
+// resolve pass of level s: winners commit, the rest move to level s+1.  Level 0 holds k_round_commit's reservations.
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch)
 {
 	__shared__ int s_cnt, s_base, s_succ;
@@ -728,7 +729,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve(
 	if (threadIdx.x == 0 && s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)s_succ);
 }
 
-// resolve pass of level 0 without a gather: the untagged mask verify_commit left in the record is still right for
+// resolve pass of level 0 without a gather: the untagged mask check_emit left in the record is still right for
 // this purpose (see finish_lds), so a k-mer that holds the reservation of every position in it commits, and one that
 // does not is deferred -- also when the position was tagged meanwhile by a winner of this very pass, which held it.
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0(ModelDev md, BlockDev bd, int t, int pp, u64 epoch)
@@ -796,7 +797,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0
 //
 // finish_lds -- at most KMX_FIN_RPT*1024 records at a time.  Every thread keeps its records (cell indices and bit
 // numbers of their positions, mask of the positions still untagged) in registers; the reservations live in LDS.
-// The state of the array is read ONCE -- the untagged mask verify_commit left in the record when nothing was committed
+// The state of the array is read ONCE -- the untagged mask check_emit left in the record when nothing was committed
 // on contended positions since (snapshot), one round of coherent gathers otherwise -- and afterwards only this
 // workgroup changes it, so everything else is learnt through LDS:
 //   1. every undecided record reserves its untagged positions with atomicMax(priority << 13 | tag) in table 1
@@ -1103,7 +1104,7 @@ __device__ __forceinline__ void finish_lds_ranges(const ModelDev &md, const Bloc
 
 // finish_global -- more records than finish_lds holds (the host adds grid-wide passes when it sees that happen): the
 // same iteration through the records and the epoch-tagged reservation table in global memory.  The first iteration
-// of s == 0 resolves verify_commit's reservations (epoch_b); afterwards it reserves for itself with epoch0, epoch0+1, ...
+// of s == 0 resolves k_round_commit's reservations (epoch_b); afterwards it reserves for itself with epoch0, epoch0+1, ...
 template <int W, int NHM>
 __device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev &bd, int pp, int i, int a, int lv, int n, bool first, u64 epoch_b, u64 epoch0,
                                                int *s_pending, int *s_succ)
@@ -1187,7 +1188,7 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 // reorder_buffer (kmodel.hpp:529-540): m survivors; survivors already below m stay; the i-th hole from the left
 // (below m) receives the i-th survivor from the right (at or above m).  ONE launch: the tile survivor counts were
 // accumulated while the slots failed; holes are written as (LIST_HOLE | rank) and filled lazily from mover[] by the
-// next round's check_claim (or by rest_append after the last round), so no grid-wide fill pass is needed.
+// next round's check_emit (or by rest_append after the last round), so no grid-wide fill pass is needed.
 // Also closes the round's books: successes = n - m.
 // Before that, it applies what the finisher decided but left undone (REC_WON records of level lv): tag/value bits
 // (kmodel.hpp:611-618, every position: an already tagged one carries the same value) and the km_back insert (:548-550).
@@ -1259,7 +1260,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 	if (tile == 0 && threadIdx.x == 0) {
 		bd.cl_ovf[i] = 0;
 		if (n > m) atomicAdd(bd.stats + ST_SUCCESSES, (u64)(n - m));
-		bd.n[pp ^ 1][i] = m;                                       // (the record counters are reset by the next check_claim)
+		bd.n[pp ^ 1][i] = m;                                       // (the record counters are reset by the next check_emit)
 	}
 }
 

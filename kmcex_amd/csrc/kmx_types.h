@@ -77,7 +77,7 @@ struct BlockDev {
 	const u64 *kmers;        // [nb*BUCKET][W] this block's k-mers in listing order (buffer i = slice i)
 	const u32 *counts;       // [nb*BUCKET]
 	// Lists are index permutations, ping-pong by round parity pp.  An entry with bit 31 set is a hole of the last
-	// reorder that has not been filled yet: its value is mover[pp][entry & 0x7FFFFFFF] (resolved by check_claim).
+	// reorder that has not been filled yet: its value is mover[pp][entry & 0x7FFFFFFF] (resolved by check_emit).
 	u32 *list[2];            // list[pp][i*BUCKET + x] = index into buffer i of slot x
 	u32 *mover[2];           // mover[pp][i*BUCKET + r] = r-th survivor from the right of the previous round
 	int *n[2];               // n[pp][i] current list lengths (buff_real_n, kmodel.hpp:277)

@@ -223,7 +223,7 @@ def test_heavy_collision_tiny_arrays():
 def test_both_finisher_paths_bit_exact(cfg, monkeypatch):
     """The single-workgroup finisher has an LDS path (sets up to 2048 / 1024 records) and a global-memory path (larger
     sets).  Both must give the oracle's arrays on the same input: KMX_FIN_GLOBAL=1 sends every set through the second;
-    KMX_NSUB0/1 force the number of grid-wide passes in front of it (0: the finisher alone, from verify_commit's
+    KMX_NSUB0/1 force the number of grid-wide passes in front of it (0: the finisher alone, from check_emit's
     snapshot; 2: resolve + reserve/resolve first) and KMX_RESOLVE_GATHER=1 the gathering form of the first pass.  The
     hooks are read by kmx_begin, once per build."""
     k, ci, cs, nh, nb, n = cfg
