@@ -319,32 +319,34 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const int *cnt, int *off, i
 	if (threadIdx.x == 0) *total_out = carry;
 }
 
+// compaction of the coupled-array k-mers of a tile into the staging stream, in listing order: lane-contiguous loads, a
+// ballot per 256 elements for the positions, consecutive stores
 template <int W> __global__ __launch_bounds__(256) void k_classify_scatter(ModelDev md, const u64 *kmers, const u32 *counts, u64 n, const int *tile_off, u64 *stg_kmers, u32 *stg_counts, u64 stg_base)
 {
-	__shared__ int s_tmp[4];
-	constexpr int PER = CLS_TILE / 256;
-	u64 base = (u64)blockIdx.x * CLS_TILE + (u64)threadIdx.x * PER;
-	int flag[PER], cnt = 0;
+	__shared__ int s_w[2][4];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const u64 tile = (u64)blockIdx.x * CLS_TILE;
+	u64 off = stg_base + (u64)tile_off[blockIdx.x];
+	for (int q = 0; q < CLS_TILE / 256; q++) {
+		const u64 i = tile + (u64)q * 256 + threadIdx.x;
+		u32 c = 0;
+		bool f = false;
+		if (i < n) { c = counts[i]; f = c >= (u32)(md.ci + md.bf_num) && c <= (u32)md.cs; }
+		const u64 mask = __ballot(f);
+		if (lane == 0) s_w[q & 1][wave] = (int)__popcll(mask);
+		__syncthreads();                                             // (the two buffers alternate: one barrier per step is enough)
+		int before = 0, total = 0;
 #pragma unroll
-	for (int q = 0; q < PER; q++) {
-		u64 i = base + q;
-		flag[q] = 0;
-		if (i < n) {
-			u32 c = counts[i];
-			flag[q] = (c >= (u32)(md.ci + md.bf_num) && c <= (u32)md.cs) ? 1 : 0;
-		}
-		cnt += flag[q];
-	}
-	int off = block_excl_scan_256(cnt, s_tmp, nullptr) + tile_off[blockIdx.x];
-#pragma unroll
-	for (int q = 0; q < PER; q++)
-		if (flag[q]) {
+		for (int w = 0; w < 4; w++) { const int t = s_w[q & 1][w]; before += w < wave ? t : 0; total += t; }
+		if (f) {
+			const u64 o = off + (u64)before + (u64)__popcll(mask & ((1ULL << lane) - 1));
 			u64 v[W];
-			load_kmer<W>(kmers, base + q, v);
-			store_kmer<W>(stg_kmers, stg_base + (u64)off, v);
-			stg_counts[stg_base + (u64)off] = counts[base + q];
-			off++;
+			load_kmer<W>(kmers, i, v);
+			store_kmer<W>(stg_kmers, o, v);
+			stg_counts[o] = c;
 		}
+		off += (u64)total;
+	}
 }
 
 // Block-aggregated append: ONE global atomic per workgroup (same-address atomics serialise at ~11 ns each on
@@ -497,7 +499,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_e
 // entry agree in 52 hash bits: it happens once in ~10^9 builds and only sends a k-mer down the ordered path, which is
 // exact for any superset of the truly contended k-mers).  An entry collects which values are wanted there; a second pass
 // marks every candidate that meets the opposite value on one of its positions as contended.
-template <int NHM> __global__ __launch_bounds__(1024) void k_round_detect(BlockDev bd)
+template <int NHM, int BT> __global__ __launch_bounds__(BT) void k_round_detect(BlockDev bd)
 {
 	constexpr int NBIN = KMX_CL_BINS(NHM), T = 1 << KMX_CL_TBITS;
 	__shared__ u32 s_t[T];
@@ -509,15 +511,15 @@ template <int NHM> __global__ __launch_bounds__(1024) void k_round_detect(BlockD
 	int tb = 10;
 	while ((1 << tb) < 4 * cnt && tb < KMX_CL_TBITS) tb++;           // load <= 1/4 (<= 5/8 for a full bin): short probe chains
 	const u32 tmask = (1u << tb) - 1;
-	for (int q = threadIdx.x; q < (1 << tb); q += 1024) s_t[q] = 0;
+	for (int q = threadIdx.x; q < (1 << tb); q += BT) s_t[q] = 0;
 	__syncthreads();
 	const u64 *tp = bd.cl_tup + ((u64)i * NBIN + b) * KMX_CL_CAP;
 	const u64 row = (u64)i * KMX_BUCKET;
 	constexpr int U = 8;                                             // tuples per thread in flight: the loads of a batch are issued together
-	for (int q0 = 0; q0 < cnt; q0 += U * 1024) {
+	for (int q0 = 0; q0 < cnt; q0 += U * BT) {
 		u64 e[U];
 #pragma unroll
-		for (int u = 0; u < U; u++) { const int q = q0 + u * 1024 + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
+		for (int u = 0; u < U; u++) { const int q = q0 + u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
 #pragma unroll
 		for (int u = 0; u < U; u++) {
 			if (e[u] == ~0ULL) continue;
@@ -533,10 +535,10 @@ template <int NHM> __global__ __launch_bounds__(1024) void k_round_detect(BlockD
 		}
 	}
 	__syncthreads();
-	for (int q0 = 0; q0 < cnt; q0 += U * 1024) {
+	for (int q0 = 0; q0 < cnt; q0 += U * BT) {
 		u64 e[U];
 #pragma unroll
-		for (int u = 0; u < U; u++) { const int q = q0 + u * 1024 + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
+		for (int u = 0; u < U; u++) { const int q = q0 + u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
 #pragma unroll
 		for (int u = 0; u < U; u++) {
 			if (e[u] == ~0ULL) continue;
@@ -2036,7 +2038,7 @@ void classify_count(const ModelDev &md, const u64 *kmers, const u32 *counts, u64
 	const int tiles = classify_tiles(n), tiles_per_chunk = (int)(chunk / CLS_TILE);
 	const int W_ = words(md);
 	KPROF_BEGIN(prof, KC_CLASSIFY, st);
-	const u64 piece = md.bloom_direct ? n : chunk / 2;              // k-mers per launch: what the bins of the BitScatter take
+	const u64 piece = md.bloom_direct ? n : chunk;                  // k-mers per launch: what the bins of the BitScatter take (a bin that fills up falls back to atomics)
 	for (u64 lo = 0; lo < n; lo += piece) {
 		const u64 c = n - lo < piece ? n - lo : piece;
 		const int t0 = (int)(lo / CLS_TILE), nt = classify_tiles(c);
@@ -2076,8 +2078,8 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_emit<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_DETECT, st);
-	if (md.nh <= 8) hipLaunchKernelGGL((k_round_detect<8>), dim3(KMX_CL_BINS(8), nb), dim3(1024), 0, st, bd);
-	else hipLaunchKernelGGL((k_round_detect<16>), dim3(KMX_CL_BINS(16), nb), dim3(1024), 0, st, bd);
+	if (md.nh <= 8) hipLaunchKernelGGL((k_round_detect<8, 1024>), dim3(KMX_CL_BINS(8), nb), dim3(1024), 0, st, bd);       // (256 threads for the late rounds' few
+	else hipLaunchKernelGGL((k_round_detect<16, 1024>), dim3(KMX_CL_BINS(16), nb), dim3(1024), 0, st, bd);               //  hundred tuples per bin measured slower)
 	KPROF_END(prof, st);
 	const u64 eb = (*epoch)++;                                 // k_round_commit's reservations
 	KPROF_BEGIN(prof, KC_VERIFY_COMMIT, st);
