@@ -19,8 +19,22 @@ try:
         t = time.perf_counter(); m.init(db); dt = time.perf_counter() - t
         print(f"init(db) rep {rep}: {km.numel() / dt / 1e6:.1f} M k-mers/s end to end ({dt * 1e3:.1f} ms)", flush=True)
     m2 = KModel(1, 1023, 7, 5)
-    m2.build_dev(31, km.data_ptr(), cnt.data_ptr(), km.numel())
+    for rep in range(3):
+        torch.cuda.synchronize(); t = time.perf_counter(); m2.build_dev(31, km.data_ptr(), cnt.data_ptr(), km.numel()); torch.cuda.synchronize(); dt_dev = time.perf_counter() - t
+    print(f"kmx_build_dev (listing resident in HBM): {km.numel() / dt_dev / 1e6:.1f} M k-mers/s ({dt_dev * 1e3:.1f} ms)", flush=True)
     assert all((m.download("tag", a) == m2.download("tag", a)).all() for a in range(5))
     print("same arrays as the resident build")
+    # the host-pointer ABI (pageable caller buffers -> pinned double-buffered hipMemcpyAsync ring -> insert)
+    import numpy as np
+    hk, hc = km.cpu().numpy().view(np.uint64), cnt.cpu().numpy().view(np.uint32)
+    m3 = KModel(1, 1023, 7, 5)
+    for rep in range(3):
+        t = time.perf_counter(); m3.build_packed(31, hk, hc); dt_host = time.perf_counter() - t
+        print(f"kmx_build_host rep {rep}: {len(hc) / dt_host / 1e6:.1f} M k-mers/s ({dt_host * 1e3:.1f} ms) = {dt_host / dt_dev:.2f} x the resident build", flush=True)
+    n_bf = [int((hc == 1).sum())]
+    for rep in range(2):
+        t = time.perf_counter(); m3.begin(31, n_bf, len(hc)); m3.insert_batch(hk, hc); m3.finish(); dt_str = time.perf_counter() - t
+        print(f"kmx_begin + kmx_insert_batch (host pointers) + kmx_finish rep {rep}: {len(hc) / dt_str / 1e6:.1f} M k-mers/s ({dt_str * 1e3:.1f} ms) = {dt_str / dt_dev:.2f} x the resident build", flush=True)
+    assert all((m3.download("tag", a) == m2.download("tag", a)).all() for a in range(5))
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
