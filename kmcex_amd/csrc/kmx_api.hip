@@ -512,6 +512,13 @@ static int alloc_arrays(kmx_model *m)
 // 2.5*10^9 k-mers: warm build 2.66 s -> 4.14 s, the sweeps of a 680 MB km_back and a 550 MB Bloom slab cost more than the
 // atomics they replace), so larger filters keep the direct atomic path until a second partition level exists.
 static const u32 kBsMaxTileShift = 3;
+// test hook: KMX_BS_CAP=<tuples per bin> shrinks the bins of both partitioned bit-sets, so that producers meet full bins
+// all the time and set those bits with atomics instead (the result must not change); read once per process
+static u64 bs_cap_hook()
+{
+	static const u64 v = [] { const char *e = getenv("KMX_BS_CAP"); const long long x = e ? atoll(e) : 0; return x > 0 ? (u64)std::min<long long>(x, 1 << 18) : 0ull; }();
+	return v;
+}
 static int setup_kmback_scatter(kmx_model *m)
 {
 	m->kmb_deferred = false;
@@ -524,7 +531,9 @@ static int setup_kmback_scatter(kmx_model *m)
 	const u64 blk = (u64)m->nb * KMX_BUCKET, per_block = blk * (u64)(m->nh - 2);
 	// tuples per bin: 1 MB while a bin is a few tiles; more when the sweep re-reads the tuples tile after tile, so that
 	// a sweep of the whole filter is shared by more blocks
-	const u64 cap = wshift <= 22 ? (1u << 18) : (wshift == 23 ? (1u << 19) : (1u << 20));
+	u64 cap = wshift <= 22 ? (1u << 18) : (wshift == 23 ? (1u << 19) : (1u << 20));
+	const u64 cap_hook = bs_cap_hook();
+	if (cap_hook) cap = cap_hook;
 	const u64 bins_used = (nwords * 32 + (1ULL << wshift) - 1) >> wshift;
 	if (!m->d_kmb_tup || m->kmb_tup_cap < (u64)BS_BINS * cap) {
 		HIPCHK(hipStreamSynchronize(m->stream));
@@ -538,7 +547,7 @@ static int setup_kmback_scatter(kmx_model *m)
 	m->kmb.tup = m->d_kmb_tup; m->kmb.cnt = m->d_kmb_cnt;
 	// positions are hashed uniformly over the used bins: keep the expected fill of a bin below 3/4 (a full bin is still exact)
 	m->kmb_budget = bins_used * cap * 3 / 4;
-	if (m->kmb_budget < per_block) return KMX_OK;                  // a single block would not fit: tiny filter, direct path
+	if (m->kmb_budget < per_block && !cap_hook) return KMX_OK;     // a single block would not fit: tiny filter, direct path
 	m->kmb_deferred = true;
 	return KMX_OK;
 }
@@ -552,7 +561,7 @@ static int setup_bloom_scatter(kmx_model *m)
 	u32 wshift = 5;
 	while ((((u64)BS_BINS) << wshift) < m->bloom_words * 32) wshift++;
 	if (wshift > 20 + kBsMaxTileShift) return KMX_OK;
-	const u64 cap = 1u << 18;
+	const u64 cap = bs_cap_hook() ? bs_cap_hook() : (1u << 18);
 	if (!m->d_blm_tup) {
 		TRY(dalloc(&m->d_blm_tup, (u64)BS_BINS * cap, false, m->stream));
 		TRY(dalloc(&m->d_blm_cnt, (u64)BS_BINS, true, m->stream));

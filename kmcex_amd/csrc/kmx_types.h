@@ -102,7 +102,9 @@ struct BlockDev {
 #define KMX_CL_BINS_LOG2(NHM) ((NHM) <= 8 ? 7 : 8)
 #define KMX_CL_BINS(NHM) (1 << KMX_CL_BINS_LOG2(NHM))
 #define KMX_CL_MAXBINS 256
+#ifndef KMX_CL_CAP                             // (tools/stress_small_tables.py builds a library with a tiny capacity: the overflow path every round)
 #define KMX_CL_CAP 20480                       // tuples per bin: 2^18 * nh / bins = 16384 at most on average, + 25 %
+#endif
 #define KMX_CL_TBITS 15                        // 2^15 > KMX_CL_CAP slots: the table of a bin can always take every tuple
 
 #define LIST_HOLE 0x80000000u

@@ -1,6 +1,6 @@
 """One-off randomized stress of the ordered insert against the CPU oracle: many small and mid-size configurations,
 biased to heavy contention (everything into the coupled arrays, tiny arrays), every forced code path.
-usage: python tools/stress_parity.py [seconds] [seed] [big]"""
+usage: python tools/stress_parity.py [seconds] [seed] [big|small]   (small: at most 30 000 k-mers, for libraries built to overflow)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,7 +12,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
 HOOKS = [dict(), dict(KMX_NSUB0="0", KMX_NSUB1="0"), dict(KMX_NSUB0="1", KMX_NSUB1="1"), dict(KMX_NSUB0="3", KMX_NSUB1="2"),
          dict(KMX_FIN_GLOBAL="1"), dict(KMX_NSUB0="2", KMX_RESOLVE_GATHER="1"), dict(KMX_KMB_DIRECT="1"), dict(KMX_KMB_DIRECT="1", KMX_NSUB0="1")]
-SIZES = [600000, 1500000, 3000000, 5000000] if "big" in sys.argv else [40, 300, 3000, 30000, 120000, 300000, 700000]   # big: several blocks, final partial block
+SIZES = [600000, 1500000, 3000000, 5000000] if "big" in sys.argv else ([40, 300, 3000, 12000, 30000] if "small" in sys.argv else [40, 300, 3000, 30000, 120000, 300000, 700000])   # big: several blocks, final partial block
 t0 = time.time(); done = 0; contended = 0
 while time.time() - t0 < budget:
     k = int(rng.integers(12, 65)); nh = int(rng.integers(3, 17)); nb = int(rng.integers(1, 9))
