@@ -30,7 +30,8 @@ class Stats(C.Structure):
                 ("fast_commits", C.c_uint64), ("contended", C.c_uint64), ("finisher_iters", C.c_uint64),
                 ("blocks", C.c_uint64), ("rounds", C.c_uint64),
                 ("k", C.c_int32), ("ci", C.c_int32), ("cs", C.c_int32), ("nh", C.c_int32), ("nb", C.c_int32),
-                ("bf_num", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32), ("rest_bytes", C.c_uint64)]
+                ("bf_num", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32), ("rest_bytes", C.c_uint64),
+                ("piped_attempts", C.c_uint64), ("piped_commits", C.c_uint64)]
 
 
 # every symbol include/kmx.h declares (tests check that the library exports all of them)
@@ -337,14 +338,14 @@ class KModel:
         _chk(self.L.kmx_download(self.h, self.DL[which], index, buf.ctypes.data, cap, C.byref(w)))
         return buf[:w.value].copy()
 
-    KERNEL_CLASSES = ["classify", "check", "commit", "slow_path", "reorder", "rest_append", "query", "detect"]
+    KERNEL_CLASSES = ["classify", "check", "commit", "slow_path", "reorder", "rest_append", "query", "detect", "commit_check"]
 
     def set_profile(self, on: bool) -> None:
         _chk(self.L.kmx_set_profile(self.h, int(on)))
 
     def kernel_times(self, reset: bool = True) -> dict:
-        sec = (C.c_double * 8)()
-        cnt = (C.c_uint64 * 8)()
+        sec = (C.c_double * len(self.KERNEL_CLASSES))()
+        cnt = (C.c_uint64 * len(self.KERNEL_CLASSES))()
         _chk(self.L.kmx_get_kernel_times(self.h, sec, cnt, int(reset)))
         return {n: {"seconds": sec[i], "launches": int(cnt[i])} for i, n in enumerate(self.KERNEL_CLASSES)}
 

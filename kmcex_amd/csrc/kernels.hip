@@ -409,24 +409,25 @@ __global__ __launch_bounds__(256) void k_block_init(BlockDev bd, int nb, int pp,
 __device__ __forceinline__ u64 cl_hash(u64 pos) { return pos * 0x9E3779B97F4A7C15ULL; }
 template <int NHM> __device__ __forceinline__ u32 cl_bin(u64 h) { return (u32)(h >> (64 - KMX_CL_BINS_LOG2(NHM))); }
 
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_emit(ModelDev md, BlockDev bd, int t, int pp)
+// (bx of gx workgroups work on list i: the kernels below map their grids onto these bodies)
+template <int W, int NHM, bool PIPED> __device__ __forceinline__ void check_emit_body(const ModelDev &md, const BlockDev &bd, int t, int pp, int i, int bx, int gx)
 {
 	constexpr int NBIN = KMX_CL_BINS(NHM);
 	__shared__ int s_fail, s_tmp[4];
 	__shared__ int s_cnt[NBIN], s_off[NBIN], s_base[NBIN];
 	__shared__ u64 s_tup[256 * NHM];
-	const int i = blockIdx.y;
 	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;                                  // kmodel.hpp:563
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
+	if (bx == 0 && threadIdx.x == 0) {
 		if (n) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
+		if (PIPED && n) atomicAdd(bd.stats + ST_PIPE_ATTEMPTS, (u64)n);
 		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, md.nb)] = 0;   // k_round_commit files this round's records
 	}
 	u64 *tup = bd.cl_tup + (u64)i * NBIN * KMX_CL_CAP;
 	int *gcnt = bd.cl_cnt + i * KMX_CL_MAXBINS;
 	// grid-stride over the list: later rounds are launched with fewer workgroups (lists shrink round by round)
-	for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+	for (int base = bx * 256; base < n; base += gx * 256) {
 		if (threadIdx.x == 0) s_fail = 0;
 		if (threadIdx.x < NBIN) s_cnt[threadIdx.x] = 0;
 		__syncthreads();
@@ -492,6 +493,10 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_e
 		__syncthreads();
 	}
 }
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_emit(ModelDev md, BlockDev bd, int t, int pp, int i0)
+{
+	check_emit_body<W, NHM, false>(md, bd, t, pp, i0 + (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+}
 
 // ------------------------------------------------------------------------------------------ D: opposite claims, bin by bin
 // One workgroup per (bin, list): every tuple of the bin goes into an open-addressing table in LDS keyed by a 30-bit
@@ -499,11 +504,11 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_e
 // entry agree in 52 hash bits: it happens once in ~10^9 builds and only sends a k-mer down the ordered path, which is
 // exact for any superset of the truly contended k-mers).  An entry collects which values are wanted there; a second pass
 // marks every candidate that meets the opposite value on one of its positions as contended.
-template <int NHM, int BT> __global__ __launch_bounds__(BT) void k_round_detect(BlockDev bd)
+template <int NHM, int BT> __global__ __launch_bounds__(BT) void k_round_detect(BlockDev bd, int i0)
 {
 	constexpr int NBIN = KMX_CL_BINS(NHM), T = 1 << KMX_CL_TBITS;
 	__shared__ u32 s_t[T];
-	const int i = blockIdx.y, b = blockIdx.x;
+	const int i = i0 + (int)blockIdx.y, b = blockIdx.x;
 	int *gc = bd.cl_cnt + i * KMX_CL_MAXBINS + b;
 	int cnt = *gc;
 	if (cnt == 0) return;                                            // uniform: nothing was emitted into this bin
@@ -614,17 +619,16 @@ template <int W> __device__ __forceinline__ u32 rec_load(const u64 *rec, u64 slo
 // in one word, kmodel.hpp:611-618) and the km_back insert (:548-550) -- no second look at the cells.  Contended ones file
 // a record in U[0] (with the untagged mask of the check) and place their reservations right away (epoch `epoch`), which
 // saves the first reserve pass of the ordered slow path.
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit(ModelDev md, BlockDev bd, int t, int pp, u64 epoch)
+template <int W, int NHM> __device__ __forceinline__ void commit_body(const ModelDev &md, const BlockDev &bd, int t, int pp, u64 epoch, int i, int bx, int gx)
 {
 	__shared__ int s_cnt, s_base;
-	const int i = blockIdx.y;
 	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;
 	const int sbase = a * md.nh;
 	cell_t *cells = md.cells[a];
 	const bool all_contended = bd.cl_ovf[i] != 0;
-	for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+	for (int base = bx * 256; base < n; base += gx * 256) {
 		if (threadIdx.x == 0) s_cnt = 0;
 		__syncthreads();
 		const int x = base + threadIdx.x;
@@ -663,6 +667,26 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit(
 		if (contended) rec_store<W>(bd.Urec[0], row + p, (u32)x, bin, v, um);
 		__syncthreads();
 	}
+}
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit(ModelDev md, BlockDev bd, int t, int pp, u64 epoch, int i0)
+{
+	commit_body<W, NHM>(md, bd, t, pp, epoch, i0 + (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------------ B|A: commit of one list beside the check of the next
+// The lists of a round work on different arrays, so list i can commit while list i+1 is examined.  The check is bound by
+// random 4-byte gathers, the commit by memory-side atomics; side by side the two take ~3/4 of what they take one after
+// the other (tools/microbench_pair.py), so the big rounds run as a software pipeline over the lists:
+//   check(G0) detect(G0) [commit(G0)|check(G1)] detect(G1) ... commit(G_last)          G = a group of lists
+// One list is a single residency wave of workgroups on this chip, so a per-list pipeline is latency-bound and loses
+// (84.0 ms against 77.9 for whole-round kernels); two groups, the bigger first, is the split that pays (76.1-76.6 ms):
+// gathers ride almost free beside atomics, not the other way round.  Even workgroups commit, odd ones check, so both
+// kinds are resident on every CU from the first wave of workgroups on (all of one kind first: no gain).
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit_check(ModelDev md, BlockDev bd, int t, int pp, u64 epoch, int i_commit, int n_commit, int i_check, int n_check)
+{
+	const int bx = (int)(blockIdx.x >> 1), gx = (int)(gridDim.x >> 1), y = (int)blockIdx.y;
+	if (blockIdx.x & 1) { if (y < n_check) check_emit_body<W, NHM, true>(md, bd, t, pp, i_check + y, bx, gx); }
+	else if (y < n_commit) commit_body<W, NHM>(md, bd, t, pp, epoch, i_commit + y, bx, gx);
 }
 
 // ------------------------------------------------------------------------------------------ S: ordered slow path
@@ -1194,7 +1218,7 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 // Also closes the round's books: successes = n - m.
 // Before that, it applies what the finisher decided but left undone (REC_WON records of level lv): tag/value bits
 // (kmodel.hpp:611-618, every position: an already tagged one carries the same value) and the km_back insert (:548-550).
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(ModelDev md, BlockDev bd, int t, int pp, int lv)
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(ModelDev md, BlockDev bd, int t, int pp, int lv, int piped_commits)
 {
 	__shared__ int s_tmp[4];
 	__shared__ int s_m, s_off;
@@ -1262,6 +1286,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 	if (tile == 0 && threadIdx.x == 0) {
 		bd.cl_ovf[i] = 0;
 		if (n > m) atomicAdd(bd.stats + ST_SUCCESSES, (u64)(n - m));
+		if (n > m && i < piped_commits) atomicAdd(bd.stats + ST_PIPE_SUCC, (u64)(n - m));
 		bd.n[pp ^ 1][i] = m;                                       // (the record counters are reset by the next check_emit)
 	}
 }
@@ -2074,17 +2099,43 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	// lists shrink by roughly half per round; the kernels are grid-stride, so a smaller grid is only a speed choice
 	const int gx = (KMX_BUCKET / 256) >> (t < 4 ? t : 4);
 	const dim3 grid(gx, nb), blk(256), sgrid(SLOW_BLOCKS, nb);
-	KPROF_BEGIN(prof, KC_CHECK_CLAIM, st);
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_emit<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
-	KPROF_END(prof, st);
-	KPROF_BEGIN(prof, KC_DETECT, st);
-	if (md.nh <= 8) hipLaunchKernelGGL((k_round_detect<8, 1024>), dim3(KMX_CL_BINS(8), nb), dim3(1024), 0, st, bd);       // (256 threads for the late rounds' few
-	else hipLaunchKernelGGL((k_round_detect<16, 1024>), dim3(KMX_CL_BINS(16), nb), dim3(1024), 0, st, bd);               //  hundred tuples per bin measured slower)
-	KPROF_END(prof, st);
 	const u64 eb = (*epoch)++;                                 // k_round_commit's reservations
-	KPROF_BEGIN(prof, KC_VERIFY_COMMIT, st);
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit<W, NHM>), grid, blk, 0, st, md, bd, t, pp, eb));
-	KPROF_END(prof, st);
+	auto detect = [&](int i0, int n_lists) {
+		KPROF_BEGIN(prof, KC_DETECT, st);
+		if (md.nh <= 8) hipLaunchKernelGGL((k_round_detect<8, 1024>), dim3(KMX_CL_BINS(8), n_lists), dim3(1024), 0, st, bd, i0);   // (256 threads for the late rounds' few
+		else hipLaunchKernelGGL((k_round_detect<16, 1024>), dim3(KMX_CL_BINS(16), n_lists), dim3(1024), 0, st, bd, i0);           //  hundred tuples per bin measured slower)
+		KPROF_END(prof, st);
+	};
+	int groups = (flags >> KMX_ROUND_PIPE_SHIFT) & 15;          // 0: whole-round kernels; P: the lists in P groups, pipelined
+	if (groups > nb) groups = nb;
+	int piped_commits = 0;                                     // lists [0, piped_commits) committed inside k_round_commit_check
+	if (groups > 1 && t < KMX_PIPE_ROUNDS) {
+		// software pipeline over groups of lists (k_round_commit_check); group g = lists [lo(g), lo(g+1)), the bigger groups first
+		auto lo = [&](int g) { return (g * nb + groups - 1) / groups; };
+		KPROF_BEGIN(prof, KC_CHECK_CLAIM, st);
+		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_emit<W, NHM>), dim3(gx, lo(1)), blk, 0, st, md, bd, t, pp, 0));
+		KPROF_END(prof, st);
+		for (int g = 0; g + 1 < groups; g++) {
+			const int nc = lo(g + 1) - lo(g), nk = lo(g + 2) - lo(g + 1);
+			detect(lo(g), nc);
+			KPROF_BEGIN(prof, KC_COMMIT_CHECK, st);
+			DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit_check<W, NHM>), dim3(2 * gx, nc > nk ? nc : nk), blk, 0, st, md, bd, t, pp, eb, lo(g), nc, lo(g + 1), nk));
+			KPROF_END(prof, st);
+		}
+		piped_commits = lo(groups - 1);
+		detect(lo(groups - 1), nb - lo(groups - 1));
+		KPROF_BEGIN(prof, KC_VERIFY_COMMIT, st);
+		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit<W, NHM>), dim3(gx, nb - lo(groups - 1)), blk, 0, st, md, bd, t, pp, eb, lo(groups - 1)));
+		KPROF_END(prof, st);
+	} else {
+		KPROF_BEGIN(prof, KC_CHECK_CLAIM, st);
+		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_emit<W, NHM>), grid, blk, 0, st, md, bd, t, pp, 0));
+		KPROF_END(prof, st);
+		detect(0, nb);
+		KPROF_BEGIN(prof, KC_VERIFY_COMMIT, st);
+		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit<W, NHM>), grid, blk, 0, st, md, bd, t, pp, eb, 0));
+		KPROF_END(prof, st);
+	}
 	KPROF_BEGIN(prof, KC_SLOW, st);
 	const bool legacy0 = flags & KMX_ROUND_RESOLVE_GATHER;      // test hook: the gathering resolve kernel for level 0 too
 	for (int s = 0; s < nsub; s++) {
@@ -2102,7 +2153,7 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb, 1), dim3(1024), 0, st, md, bd, t, pp, nsub, eb, e0, force_global));
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_REORDER, st);
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, nb), dim3(256), 0, st, md, bd, t, pp, nsub & 1));
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, nb), dim3(256), 0, st, md, bd, t, pp, nsub & 1, piped_commits));
 	KPROF_END(prof, st);
 }
 

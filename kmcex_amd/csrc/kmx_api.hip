@@ -389,7 +389,8 @@ static int create_device_side(kmx_model *m)
 		auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
 		m->dbg_nsub0 = env_int("KMX_NSUB0", -1);
 		m->dbg_nsub1 = env_int("KMX_NSUB1", -1);
-		m->dbg_flags = (env_int("KMX_FIN_GLOBAL", 0) ? KMX_ROUND_FIN_GLOBAL : 0) | (env_int("KMX_RESOLVE_GATHER", 0) ? KMX_ROUND_RESOLVE_GATHER : 0);
+		m->dbg_flags = (env_int("KMX_FIN_GLOBAL", 0) ? KMX_ROUND_FIN_GLOBAL : 0) | (env_int("KMX_RESOLVE_GATHER", 0) ? KMX_ROUND_RESOLVE_GATHER : 0)
+		               | ((env_int("KMX_PIPE", 2) & 15) << KMX_ROUND_PIPE_SHIFT);   // groups of lists the big rounds are pipelined over (0: off)   // KMX_PIPE=0: every round as whole-round kernels
 		m->dbg_ctrl = env_int("KMX_CTRL_DEBUG", 0) != 0;
 		m->dbg_kmb_direct = env_int("KMX_KMB_DIRECT", 0) != 0;
 	}
@@ -1414,7 +1415,8 @@ static int kmx_ring_round_dev_impl(kmx_model *m, int t, const kmx_ring_list *lis
 	}
 	if (t == 0) steer_passes(m);
 	kmxk::ring_import(m->md, m->bd, rl, m->d_stg_kmers, m->d_stg_counts, m->stream);
-	kmxk::round(m->md, m->bd, t, 0, passes_of_round(m, t), &m->epoch, m->dbg_flags, m->stream, &m->prof);
+	// (a rank holds one or two of the round's lists: nothing to pipeline)
+	kmxk::round(m->md, m->bd, t, 0, passes_of_round(m, t), &m->epoch, m->dbg_flags & ~(15 << KMX_ROUND_PIPE_SHIFT), m->stream, &m->prof);
 	TRY(kmback_emit(m, t, 0, -1, (u64)n_lists * KMX_BUCKET));
 	m->rounds++;
 	bool any_out = false;
@@ -1936,6 +1938,7 @@ static int kmx_get_stats_impl(kmx_model *m, kmx_stats *st)
 	st->fast_commits = m->h_stats[ST_SUCCESSES] - m->h_stats[ST_SLOW_SUCC]; st->contended = m->h_stats[ST_CONTENDED]; st->finisher_iters = m->h_stats[ST_FIN_ITERS];
 	st->rest_entries = m->rest.entries; st->km_byte_size = m->km_byte_size; st->byte_km_back = m->byte_km_back;
 	st->blocks = m->blocks; st->rounds = m->rounds;
+	st->piped_attempts = m->h_stats[ST_PIPE_ATTEMPTS]; st->piped_commits = m->h_stats[ST_PIPE_SUCC];
 	st->rest_bytes = m->rest.suff_bin_size + 4 * m->rest.entries + 4 * (u64)m->rest.pre_buffer_size + 4 * (u64)m->rest.map_size;
 	st->k = m->k; st->ci = m->ci; st->cs = m->cs; st->nh = m->nh; st->nb = m->nb; st->bf_num = m->bf_num; st->device = m->device;
 	return KMX_OK;
@@ -1990,9 +1993,55 @@ static int kmx_debug_mod_impl(const uint64_t *h, uint64_t n, uint64_t d, uint64_
 	return KMX_OK;
 }
 
+// mode 20: the 4-byte gathers (mode 8) on one stream and the 32-bit atomic ORs (mode 5) on another, side by side, each on
+// its own buffer; seconds = wall time until both are done.  Compared with the sum of the two alone it says whether the
+// gather-bound and the atomic-bound kernels of a round could hide behind each other.
+static int microbench_pair(uint64_t bytes, uint64_t touches, int iters, double *seconds)
+{
+	DevMem b0, b1, sinkm;
+	const u64 ncell = bytes / 8, lanes = touches / 8;
+	HIPCHK(b0.alloc(ncell * 8));
+	HIPCHK(b1.alloc(ncell * 8));
+	HIPCHK(sinkm.alloc(8));
+	HIPCHK(hipMemset(b0.as<u64>(), 0, ncell * 8));
+	HIPCHK(hipMemset(b1.as<u64>(), 0, ncell * 8));
+	hipStream_t s0 = nullptr, s1 = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr, j = nullptr;
+	auto guard = scope_exit([&] {
+		if (e0) hipEventDestroy(e0);
+		if (e1) hipEventDestroy(e1);
+		if (j) hipEventDestroy(j);
+		if (s0) hipStreamDestroy(s0);
+		if (s1) hipStreamDestroy(s1);
+	});
+	HIPCHK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+	HIPCHK(hipEventCreate(&e0));
+	HIPCHK(hipEventCreate(&e1));
+	HIPCHK(hipEventCreateWithFlags(&j, hipEventDisableTiming));
+	kmxk::micro(8, b0.as<u64>(), ncell, lanes, 12345, sinkm.as<u64>(), s0);
+	kmxk::micro(5, b1.as<u64>(), ncell, lanes, 12345, sinkm.as<u64>(), s1);
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipEventRecord(e0, s0));
+	HIPCHK(hipStreamWaitEvent(s1, e0, 0));
+	for (int it = 0; it < iters; it++) {
+		kmxk::micro(8, b0.as<u64>(), ncell, lanes, 1000003ULL * (it + 1), sinkm.as<u64>(), s0);
+		kmxk::micro(5, b1.as<u64>(), ncell, lanes, 1000003ULL * (it + 1), sinkm.as<u64>(), s1);
+	}
+	HIPCHK(hipEventRecord(j, s1));
+	HIPCHK(hipStreamWaitEvent(s0, j, 0));
+	HIPCHK(hipEventRecord(e1, s0));
+	HIPCHK(hipEventSynchronize(e1));
+	float ms = 0;
+	HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+	*seconds = ms * 1e-3 / iters;
+	return KMX_OK;
+}
+
 static int kmx_microbench_impl(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds)
 {
 	if (bytes < 4096 || touches < 8 || iters < 1 || !seconds) return fail(KMX_E_ARG, "bad arguments");
+	if (mode == 20) return microbench_pair(bytes, touches, iters, seconds);
 	DevMem bufm, sinkm;
 	const u64 ncell = bytes / 8, lanes = touches / 8;
 	HIPCHK(bufm.alloc(ncell * 8));

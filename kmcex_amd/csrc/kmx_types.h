@@ -56,7 +56,9 @@ struct KmcDecode {
 };
 
 // device-side statistics (one u64 each)
-enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_MAX_U0, ST_MAX_UFIN, ST_N };
+enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_MAX_U0, ST_MAX_UFIN,
+       ST_PIPE_ATTEMPTS, ST_PIPE_SUCC,        // attempts examined / successes committed inside k_round_commit_check launches (accounting only)
+       ST_N };
 
 #define KMX_CLS_TILE 2048                      // k-mers per classification tile (front end)
 #define KMX_RSIZE_LOG2 20
@@ -64,7 +66,11 @@ enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, 
 #define KMX_FIN_RPT(NHM) ((NHM) <= 8 ? 2 : 1)      // records per finisher thread kept in registers (1024 threads)
 #define KMX_FIN_RANGES 8                        // the finisher takes up to this many register loads, in index ranges
 #define KMX_APPLY_WGS 8                         // extra workgroups per list in k_reorder that apply the finisher's decisions
-enum { KMX_ROUND_FIN_GLOBAL = 1, KMX_ROUND_RESOLVE_GATHER = 2 };   // test hooks of kmxk::round (older code paths)
+enum { KMX_ROUND_FIN_GLOBAL = 1, KMX_ROUND_RESOLVE_GATHER = 2,     // test hooks of kmxk::round (older code paths)
+       KMX_ROUND_PIPE_SHIFT = 4 };                                   // bits 4..7: the big rounds as a software pipeline over this many groups of lists
+#ifndef KMX_PIPE_ROUNDS
+#define KMX_PIPE_ROUNDS 2                      // rounds 0 .. KMX_PIPE_ROUNDS-1 are pipelined (later lists are too short to pay for the launches)
+#endif
 #define KMX_NSLOW 2                            // contended-record levels, ping-pong: pass s reads level s&1, defers to (s+1)&1
 #define KMX_MAX_NSUB 16                        // most grid-wide ordered passes per round
 #define KMX_CTR_STRIDE 32                      // ints between per-list counters: one 128-byte line each (same-line atomics serialise)
@@ -124,7 +130,7 @@ struct RingLists { RingList e[KMX_MAX_NB]; };
 enum { SLOT_UNDECIDED = 0, SLOT_FAILED = 1, SLOT_INSERTED = 2, SLOT_CONTENDED = 3 };
 
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
-enum { KC_CLASSIFY = 0, KC_CHECK_CLAIM, KC_VERIFY_COMMIT, KC_SLOW, KC_REORDER, KC_REST, KC_QUERY, KC_DETECT, KC_N };   // CHECK_CLAIM = check + emit, VERIFY_COMMIT = commit
+enum { KC_CLASSIFY = 0, KC_CHECK_CLAIM, KC_VERIFY_COMMIT, KC_SLOW, KC_REORDER, KC_REST, KC_QUERY, KC_DETECT, KC_COMMIT_CHECK, KC_N };   // CHECK_CLAIM = check + emit, VERIFY_COMMIT = commit
 struct KernelProf {
 	bool on = false;
 	void *events = nullptr;      // std::vector<hipEvent_t>* owned by the host side
