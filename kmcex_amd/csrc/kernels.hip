@@ -1298,6 +1298,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 __global__ __launch_bounds__(1024) void k_bs_apply(BitScatter bs)
 {
 	__shared__ u32 s_tile[BS_TILE_WORDS];
+	const u32 TW = 1u << (bs.tlog2 - 5);                             // words per tile (BS_TILE_WORDS outside the test hook)
 	const u32 b = blockIdx.x;
 	u32 cnt = (u32)bs.cnt[b];
 	if (cnt == 0) return;                                            // uniform
@@ -1307,8 +1308,8 @@ __global__ __launch_bounds__(1024) void k_bs_apply(BitScatter bs)
 	const u32 nw = (u32)((bs.nwords - word0) < wpb ? (bs.nwords - word0) : wpb);
 	const u32 *tup = bs.tup + (u64)b * bs.cap;
 	u32 *words = bs.words + word0;
-	for (u32 t0 = 0; t0 < nw; t0 += BS_TILE_WORDS) {
-		const u32 tw = nw - t0 < BS_TILE_WORDS ? nw - t0 : BS_TILE_WORDS;
+	for (u32 t0 = 0; t0 < nw; t0 += TW) {
+		const u32 tw = nw - t0 < TW ? nw - t0 : TW;
 		for (u32 w = threadIdx.x; w < tw; w += 1024) s_tile[w] = 0;
 		__syncthreads();
 		for (u32 q = threadIdx.x; q < cnt; q += 1024) {
@@ -1323,6 +1324,85 @@ __global__ __launch_bounds__(1024) void k_bs_apply(BitScatter bs)
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) bs.cnt[b] = 0;
+}
+
+// Second level for big filters.  k_bs_split: the tuples of bin blockIdx.y are dealt to the bin's tiles the way
+// bs_block_emit dealt them to the bins (per-tile counts in LDS, ONE global atomic per run, LDS-staged run-by-run
+// write-out); a tile that is full gets the bit set with an atomic instead (exact either way).
+#define BS_SPLIT_K 8
+__global__ __launch_bounds__(256) void k_bs_split(BitScatter bs)
+{
+	__shared__ int s_cnt[1 << BS_MAX_TILES_LOG2], s_off[1 << BS_MAX_TILES_LOG2], s_base[1 << BS_MAX_TILES_LOG2], s_tmp[4];
+	__shared__ u32 s_stage[256 * BS_SPLIT_K];
+	const u32 b = blockIdx.y, tl = bs.wshift - bs.tlog2, tmask = (1u << bs.tlog2) - 1;
+	u32 cnt = (u32)bs.cnt[b];
+	if (cnt > bs.cap) cnt = bs.cap;
+	const u32 *tup = bs.tup + (u64)b * bs.cap;
+	u32 *out = bs.tup2 + (((u64)b << tl) * bs.cap2);
+	int *gcnt = bs.cnt2 + ((u64)b << tl);
+	for (u32 base = blockIdx.x * (256 * BS_SPLIT_K); base < cnt; base += gridDim.x * (256 * BS_SPLIT_K)) {   // uniform trip count
+		s_cnt[threadIdx.x] = 0;
+		__syncthreads();
+		u32 o[BS_SPLIT_K];
+		int rank[BS_SPLIT_K];
+#pragma unroll
+		for (int j = 0; j < BS_SPLIT_K; j++) {
+			const u32 q = base + j * 256 + threadIdx.x;
+			o[j] = q < cnt ? tup[q] : ~0u;
+		}
+#pragma unroll
+		for (int j = 0; j < BS_SPLIT_K; j++)
+			if (o[j] != ~0u) rank[j] = atomicAdd(&s_cnt[o[j] >> bs.tlog2], 1);
+		__syncthreads();
+		int total;
+		{
+			const int c = s_cnt[threadIdx.x];
+			const int ex = block_excl_scan_256(c, s_tmp, &total);
+			s_off[threadIdx.x] = ex;
+			s_base[threadIdx.x] = c ? atomicAdd(gcnt + threadIdx.x, c) : 0;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int j = 0; j < BS_SPLIT_K; j++)
+			if (o[j] != ~0u) s_stage[s_off[o[j] >> bs.tlog2] + rank[j]] = o[j];
+		__syncthreads();
+		for (int q = threadIdx.x; q < total; q += 256) {
+			const u32 e = s_stage[q], t = e >> bs.tlog2;
+			const u32 g = (u32)s_base[t] + (u32)(q - s_off[t]);
+			if (g < bs.cap2) out[(u64)t * bs.cap2 + g] = e & tmask;
+			else atomicOr(bs.words + (((u64)b << bs.wshift) >> 5) + (e >> 5), 1u << (e & 31));
+		}
+		__syncthreads();
+	}
+}
+// k_bs_apply2: one workgroup per (tile, bin).  Only this workgroup writes these words during the launch (k_bs_split's
+// atomics for full tiles came in the launch before).
+__global__ __launch_bounds__(1024) void k_bs_apply2(BitScatter bs)
+{
+	__shared__ u32 s_tile[BS_TILE_WORDS];
+	const u32 b = blockIdx.y, t = blockIdx.x, tl = bs.wshift - bs.tlog2, TW = 1u << (bs.tlog2 - 5);
+	int *gc = bs.cnt2 + (((u64)b << tl) + t);
+	u32 cnt = (u32)*gc;
+	if (t == 0 && threadIdx.x == 0) bs.cnt[b] = 0;                   // (k_bs_split has read it, a launch ago)
+	if (cnt == 0) return;                                            // uniform
+	if (cnt > bs.cap2) cnt = bs.cap2;
+	const u64 word0 = (((u64)b << bs.wshift) >> 5) + (u64)t * TW;
+	if (word0 >= bs.nwords) { if (threadIdx.x == 0) *gc = 0; return; }
+	const u32 tw = (u32)((bs.nwords - word0) < TW ? (bs.nwords - word0) : TW);
+	const u32 *tup = bs.tup2 + (((u64)b << tl) + t) * bs.cap2;
+	u32 *words = bs.words + word0;
+	for (u32 w = threadIdx.x; w < tw; w += 1024) s_tile[w] = 0;
+	__syncthreads();
+	for (u32 q = threadIdx.x; q < cnt; q += 1024) {
+		const u32 o = tup[q];
+		if ((o >> 5) < tw) atomicOr(&s_tile[o >> 5], 1u << (o & 31));
+	}
+	__syncthreads();
+	for (u32 w = threadIdx.x; w < tw; w += 1024) {
+		const u32 x = s_tile[w];
+		if (x) words[w] |= x;
+	}
+	if (threadIdx.x == 0) *gc = 0;
 }
 
 // km_back insert of a round (kmodel.hpp:548-550), deferred: every slot the round decided as inserted -- by the parallel
@@ -2041,6 +2121,7 @@ namespace kmxk {
 	} while (0)
 
 static inline int words(const ModelDev &md) { return (md.k + 31) / 32; }
+void bs_apply(const BitScatter &bs, hipStream_t st);
 
 void histogram(const u32 *counts, u64 n, int ci, int cs, int bf_num, u64 *n_bf, u64 *stats, hipStream_t st)
 {
@@ -2054,21 +2135,22 @@ void histogram(const u32 *counts, u64 n, int ci, int cs, int bf_num, u64 *n_bf, 
 int classify_tiles(u64 n) { return (int)((n + CLS_TILE - 1) / CLS_TILE); }
 
 // Front end of `n` k-mers cut into chunks of `chunk` k-mers (a multiple of CLS_TILE): the Bloom-class k-mers are inserted
-// (directly, or half a chunk at a time through the BitScatter `bs`, swept right away) and the coupled-array k-mers are
-// counted per tile; one small scan per chunk turns the counts into offsets relative to the chunk start and the chunk's
-// total (totals[c]).
-void classify_count(const ModelDev &md, const u64 *kmers, const u32 *counts, u64 n, u64 chunk, int *tile_cnt, int *tile_off, int *totals, u64 *stats, const BitScatter &bs, hipStream_t st, KernelProf *prof)
+// (directly, or a chunk at a time through the BitScatter `bs`, swept after every `sweep_every` chunks and at the end) and
+// the coupled-array k-mers are counted per tile; one small scan per chunk turns the counts into offsets relative to the
+// chunk start and the chunk's total (totals[c]).
+void classify_count(const ModelDev &md, const u64 *kmers, const u32 *counts, u64 n, u64 chunk, int *tile_cnt, int *tile_off, int *totals, u64 *stats, const BitScatter &bs, int sweep_every, hipStream_t st, KernelProf *prof)
 {
 	if (!n) return;
 	const int tiles = classify_tiles(n), tiles_per_chunk = (int)(chunk / CLS_TILE);
 	const int W_ = words(md);
 	KPROF_BEGIN(prof, KC_CLASSIFY, st);
 	const u64 piece = md.bloom_direct ? n : chunk;                  // k-mers per launch: what the bins of the BitScatter take (a bin that fills up falls back to atomics)
+	int since = 0;
 	for (u64 lo = 0; lo < n; lo += piece) {
 		const u64 c = n - lo < piece ? n - lo : piece;
 		const int t0 = (int)(lo / CLS_TILE), nt = classify_tiles(c);
 		DISPATCH_W_NH(W_, md.nh, hipLaunchKernelGGL((k_classify_count<W, NHM>), dim3(nt), dim3(256), 0, st, md, kmers + lo * W_, counts + lo, c, tile_cnt + t0, stats, bs));
-		if (!md.bloom_direct) hipLaunchKernelGGL(k_bs_apply, dim3(BS_BINS), dim3(1024), 0, st, bs);
+		if (!md.bloom_direct && (++since >= sweep_every || lo + piece >= n)) { bs_apply(bs, st); since = 0; }
 	}
 	KPROF_END(prof, st);
 	for (int c = 0, t0 = 0; t0 < tiles; c++, t0 += tiles_per_chunk) {
@@ -2179,7 +2261,10 @@ void kmback_emit(const ModelDev &md, const BlockDev &bd, int t, int pp, int n_in
 }
 void bs_apply(const BitScatter &bs, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_bs_apply, dim3(BS_BINS), dim3(1024), 0, st, bs);
+	if (!bs.cap2) { hipLaunchKernelGGL(k_bs_apply, dim3(BS_BINS), dim3(1024), 0, st, bs); return; }
+	const unsigned per_bin = (bs.cap + 256 * BS_SPLIT_K - 1) / (256 * BS_SPLIT_K);
+	hipLaunchKernelGGL(k_bs_split, dim3(per_bin < 64 ? per_bin : 64, BS_BINS), dim3(256), 0, st, bs);
+	hipLaunchKernelGGL(k_bs_apply2, dim3(1u << (bs.wshift - bs.tlog2), BS_BINS), dim3(1024), 0, st, bs);
 }
 
 void kmc_decode(const KmcDecode &d, int W_, u64 rec0, u64 n, u64 *kmers, u32 *counts, hipStream_t st)

@@ -30,7 +30,7 @@
 namespace kmxk {
 void histogram(const u32 *, u64, int, int, int, u64 *, u64 *, hipStream_t);
 int classify_tiles(u64 n);
-void classify_count(const ModelDev &, const u64 *, const u32 *, u64, u64, int *, int *, int *, u64 *, const BitScatter &, hipStream_t, KernelProf *);
+void classify_count(const ModelDev &, const u64 *, const u32 *, u64, u64, int *, int *, int *, u64 *, const BitScatter &, int, hipStream_t, KernelProf *);
 void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int *, u64 *, u32 *, u64, hipStream_t);
 void block_init(const BlockDev &, int, int, int, hipStream_t);
 void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *);
@@ -207,8 +207,10 @@ struct kmx_model {
 	// Bloom-class k-mers of the front end as a partitioned bit-set over the slab (k_classify_count emits, k_bs_apply sweeps)
 	BitScatter blm;
 	u32 *d_blm_tup = nullptr;
+	u64 blm_tup_cap = 0;
 	int *d_blm_cnt = nullptr;
 	bool blm_deferred = false;
+	int blm_sweep_every = 1;                                   // chunks of the front end per sweep of the slab
 	// km_back insert as a partitioned bit-set (k_kmback_emit per round, k_bs_apply every few blocks)
 	BitScatter kmb;
 	u32 *d_kmb_tup = nullptr;
@@ -217,6 +219,9 @@ struct kmx_model {
 	u64 kmb_pending = 0, kmb_budget = 0;                       // upper bound of tuples emitted since the last apply / what the bins take
 	bool kmb_deferred = false;
 	bool dbg_kmb_direct = false;                               // KMX_KMB_DIRECT=1: the atomic path at every size (test hook)
+	u32 *d_bs2_tup = nullptr;                                  // second level of the two bit-sets (big filters), shared: [bins * tiles][cap2]
+	int *d_bs2_cnt = nullptr;
+	u64 bs2_tup_cap = 0, bs2_cnt_cap = 0;
 	// feed of KModel::init(db): pinned slots, device buffers, copy stream -- kept across calls on the handle (allocating and
 	// freeing ~300 MB of pinned + device memory costs ~30 ms per call on this stack)
 	struct KmcFeed {
@@ -326,9 +331,13 @@ static void free_build_state(kmx_model *m)
 	hipFree(m->d_total); m->d_total = nullptr;
 	hipFree(m->d_blm_tup); m->d_blm_tup = nullptr;
 	hipFree(m->d_blm_cnt); m->d_blm_cnt = nullptr;
+	m->blm_tup_cap = 0;
 	hipFree(m->d_kmb_tup); m->d_kmb_tup = nullptr;
 	hipFree(m->d_kmb_cnt); m->d_kmb_cnt = nullptr;
 	m->kmb_tup_cap = 0;
+	hipFree(m->d_bs2_tup); m->d_bs2_tup = nullptr;
+	hipFree(m->d_bs2_cnt); m->d_bs2_cnt = nullptr;
+	m->bs2_tup_cap = m->bs2_cnt_cap = 0;
 	m->stg_n = m->stg_cap = 0;
 }
 
@@ -507,18 +516,56 @@ static int alloc_arrays(kmx_model *m)
 	return KMX_OK;
 }
 
-// km_back as a partitioned bit-set: bins of a power-of-two number of positions, swept in tiles of 2^20.  The sweep re-reads
-// a bin's tuples once per tile and the whole filter once per sweep: up to 8 tiles per bin (a filter of 256 MB: ~8*10^8
-// coupled k-mers at nh = 7) that is far cheaper than one memory-side atomic per bit; with 32 tiles it LOSES (measured at
-// 2.5*10^9 k-mers: warm build 2.66 s -> 4.14 s, the sweeps of a 680 MB km_back and a 550 MB Bloom slab cost more than the
-// atomics they replace), so larger filters keep the direct atomic path until a second partition level exists.
+// km_back as a partitioned bit-set: bins of a power-of-two number of positions, swept in tiles of 2^20.  Up to 8 tiles per
+// bin (a filter of 256 MB: ~8*10^8 coupled k-mers at nh = 7) one workgroup per bin sweeps its tiles one after the other and
+// re-reads the bin's tuples for each (k_bs_apply); doing that with 32 tiles LOSES against plain atomics (2.5*10^9 k-mers:
+// warm build 2.66 s -> 4.14 s).  Bigger filters get a second level: k_bs_split deals every bin's tuples to its tiles
+// (up to 256 per bin: filters of 8 GB), k_bs_apply2 sweeps one tile per workgroup, so every tuple and every word of the
+// filter is read once per sweep.  Beyond 2^36 positions the direct atomic path stays.
 static const u32 kBsMaxTileShift = 3;
-// test hook: KMX_BS_CAP=<tuples per bin> shrinks the bins of both partitioned bit-sets, so that producers meet full bins
-// all the time and set those bits with atomics instead (the result must not change); read once per process
+// test hooks: KMX_BS_CAP=<tuples per bin> (read once per process) shrinks the bins of both partitioned bit-sets, so that
+// producers meet full bins all the time and set those bits with atomics instead (the result must not change);
+// KMX_BS_TILE_LOG2=<t> (10..20) shrinks the tiles, so that small filters take the multi-tile and the two-level sweeps
 static u64 bs_cap_hook()
 {
 	static const u64 v = [] { const char *e = getenv("KMX_BS_CAP"); const long long x = e ? atoll(e) : 0; return x > 0 ? (u64)std::min<long long>(x, 1 << 18) : 0ull; }();
 	return v;
+}
+static u32 bs_tile_log2()
+{
+	const char *e = getenv("KMX_BS_TILE_LOG2");                    // (read at every kmx_begin, so one test process can try several)
+	const int x = e ? atoi(e) : 20;
+	return (u32)std::min(std::max(x, 10), 20);
+}
+// geometry of a partitioned bit-set over `nwords` words: false when the filter is too big for it.  L2 storage (shared by
+// the two bit-sets of a model: their sweeps never overlap) is grown to what this one needs.
+static int bs_geometry(kmx_model *m, BitScatter &bs, u64 nwords, u64 cap, bool *ok)
+{
+	*ok = false;
+	const u32 tlog2 = bs_tile_log2();
+	u32 wshift = 5;
+	while ((((u64)BS_BINS) << wshift) < nwords * 32) wshift++;
+	if (wshift > tlog2 + BS_MAX_TILES_LOG2 || wshift > 32) return KMX_OK;
+	bs.nwords = nwords; bs.wshift = wshift; bs.tlog2 = tlog2; bs.cap = (u32)cap;
+	bs.cap2 = 0; bs.tup2 = nullptr; bs.cnt2 = nullptr;
+	if (wshift > tlog2 + kBsMaxTileShift) {
+		const u32 tiles = 1u << (wshift - tlog2);
+		// uniform hashing: a tile receives cap/tiles tuples on average when the bin is full; 1/4 more + 256 never fills in
+		// practice (and a full tile only costs atomics)
+		const u64 cap2 = bs_cap_hook() ? std::max<u64>(bs_cap_hook() / 4, 8) : (cap / tiles + cap / (4 * tiles) + 256);
+		const u64 need = (u64)BS_BINS * tiles * cap2, ncnt = (u64)BS_BINS * tiles;
+		if (m->bs2_tup_cap < need || m->bs2_cnt_cap < ncnt) {
+			HIPCHK(hipStreamSynchronize(m->stream));
+			hipFree(m->d_bs2_tup); hipFree(m->d_bs2_cnt);
+			m->d_bs2_tup = nullptr; m->d_bs2_cnt = nullptr; m->bs2_tup_cap = m->bs2_cnt_cap = 0;
+			TRY(dalloc(&m->d_bs2_tup, need, false, m->stream));
+			TRY(dalloc(&m->d_bs2_cnt, ncnt, true, m->stream));
+			m->bs2_tup_cap = need; m->bs2_cnt_cap = ncnt;
+		}
+		bs.cap2 = (u32)cap2;
+	}
+	*ok = true;
+	return KMX_OK;
 }
 static int setup_kmback_scatter(kmx_model *m)
 {
@@ -528,14 +575,16 @@ static int setup_kmback_scatter(kmx_model *m)
 	if (m->dbg_kmb_direct || nwords == 0) return KMX_OK;
 	u32 wshift = 5;
 	while ((((u64)BS_BINS) << wshift) < nwords * 32) wshift++;
-	if (wshift > 20 + kBsMaxTileShift) return KMX_OK;              // too many tiles per bin
 	const u64 blk = (u64)m->nb * KMX_BUCKET, per_block = blk * (u64)(m->nh - 2);
-	// tuples per bin: 1 MB while a bin is a few tiles; more when the sweep re-reads the tuples tile after tile, so that
-	// a sweep of the whole filter is shared by more blocks
+	// tuples per bin: 1 MB while a bin is a few tiles; more when the sweep re-reads the tuples tile after tile or the filter
+	// is big, so that a sweep of the whole filter is shared by more blocks
 	u64 cap = wshift <= 22 ? (1u << 18) : (wshift == 23 ? (1u << 19) : (1u << 20));
 	const u64 cap_hook = bs_cap_hook();
 	if (cap_hook) cap = cap_hook;
-	const u64 bins_used = (nwords * 32 + (1ULL << wshift) - 1) >> wshift;
+	bool ok;
+	TRY(bs_geometry(m, m->kmb, nwords, cap, &ok));
+	if (!ok) return KMX_OK;                                        // too big: direct atomics
+	const u64 bins_used = (nwords * 32 + (1ULL << m->kmb.wshift) - 1) >> m->kmb.wshift;
 	if (!m->d_kmb_tup || m->kmb_tup_cap < (u64)BS_BINS * cap) {
 		HIPCHK(hipStreamSynchronize(m->stream));
 		hipFree(m->d_kmb_tup); hipFree(m->d_kmb_cnt);
@@ -544,7 +593,7 @@ static int setup_kmback_scatter(kmx_model *m)
 		TRY(dalloc(&m->d_kmb_cnt, (u64)BS_BINS, true, m->stream));
 		m->kmb_tup_cap = (u64)BS_BINS * cap;
 	}
-	m->kmb.words = m->d_km_back; m->kmb.nwords = nwords; m->kmb.wshift = wshift; m->kmb.cap = (u32)cap;
+	m->kmb.words = m->d_km_back;
 	m->kmb.tup = m->d_kmb_tup; m->kmb.cnt = m->d_kmb_cnt;
 	// positions are hashed uniformly over the used bins: keep the expected fill of a bin below 3/4 (a full bin is still exact)
 	m->kmb_budget = bins_used * cap * 3 / 4;
@@ -553,24 +602,48 @@ static int setup_kmback_scatter(kmx_model *m)
 	return KMX_OK;
 }
 
-// The Bloom slab as a partitioned bit-set: the front end emits half a chunk (2^22 k-mers) and sweeps.  Same limit of
-// 8 tiles per bin; the bins take a half chunk of which ~2/3 is Bloom class (more falls back to atomics, bit by bit).
+// The Bloom slab as a partitioned bit-set: the front end emits a chunk (2^23 k-mers) and sweeps; the bins take a chunk of
+// which ~2/3 is Bloom class (more falls back to atomics, bit by bit).
 static int setup_bloom_scatter(kmx_model *m)
 {
 	m->blm_deferred = false;
 	if (m->dbg_kmb_direct || m->bloom_words == 0) return KMX_OK;
-	u32 wshift = 5;
-	while ((((u64)BS_BINS) << wshift) < m->bloom_words * 32) wshift++;
-	if (wshift > 20 + kBsMaxTileShift) return KMX_OK;
-	const u64 cap = bs_cap_hook() ? bs_cap_hook() : (1u << 18);
-	if (!m->d_blm_tup) {
+	m->blm_sweep_every = 1;
+	// a slab above 256 MB (second level) costs > 0.5 GB of traffic per sweep: bigger bins, so that a sweep serves more chunks
+	const u64 cap = bs_cap_hook() ? bs_cap_hook() : (m->bloom_words > (1ull << 26) ? (1u << 20) : (1u << 18));
+	bool ok;
+	TRY(bs_geometry(m, m->blm, m->bloom_words, cap, &ok));
+	if (!ok) return KMX_OK;
+	if (!m->d_blm_tup || m->blm_tup_cap < (u64)BS_BINS * cap) {
+		HIPCHK(hipStreamSynchronize(m->stream));
+		hipFree(m->d_blm_tup); hipFree(m->d_blm_cnt);
+		m->d_blm_tup = nullptr; m->d_blm_cnt = nullptr; m->blm_tup_cap = 0;
 		TRY(dalloc(&m->d_blm_tup, (u64)BS_BINS * cap, false, m->stream));
 		TRY(dalloc(&m->d_blm_cnt, (u64)BS_BINS, true, m->stream));
+		m->blm_tup_cap = (u64)BS_BINS * cap;
 	}
-	m->blm.words = m->d_bloom; m->blm.nwords = m->bloom_words; m->blm.wshift = wshift; m->blm.cap = (u32)cap;
+	{
+		// chunks per sweep from the EXPECTED number of tuples of a chunk (the share of Bloom-class k-mers is known from pass 1):
+		// positions are hashed uniformly over the used bins, aim at 3/4 of their capacity; a bin that fills up all the same
+		// only costs atomics
+		const u64 bins_used = (m->bloom_words * 32 + (1ULL << m->blm.wshift) - 1) >> m->blm.wshift;
+		u64 nbf = 0;
+		for (int i = 0; i < m->bf_num; i++) nbf += m->n_bf[i];
+		const double per_chunk = (double)kChunk * ((double)nbf / (double)std::max<u64>(m->n_total, 1)) * (double)(2 * m->nh - 3) * 1.25;
+		const double budget = (double)bins_used * (double)cap * 0.75;
+		const double e = per_chunk > 0 ? budget / per_chunk : 1.0;
+		m->blm_sweep_every = (int)std::min(std::max(e, 1.0), 64.0);
+	}
+	m->blm.words = m->d_bloom;
 	m->blm.tup = m->d_blm_tup; m->blm.cnt = m->d_blm_cnt;
 	m->blm_deferred = true;
 	return KMX_OK;
+}
+// (the two bit-sets share the second-level storage: point both at it once both geometries are known)
+static void bs_attach_level2(kmx_model *m)
+{
+	m->kmb.tup2 = m->blm.tup2 = m->d_bs2_tup;
+	m->kmb.cnt2 = m->blm.cnt2 = m->d_bs2_cnt;
 }
 
 // sweep km_back with what the rounds have emitted so far
@@ -611,6 +684,7 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 	m->rest = RestTable();
 	TRY(setup_kmback_scatter(m));
 	TRY(setup_bloom_scatter(m));
+	bs_attach_level2(m);
 	fill_model_dev(m);
 	const int nb = m->nb;
 	const u64 B = KMX_BUCKET, blk = (u64)nb * B;
@@ -818,7 +892,7 @@ static int kmx_insert_batch_dev_impl(kmx_model *m, const uint64_t *d_kmers, cons
 	const u64 *km0 = (const u64 *)d_kmers;
 	const u32 *ct0 = (const u32 *)d_counts;
 	// the order-free front end of the whole batch first (classification, Bloom classes), then the ordered rounds chunk by chunk
-	kmxk::classify_count(m->md, km0, ct0, n, kChunk, m->d_tile_cnt, m->d_tile_off, m->d_totals, m->d_stats, m->blm, m->stream, &m->prof);
+	kmxk::classify_count(m->md, km0, ct0, n, kChunk, m->d_tile_cnt, m->d_tile_off, m->d_totals, m->d_stats, m->blm, m->blm_sweep_every, m->stream, &m->prof);
 	HIPCHK(hipMemcpyAsync(m->h_totals, m->d_totals, n_chunks * 4, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipStreamSynchronize(m->stream));
 	for (u64 ci = 0, done = 0; ci < n_chunks; ci++) {
@@ -1372,7 +1446,7 @@ static int kmx_shard_classify_dev_impl(kmx_model *m, const uint64_t *d_kmers, co
 	HIPCHK(hipSetDevice(m->device));
 	TRY(ensure_front_end(m, n));
 	const u64 n_chunks = (n + kChunk - 1) / kChunk;
-	kmxk::classify_count(m->md, (const u64 *)d_kmers, (const u32 *)d_counts, n, kChunk, m->d_tile_cnt, m->d_tile_off, m->d_totals, m->d_stats, m->blm, m->stream, &m->prof);
+	kmxk::classify_count(m->md, (const u64 *)d_kmers, (const u32 *)d_counts, n, kChunk, m->d_tile_cnt, m->d_tile_off, m->d_totals, m->d_stats, m->blm, m->blm_sweep_every, m->stream, &m->prof);
 	HIPCHK(hipMemcpyAsync(m->h_totals, m->d_totals, n_chunks * 4, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipStreamSynchronize(m->stream));
 	u64 base = 0;

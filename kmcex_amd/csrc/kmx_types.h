@@ -44,7 +44,14 @@ struct BitScatter {
 	u32 cap;                 // tuples per bin; a producer that finds its bin full sets the bit with an atomic instead
 	u32 *tup;                // [BS_BINS][cap] bit offsets inside the bin: (word - bin start) << 5 | bit in word
 	int *cnt;                // [BS_BINS], reset by k_bs_apply
+	u32 tlog2;               // log2(positions per tile), <= 20 (smaller only under the KMX_BS_TILE_LOG2 test hook)
+	// second level, for bins of more than 8 tiles (filters above 256 MB): k_bs_split deals a bin's tuples to its tiles,
+	// k_bs_apply2 sweeps one tile per workgroup -- every tuple and every word of the filter is then read once per sweep
+	u32 cap2;                // tuples per (bin, tile); 0 = single level
+	u32 *tup2;               // [BS_BINS << (wshift - tlog2)][cap2] bit offsets inside the tile
+	int *cnt2;               // [BS_BINS << (wshift - tlog2)], reset by k_bs_apply2
 };
+#define BS_MAX_TILES_LOG2 8                    // tiles per bin at most, two-level (the split counts them in 256 LDS counters)
 
 // Raw KMC records on the device (k_kmc_decode): fixed-size [suffix bytes big-endian | counter bytes little-endian];
 // record r carries the prefix idx & prefix_mask of the LUT entry with lut[idx] <= r < lut[idx + 1] (kmc_file.cpp:439-478).

@@ -248,6 +248,28 @@ def test_both_finisher_paths_bit_exact(cfg, monkeypatch):
         monkeypatch.delenv(v)
 
 
+@pytest.mark.parametrize("cfg", [(31, 1, 1023, 7, 5, 1500000), (40, 3, 4095, 9, 4, 600000)], ids=lambda c: "k%d_ci%d_nh%d_n%d" % (c[0], c[1], c[3], c[5]))
+def test_partitioned_bit_sets_at_every_depth(cfg, monkeypatch):
+    """km_back and the Bloom slab are set by partitioned bit-sets: one tile per bin (the sizes of every other test), several
+    tiles swept by one workgroup, or -- filters above 256 MB -- a second partition level (k_bs_split / k_bs_apply2).
+    KMX_BS_TILE_LOG2 shrinks the tile so that a test-size filter takes each of them: 2^20 one tile, 2^13 several tiles, 2^10
+    and 2^11 two levels.  The filters must be the oracle's bit for bit whichever way they were set."""
+    k, ci, cs, nh, nb, n = cfg
+    km, cnt = synth.make_stream(n, k, ci, cs, seed_k=777, seed_c=778)
+    o = O.OracleModel(ci, cs, nh, nb)
+    o.build(k, km, cnt)
+    so = o.stats()
+    for tlog2 in (10, 11, 13, 20):
+        monkeypatch.setenv("KMX_BS_TILE_LOG2", str(tlog2))
+        m = KModel(ci, cs, nh, nb)
+        m.build_packed(k, km, cnt)
+        st = m.stats()
+        _check_arrays(m, o, nb, st.bf_num)
+        assert (st.attempts, st.successes, st.rest_entries) == (so.attempts, so.successes, so.rest_entries)
+        del m
+    monkeypatch.delenv("KMX_BS_TILE_LOG2")
+
+
 def test_error_behaviour():
     m = KModel(1, 1023, 7, 5)
     with pytest.raises(api.KmxError):
