@@ -424,7 +424,8 @@ template <int W, int NHM, bool PIPED> __device__ __forceinline__ void check_emit
 		if (PIPED && n) atomicAdd(bd.stats + ST_PIPE_ATTEMPTS, (u64)n);
 		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, md.nb)] = 0;   // k_round_commit files this round's records
 	}
-	u64 *tup = bd.cl_tup + (u64)i * NBIN * KMX_CL_CAP;
+	constexpr int CAP = KMX_CL_CAP_OF(NHM);
+	u64 *tup = bd.cl_tup + (u64)i * NBIN * CAP;
 	int *gcnt = bd.cl_cnt + i * KMX_CL_MAXBINS;
 	// grid-stride over the list: later rounds are launched with fewer workgroups (lists shrink round by round)
 	for (int base = bx * 256; base < n; base += gx * 256) {
@@ -487,7 +488,7 @@ template <int W, int NHM, bool PIPED> __device__ __forceinline__ void check_emit
 			const u64 tp = s_tup[q];
 			const u32 b = cl_bin<NHM>(cl_hash(CL_POS(tp)));
 			const int g = s_base[b] + (q - s_off[b]);
-			if (g < KMX_CL_CAP) tup[(u64)b * KMX_CL_CAP + g] = tp;
+			if (g < CAP) tup[(u64)b * CAP + g] = tp;
 			else bd.cl_ovf[i] = 1;                                     // the whole list takes the ordered path this round
 		}
 		__syncthreads();
@@ -506,52 +507,64 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_e
 // marks every candidate that meets the opposite value on one of its positions as contended.
 template <int NHM, int BT> __global__ __launch_bounds__(BT) void k_round_detect(BlockDev bd, int i0)
 {
-	constexpr int NBIN = KMX_CL_BINS(NHM), T = 1 << KMX_CL_TBITS;
+	constexpr int NBIN = KMX_CL_BINS(NHM), TBITS = KMX_CL_TBITS(NHM), T = 1 << TBITS, CAP = KMX_CL_CAP_OF(NHM);
+	static_assert(T > CAP, "the table of a bin must take every tuple of a full bin");
 	__shared__ u32 s_t[T];
 	const int i = i0 + (int)blockIdx.y, b = blockIdx.x;
 	int *gc = bd.cl_cnt + i * KMX_CL_MAXBINS + b;
 	int cnt = *gc;
 	if (cnt == 0) return;                                            // uniform: nothing was emitted into this bin
-	if (cnt > KMX_CL_CAP) cnt = KMX_CL_CAP;                          // check_emit has raised cl_ovf[i]
+	if (cnt > CAP) cnt = CAP;                                        // check_emit has raised cl_ovf[i]
 	int tb = 10;
-	while ((1 << tb) < 4 * cnt && tb < KMX_CL_TBITS) tb++;           // load <= 1/4 (<= 5/8 for a full bin): short probe chains
+	while ((1 << tb) < 4 * cnt && tb < TBITS) tb++;                  // load <= 1/4 (<= 3/4 for a full bin): short probe chains
 	const u32 tmask = (1u << tb) - 1;
 	for (int q = threadIdx.x; q < (1 << tb); q += BT) s_t[q] = 0;
 	__syncthreads();
-	const u64 *tp = bd.cl_tup + ((u64)i * NBIN + b) * KMX_CL_CAP;
+	const u64 *tp = bd.cl_tup + ((u64)i * NBIN + b) * CAP;
 	const u64 row = (u64)i * KMX_BUCKET;
 	constexpr int U = 8;                                             // tuples per thread in flight: the loads of a batch are issued together
-	for (int q0 = 0; q0 < cnt; q0 += U * BT) {
-		u64 e[U];
-#pragma unroll
-		for (int u = 0; u < U; u++) { const int q = q0 + u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
-#pragma unroll
-		for (int u = 0; u < U; u++) {
-			if (e[u] == ~0ULL) continue;
-			const u64 h = cl_hash(CL_POS(e[u]));
-			const u32 fp = (u32)(h >> 11) & 0x3FFFFFFFu, w = 1u << CL_WANT(e[u]);
-			u32 slot = (u32)(h >> 41) & tmask;
-			for (;;) {                                               // a free slot always exists: 2^KMX_CL_TBITS > KMX_CL_CAP
-				const u32 old = atomicCAS(&s_t[slot], 0u, (fp << 2) | w);
-				if (old == 0) break;
-				if ((old >> 2) == fp) { if (!(old & w)) atomicOr(&s_t[slot], w); break; }
-				slot = (slot + 1) & tmask;
-			}
+	auto insert = [&](u64 e) {
+		const u64 h = cl_hash(CL_POS(e));
+		const u32 fp = (u32)(h >> 11) & 0x3FFFFFFFu, w = 1u << CL_WANT(e);
+		u32 slot = (u32)(h >> 41) & tmask;
+		for (;;) {                                                   // a free slot always exists: 2^TBITS > capacity
+			const u32 old = atomicCAS(&s_t[slot], 0u, (fp << 2) | w);
+			if (old == 0) break;
+			if ((old >> 2) == fp) { if (!(old & w)) atomicOr(&s_t[slot], w); break; }
+			slot = (slot + 1) & tmask;
 		}
-	}
-	__syncthreads();
-	for (int q0 = 0; q0 < cnt; q0 += U * BT) {
+	};
+	auto lookup = [&](u64 e) {
+		const u64 h = cl_hash(CL_POS(e));
+		const u32 fp = (u32)(h >> 11) & 0x3FFFFFFFu;
+		u32 slot = (u32)(h >> 41) & tmask, cur;
+		while (((cur = s_t[slot]) >> 2) != fp) slot = (slot + 1) & tmask;
+		if (cur & (2u >> CL_WANT(e))) bd.status[row + CL_X(e)] = SLOT_CONTENDED;   // the other value is wanted there too
+	};
+	if (cnt <= U * BT) {                                             // the usual case: the bin's tuples stay in registers between the passes
 		u64 e[U];
 #pragma unroll
-		for (int u = 0; u < U; u++) { const int q = q0 + u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
+		for (int u = 0; u < U; u++) { const int q = u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
 #pragma unroll
-		for (int u = 0; u < U; u++) {
-			if (e[u] == ~0ULL) continue;
-			const u64 h = cl_hash(CL_POS(e[u]));
-			const u32 fp = (u32)(h >> 11) & 0x3FFFFFFFu;
-			u32 slot = (u32)(h >> 41) & tmask, cur;
-			while (((cur = s_t[slot]) >> 2) != fp) slot = (slot + 1) & tmask;
-			if (cur & (2u >> CL_WANT(e[u]))) bd.status[row + CL_X(e[u])] = SLOT_CONTENDED;   // the other value is wanted there too
+		for (int u = 0; u < U; u++) if (e[u] != ~0ULL) insert(e[u]);
+		__syncthreads();
+#pragma unroll
+		for (int u = 0; u < U; u++) if (e[u] != ~0ULL) lookup(e[u]);
+	} else {
+		for (int q0 = 0; q0 < cnt; q0 += U * BT) {
+			u64 e[U];
+#pragma unroll
+			for (int u = 0; u < U; u++) { const int q = q0 + u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
+#pragma unroll
+			for (int u = 0; u < U; u++) if (e[u] != ~0ULL) insert(e[u]);
+		}
+		__syncthreads();
+		for (int q0 = 0; q0 < cnt; q0 += U * BT) {
+			u64 e[U];
+#pragma unroll
+			for (int u = 0; u < U; u++) { const int q = q0 + u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
+#pragma unroll
+			for (int u = 0; u < U; u++) if (e[u] != ~0ULL) lookup(e[u]);
 		}
 	}
 	if (threadIdx.x == 0) *gc = 0;                                   // (every thread has read it) ready for the next round

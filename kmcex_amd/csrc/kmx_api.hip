@@ -579,6 +579,9 @@ static int setup_kmback_scatter(kmx_model *m)
 	// tuples per bin: 1 MB while a bin is a few tiles; more when the sweep re-reads the tuples tile after tile or the filter
 	// is big, so that a sweep of the whole filter is shared by more blocks
 	u64 cap = wshift <= 22 ? (1u << 18) : (wshift == 23 ? (1u << 19) : (1u << 20));
+	// two levels: every sweep reads and writes the whole filter, so the bins grow with it (a sweep per ~nwords/3 tuples:
+	// at 10^10 k-mers 2^22 per bin = 4 GB + 5 GB of second-level storage, 52 sweeps of 15.6 GB instead of 207)
+	while (wshift > 23 && cap < (1u << 22) && cap * 512 < nwords) cap <<= 1;
 	const u64 cap_hook = bs_cap_hook();
 	if (cap_hook) cap = cap_hook;
 	bool ok;
@@ -706,7 +709,7 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 		u64 o_tc0 = carve((u64)nb * KMX_NTILES * 4), o_tc1 = carve((u64)nb * KMX_NTILES * 4);
 		const u64 cl_bins = m->nh <= 8 ? KMX_CL_BINS(8) : KMX_CL_BINS(16);
 		u64 o_surv = carve(blk);
-		u64 o_um = carve(blk * 2), o_cl_tup = carve((u64)nb * cl_bins * KMX_CL_CAP * 8), o_cl_cnt = carve((u64)nb * KMX_CL_MAXBINS * 4), o_cl_ovf = carve((u64)nb * 4);
+		u64 o_um = carve(blk * 2), o_cl_tup = carve((u64)nb * cl_bins * (u64)(m->nh <= 8 ? KMX_CL_CAP_OF(8) : KMX_CL_CAP_OF(16)) * 8), o_cl_cnt = carve((u64)nb * KMX_CL_MAXBINS * 4), o_cl_ovf = carve((u64)nb * 4);
 		HIPCHK(hipMalloc(&m->d_block_scratch, off));
 		HIPCHK(hipMemsetAsync(m->d_block_scratch, 0, off, m->stream));     // R starts at epoch 0; epochs only grow
 		m->scratch_bytes = off; m->scratch_nb = nb; m->scratch_W = m->W;

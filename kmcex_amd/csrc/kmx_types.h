@@ -112,13 +112,18 @@ struct BlockDev {
 };
 
 // claim partition: bins per list and slots of the LDS table of one bin (kernels.hip, "claims as a partitioned stream")
-#define KMX_CL_BINS_LOG2(NHM) ((NHM) <= 8 ? 7 : 8)
+#define KMX_CL_BINS_LOG2(NHM) 8
 #define KMX_CL_BINS(NHM) (1 << KMX_CL_BINS_LOG2(NHM))
 #define KMX_CL_MAXBINS 256
+// tuples per bin: 2^18 * nh / bins at most on average (7168 at nh = 7, 16384 at nh = 16), + 25 % and more
 #ifndef KMX_CL_CAP                             // (tools/stress_small_tables.py builds a library with a tiny capacity: the overflow path every round)
-#define KMX_CL_CAP 20480                       // tuples per bin: 2^18 * nh / bins = 16384 at most on average, + 25 %
+#define KMX_CL_CAP_OF(NHM) ((NHM) <= 8 ? 12288 : 20480)
+#else
+#define KMX_CL_CAP_OF(NHM) KMX_CL_CAP
 #endif
-#define KMX_CL_TBITS 15                        // 2^15 > KMX_CL_CAP slots: the table of a bin can always take every tuple
+// 2^TBITS > capacity slots: the table of a bin can always take every tuple.  64 KB of LDS at nh <= 8: two 1024-thread
+// workgroups per CU, so one's loads run under the other's table phase
+#define KMX_CL_TBITS(NHM) ((NHM) <= 8 ? 14 : 15)
 
 #define LIST_HOLE 0x80000000u
 
