@@ -191,6 +191,9 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int *s_tmp, int *total
 // bin in LDS, each bin's run is reserved with ONE global atomic, the tuples are sorted by bin in LDS and written out run
 // by run.  All threads must call it (barriers inside); the LDS arrays are the caller's.
 #define BS_LDS(K) __shared__ int s_bs_cnt[BS_BINS], s_bs_off[BS_BINS], s_bs_base[BS_BINS], s_bs_tmp[4]; __shared__ u64 s_bs_stage[256 * (K)]
+// the same arrays carved out of a byte pool the kernel owns (kernels that run one of several bodies per workgroup)
+#define BS_LDS_BYTES(K) (256 * (K) * 8 + (3 * BS_BINS + 4) * 4)
+#define BS_LDS_AT(K, p) u64 *s_bs_stage = (u64 *)(p); int *s_bs_cnt = (int *)((p) + 256 * (K) * 8), *s_bs_off = s_bs_cnt + BS_BINS, *s_bs_base = s_bs_off + BS_BINS, *s_bs_tmp = s_bs_base + BS_BINS
 template <int K> __device__ __forceinline__ void bs_block_emit(const BitScatter &bs, const u64 *v, u32 valid, int *s_cnt, int *s_off, int *s_base, int *s_tmp, u64 *s_stage)
 {
 	s_cnt[threadIdx.x] = 0;
@@ -410,18 +413,20 @@ __device__ __forceinline__ u64 cl_hash(u64 pos) { return pos * 0x9E3779B97F4A7C1
 template <int NHM> __device__ __forceinline__ u32 cl_bin(u64 h) { return (u32)(h >> (64 - KMX_CL_BINS_LOG2(NHM))); }
 
 // (bx of gx workgroups work on list i: the kernels below map their grids onto these bodies)
-template <int W, int NHM, bool PIPED> __device__ __forceinline__ void check_emit_body(const ModelDev &md, const BlockDev &bd, int t, int pp, int i, int bx, int gx)
+// LDS of one check_emit workgroup, carved out of a byte pool the kernel owns (kernels that run one of several bodies per workgroup)
+#define CHECK_LDS_BYTES(NHM) (256 * (NHM) * 8 + (3 * KMX_CL_BINS(NHM) + 8) * 4)
+template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const ModelDev &md, const BlockDev &bd, int t, int pp, int i, int bx, int gx, unsigned char *lds, int stat_slot)
 {
 	constexpr int NBIN = KMX_CL_BINS(NHM);
-	__shared__ int s_fail, s_tmp[4];
-	__shared__ int s_cnt[NBIN], s_off[NBIN], s_base[NBIN];
-	__shared__ u64 s_tup[256 * NHM];
+	u64 *s_tup = (u64 *)lds;                                         // [256 * NHM]
+	int *s_cnt = (int *)(lds + 256 * NHM * 8), *s_off = s_cnt + NBIN, *s_base = s_off + NBIN, *s_tmp = s_base + NBIN;
+	int &s_fail = s_tmp[4];
 	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;                                  // kmodel.hpp:563
 	if (bx == 0 && threadIdx.x == 0) {
 		if (n) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
-		if (PIPED && n) atomicAdd(bd.stats + ST_PIPE_ATTEMPTS, (u64)n);
+		if (stat_slot && n) atomicAdd(bd.stats + stat_slot, (u64)n);   // accounting: attempts examined inside fused launches
 		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, md.nb)] = 0;   // k_round_commit files this round's records
 	}
 	constexpr int CAP = KMX_CL_CAP_OF(NHM);
@@ -496,7 +501,8 @@ template <int W, int NHM, bool PIPED> __device__ __forceinline__ void check_emit
 }
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_emit(ModelDev md, BlockDev bd, int t, int pp, int i0)
 {
-	check_emit_body<W, NHM, false>(md, bd, t, pp, i0 + (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+	__shared__ __align__(16) unsigned char lds[CHECK_LDS_BYTES(NHM)];
+	check_emit_body<W, NHM>(md, bd, t, pp, i0 + (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, lds, 0);
 }
 
 // ------------------------------------------------------------------------------------------ D: opposite claims, bin by bin
@@ -632,9 +638,9 @@ template <int W> __device__ __forceinline__ u32 rec_load(const u64 *rec, u64 slo
 // in one word, kmodel.hpp:611-618) and the km_back insert (:548-550) -- no second look at the cells.  Contended ones file
 // a record in U[0] (with the untagged mask of the check) and place their reservations right away (epoch `epoch`), which
 // saves the first reserve pass of the ordered slow path.
-template <int W, int NHM> __device__ __forceinline__ void commit_body(const ModelDev &md, const BlockDev &bd, int t, int pp, u64 epoch, int i, int bx, int gx)
+template <int W, int NHM> __device__ __forceinline__ void commit_body(const ModelDev &md, const BlockDev &bd, int t, int pp, u64 epoch, int i, int bx, int gx, unsigned char *lds)
 {
-	__shared__ int s_cnt, s_base;
+	int &s_cnt = ((int *)lds)[0], &s_base = ((int *)lds)[1];
 	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;
@@ -683,7 +689,8 @@ template <int W, int NHM> __device__ __forceinline__ void commit_body(const Mode
 }
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit(ModelDev md, BlockDev bd, int t, int pp, u64 epoch, int i0)
 {
-	commit_body<W, NHM>(md, bd, t, pp, epoch, i0 + (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x);
+	__shared__ __align__(16) unsigned char lds[16];
+	commit_body<W, NHM>(md, bd, t, pp, epoch, i0 + (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, lds);
 }
 
 // ------------------------------------------------------------------------------------------ B|A: commit of one list beside the check of the next
@@ -697,9 +704,10 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit(
 // kinds are resident on every CU from the first wave of workgroups on (all of one kind first: no gain).
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit_check(ModelDev md, BlockDev bd, int t, int pp, u64 epoch, int i_commit, int n_commit, int i_check, int n_check)
 {
+	__shared__ __align__(16) unsigned char lds[CHECK_LDS_BYTES(NHM)];
 	const int bx = (int)(blockIdx.x >> 1), gx = (int)(gridDim.x >> 1), y = (int)blockIdx.y;
-	if (blockIdx.x & 1) { if (y < n_check) check_emit_body<W, NHM, true>(md, bd, t, pp, i_check + y, bx, gx); }
-	else if (y < n_commit) commit_body<W, NHM>(md, bd, t, pp, epoch, i_commit + y, bx, gx);
+	if (blockIdx.x & 1) { if (y < n_check) check_emit_body<W, NHM>(md, bd, t, pp, i_check + y, bx, gx, lds, ST_PIPE_ATTEMPTS); }
+	else if (y < n_commit) commit_body<W, NHM>(md, bd, t, pp, epoch, i_commit + y, bx, gx, lds);
 }
 
 // ------------------------------------------------------------------------------------------ S: ordered slow path
@@ -1422,25 +1430,27 @@ __global__ __launch_bounds__(1024) void k_bs_apply2(BitScatter bs)
 // commit or by the ordered path -- contributes the nh-2 positions of its (k-2)-mer to the BitScatter of km_back.
 // n_in_block >= 0: once per block instead -- every k-mer of the block that did not go to the rest table was inserted in
 // one of the rounds (the single-GPU build; in the multi-GPU ring a rank sees a list for one round only).
-template <int W, int NHM, int KPT> __global__ __launch_bounds__(256) void k_kmback_emit(ModelDev md, BlockDev bd, int pp, int n_in_block, BitScatter bs)
+template <int W, int NHM, int KPT>
+__device__ __forceinline__ void kmback_emit_body(const ModelDev &md, const BlockDev &bd, const u64 *kmers, const unsigned char *surv, int pp, int n_in_block,
+                                                 const BitScatter &bs, int i, int bx, int gx, unsigned char *lds)
 {
 	constexpr int K = KPT * (NHM - 2);
-	BS_LDS(K);
-	const int i = blockIdx.y;
+	BS_LDS_AT(K, lds);
 	const bool whole = n_in_block >= 0;
-	int n = bd.n[pp][i];
+	int n;
 	if (whole) { n = n_in_block - i * (int)KMX_BUCKET; n = n < 0 ? 0 : (n > (int)KMX_BUCKET ? (int)KMX_BUCKET : n); }
+	else n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
-	for (int base = blockIdx.x * 256 * KPT; base < n; base += gridDim.x * 256 * KPT) {   // uniform trip count per workgroup
+	for (int base = bx * 256 * KPT; base < n; base += gx * 256 * KPT) {   // uniform trip count per workgroup
 		u64 v[K];
 		u32 valid = 0;
 #pragma unroll
 		for (int q = 0; q < KPT; q++) {
 			const int x = base + q * 256 + (int)threadIdx.x;
-			if (x < n && (whole ? !bd.surv[row + x] : bd.status[row + x] == SLOT_INSERTED)) {
+			if (x < n && (whole ? !surv[row + x] : bd.status[row + x] == SLOT_INSERTED)) {
 				const u32 idx = whole ? (u32)x : bd.list[pp][row + x];
 				u64 km[W];
-				load_kmer<W>(bd.kmers, row + idx, km);
+				load_kmer<W>(kmers, row + idx, km);
 				Premixed<W> pb = premix_string<W>(drop_first_base<W>(left_align<W>(km, md.k)), md.gback);
 #pragma unroll
 				for (int j = 0; j < NHM - 2; j++)
@@ -1453,6 +1463,24 @@ template <int W, int NHM, int KPT> __global__ __launch_bounds__(256) void k_kmba
 		}
 		bs_block_emit<K>(bs, v, valid, s_bs_cnt, s_bs_off, s_bs_base, s_bs_tmp, s_bs_stage);
 	}
+}
+template <int W, int NHM, int KPT> __global__ __launch_bounds__(256) void k_kmback_emit(ModelDev md, BlockDev bd, const u64 *kmers, const unsigned char *surv, int i0, int pp, int n_in_block, BitScatter bs)
+{
+	__shared__ __align__(16) unsigned char lds[BS_LDS_BYTES(KPT * (NHM - 2))];
+	kmback_emit_body<W, NHM, KPT>(md, bd, kmers, surv, pp, n_in_block, bs, i0 + (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, lds);
+}
+
+// A|K: the check of a late round with the km_back emission of the PREVIOUS block riding along.  From round 2 on a check
+// launch is one short wave of workgroups that waits on a chain of dependent loads (list entry -> k-mer -> bin -> gathers ->
+// run reservation) while most of the chip idles; the first gx_check workgroups of a row are that check, the others hash
+// the (k-2)-mers of `job` and stream their tuples out -- throughput work that costs the launch (almost) nothing.
+template <int W, int NHM, int KPT> __global__ __launch_bounds__(256) void k_round_check_kmback(ModelDev md, BlockDev bd, int t, int pp, int gx_check, int n_check, KmbackJob job, BitScatter bs)
+{
+	constexpr int LB = CHECK_LDS_BYTES(NHM) > BS_LDS_BYTES(KPT * (NHM - 2)) ? CHECK_LDS_BYTES(NHM) : BS_LDS_BYTES(KPT * (NHM - 2));
+	__shared__ __align__(16) unsigned char lds[LB];
+	const int y = (int)blockIdx.y;
+	if ((int)blockIdx.x < gx_check) { if (y < n_check) check_emit_body<W, NHM>(md, bd, t, pp, y, (int)blockIdx.x, gx_check, lds, ST_HOST_ATTEMPTS); }
+	else if (y < job.n_lists) kmback_emit_body<W, NHM, KPT>(md, bd, job.kmers, job.surv, pp, job.n_in_block, bs, job.i0 + y, (int)blockIdx.x - gx_check, (int)gridDim.x - gx_check, lds);
 }
 
 // survivors of the block go to the rest table (kmodel.hpp:567-571); slot 0 is remembered for the
@@ -2186,7 +2214,7 @@ void block_init(const BlockDev &bd, int nb, int pp, int n_in_block, hipStream_t 
 // one round t of one block: A, B, `nsub` grid-wide ordered sub-rounds, finisher, reorder.  `epoch` advances.
 // The single-workgroup finisher decides whatever the sub-rounds leave (everything when nsub == 0), so nsub only
 // trades launches for finisher iterations; the host picks it from the contention it has observed so far.
-void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 *epoch, int flags, hipStream_t st, KernelProf *prof)
+void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 *epoch, int flags, hipStream_t st, KernelProf *prof, const KmbackJob *job, const BitScatter *kmb)
 {
 	const int nb = md.nb;
 	if (nsub < 0) nsub = 0;
@@ -2221,6 +2249,27 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 		detect(lo(groups - 1), nb - lo(groups - 1));
 		KPROF_BEGIN(prof, KC_VERIFY_COMMIT, st);
 		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit<W, NHM>), dim3(gx, nb - lo(groups - 1)), blk, 0, st, md, bd, t, pp, eb, lo(groups - 1)));
+		KPROF_END(prof, st);
+	} else if (job && job->n_lists > 0) {
+		// a late round: the previous block's km_back emission rides along (k_round_check_kmback)
+		// The riders keep the standalone kernel's 4 (2) k-mers per thread: with one k-mer per thread their LDS would fit
+		// inside the check's own (8 workgroups per CU instead of 3), but every workgroup iteration reserves its 256 runs
+		// with 256 returning atomics on the same 256 counters, four times as many then -- measured 79 us per launch
+		// against 54, and 83.4 ms per build against 74.8.
+		const int gxk = KMX_BUCKET / 1024;                         // workgroups per list of the job
+		const dim3 hgrid(gx + gxk, nb > job->n_lists ? nb : job->n_lists);
+		KPROF_BEGIN(prof, KC_CHECK_KMBACK, st);
+		if (words(md) == 1) {
+			if (md.nh <= 8) hipLaunchKernelGGL((k_round_check_kmback<1, 8, 4>), hgrid, blk, 0, st, md, bd, t, pp, gx, nb, *job, *kmb);
+			else hipLaunchKernelGGL((k_round_check_kmback<1, 16, 2>), hgrid, blk, 0, st, md, bd, t, pp, gx, nb, *job, *kmb);
+		} else {
+			if (md.nh <= 8) hipLaunchKernelGGL((k_round_check_kmback<2, 8, 4>), hgrid, blk, 0, st, md, bd, t, pp, gx, nb, *job, *kmb);
+			else hipLaunchKernelGGL((k_round_check_kmback<2, 16, 2>), hgrid, blk, 0, st, md, bd, t, pp, gx, nb, *job, *kmb);
+		}
+		KPROF_END(prof, st);
+		detect(0, nb);
+		KPROF_BEGIN(prof, KC_VERIFY_COMMIT, st);
+		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit<W, NHM>), grid, blk, 0, st, md, bd, t, pp, eb, 0));
 		KPROF_END(prof, st);
 	} else {
 		KPROF_BEGIN(prof, KC_CHECK_CLAIM, st);
@@ -2258,18 +2307,27 @@ void rest_append(const ModelDev &md, const BlockDev &bd, int pp, int i0, int n_l
 	DISPATCH_W(words(md), hipLaunchKernelGGL(k_rest_append<W>, dim3(KMX_BUCKET / 256, n_lists), dim3(256), 0, st, bd, pp, i0, rest_kmers, rest_counts, rest_n, stale_kmers, stale_counts, feedback));
 }
 
-// n_in_block < 0: the slots round t inserted (list[pp], status); >= 0: every k-mer of the block that is not a survivor
-void kmback_emit(const ModelDev &md, const BlockDev &bd, int t, int pp, int n_in_block, const BitScatter &bs, hipStream_t st)
+// true when round t of a block of nb lists runs as whole-round kernels under `flags` (a check launch that can host)
+bool round_can_host(int nb, int t, int flags)
 {
-	if (!md.km_back_mod.d) return;
+	int groups = (flags >> KMX_ROUND_PIPE_SHIFT) & 15;
+	if (groups > nb) groups = nb;
+	return !(groups > 1 && t < KMX_PIPE_ROUNDS);
+}
+
+// n_in_block < 0: the slots round t inserted (list[pp], status); >= 0: every k-mer of the block that is not a survivor.
+// Lists [i0, i0 + n_lists) of the block whose k-mers / survivor flags are given (the current block's: bd.kmers, bd.surv).
+void kmback_emit(const ModelDev &md, const BlockDev &bd, const u64 *kmers, const unsigned char *surv, int i0, int n_lists, int t, int pp, int n_in_block, const BitScatter &bs, hipStream_t st)
+{
+	if (!md.km_back_mod.d || n_lists <= 0) return;
 	const int gx = n_in_block >= 0 ? KMX_BUCKET / 1024 : (KMX_BUCKET / 1024) >> (t < 4 ? t : 4);   // 4 (2) slots per thread; lists shrink round by round
-	const dim3 grid(gx, md.nb), blk(256);
+	const dim3 grid(gx, n_lists), blk(256);
 	if (words(md) == 1) {
-		if (md.nh <= 8) hipLaunchKernelGGL((k_kmback_emit<1, 8, 4>), grid, blk, 0, st, md, bd, pp, n_in_block, bs);
-		else hipLaunchKernelGGL((k_kmback_emit<1, 16, 2>), grid, blk, 0, st, md, bd, pp, n_in_block, bs);
+		if (md.nh <= 8) hipLaunchKernelGGL((k_kmback_emit<1, 8, 4>), grid, blk, 0, st, md, bd, kmers, surv, i0, pp, n_in_block, bs);
+		else hipLaunchKernelGGL((k_kmback_emit<1, 16, 2>), grid, blk, 0, st, md, bd, kmers, surv, i0, pp, n_in_block, bs);
 	} else {
-		if (md.nh <= 8) hipLaunchKernelGGL((k_kmback_emit<2, 8, 4>), grid, blk, 0, st, md, bd, pp, n_in_block, bs);
-		else hipLaunchKernelGGL((k_kmback_emit<2, 16, 2>), grid, blk, 0, st, md, bd, pp, n_in_block, bs);
+		if (md.nh <= 8) hipLaunchKernelGGL((k_kmback_emit<2, 8, 4>), grid, blk, 0, st, md, bd, kmers, surv, i0, pp, n_in_block, bs);
+		else hipLaunchKernelGGL((k_kmback_emit<2, 16, 2>), grid, blk, 0, st, md, bd, kmers, surv, i0, pp, n_in_block, bs);
 	}
 }
 void bs_apply(const BitScatter &bs, hipStream_t st)

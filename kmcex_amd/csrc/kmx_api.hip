@@ -33,9 +33,10 @@ int classify_tiles(u64 n);
 void classify_count(const ModelDev &, const u64 *, const u32 *, u64, u64, int *, int *, int *, u64 *, const BitScatter &, int, hipStream_t, KernelProf *);
 void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int *, u64 *, u32 *, u64, hipStream_t);
 void block_init(const BlockDev &, int, int, int, hipStream_t);
-void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *);
+void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *, const KmbackJob *, const BitScatter *);
+bool round_can_host(int nb, int t, int flags);
 void rest_append(const ModelDev &, const BlockDev &, int, int, int, u64 *, int *, unsigned long long *, u64 *, int *, u64 *, hipStream_t);
-void kmback_emit(const ModelDev &, const BlockDev &, int, int, int, const BitScatter &, hipStream_t);
+void kmback_emit(const ModelDev &, const BlockDev &, const u64 *, const unsigned char *, int, int, int, int, int, const BitScatter &, hipStream_t);
 void bs_apply(const BitScatter &, hipStream_t);
 void ring_import(const ModelDev &, const BlockDev &, const RingLists &, u64 *, u32 *, hipStream_t);
 void ring_export(const ModelDev &, const BlockDev &, const RingLists &, hipStream_t);
@@ -219,6 +220,10 @@ struct kmx_model {
 	u64 kmb_pending = 0, kmb_budget = 0;                       // upper bound of tuples emitted since the last apply / what the bins take
 	bool kmb_deferred = false;
 	bool dbg_kmb_direct = false;                               // KMX_KMB_DIRECT=1: the atomic path at every size (test hook)
+	unsigned char *d_surv[2] = {nullptr, nullptr};             // survivor flags of the current and of the previous block (inside the scratch slab)
+	KmbackJob kmb_job = {nullptr, nullptr, 0, 0, 0};            // km_back emission the last block still owes (hosted by the next block's late rounds)
+	bool dbg_kmb_host = true;                                  // KMX_KMB_HOST=0: every block emits in a launch of its own (test hook)
+	u64 hosted_kmers = 0;                                      // k-mers of blocks whose emission rode along (accounting)
 	u32 *d_bs2_tup = nullptr;                                  // second level of the two bit-sets (big filters), shared: [bins * tiles][cap2]
 	int *d_bs2_cnt = nullptr;
 	u64 bs2_tup_cap = 0, bs2_cnt_cap = 0;
@@ -402,6 +407,7 @@ static int create_device_side(kmx_model *m)
 		               | ((env_int("KMX_PIPE", 2) & 15) << KMX_ROUND_PIPE_SHIFT);   // groups of lists the big rounds are pipelined over (0: off)   // KMX_PIPE=0: every round as whole-round kernels
 		m->dbg_ctrl = env_int("KMX_CTRL_DEBUG", 0) != 0;
 		m->dbg_kmb_direct = env_int("KMX_KMB_DIRECT", 0) != 0;
+		m->dbg_kmb_host = env_int("KMX_KMB_HOST", 1) != 0;
 	}
 	HIPCHK(hipEventCreate(&m->ev0));
 	HIPCHK(hipEventCreate(&m->ev1));
@@ -571,6 +577,8 @@ static int setup_kmback_scatter(kmx_model *m)
 {
 	m->kmb_deferred = false;
 	m->kmb_pending = 0;
+	m->kmb_job.n_lists = 0;
+	m->hosted_kmers = 0;
 	const u64 nwords = (m->byte_km_back + 3) / 4;
 	if (m->dbg_kmb_direct || nwords == 0) return KMX_OK;
 	u32 wshift = 5;
@@ -660,13 +668,30 @@ static int kmback_flush(kmx_model *m)
 }
 // the (k-2)-mers of the successes -> bins: of round t (n_in_block < 0; the ring, where a rank holds a list for one round)
 // or of a whole block after its last round (n_in_block >= 0); `bound` = most k-mers that can have been inserted
+static int kmback_reserve(kmx_model *m, u64 bound)
+{
+	const u64 add = bound * (u64)(m->nh - 2);
+	if (m->kmb_pending + add > m->kmb_budget) TRY(kmback_flush(m));
+	m->kmb_pending += add;
+	return KMX_OK;
+}
 static int kmback_emit(kmx_model *m, int t, int pp, int n_in_block, u64 bound)
 {
 	if (!m->kmb_deferred) return KMX_OK;
-	const u64 add = bound * (u64)(m->nh - 2);
-	if (m->kmb_pending + add > m->kmb_budget) TRY(kmback_flush(m));
-	kmxk::kmback_emit(m->md, m->bd, t, pp, n_in_block, m->kmb, m->stream);
-	m->kmb_pending += add;
+	TRY(kmback_reserve(m, bound));
+	kmxk::kmback_emit(m->md, m->bd, m->bd.kmers, m->bd.surv, 0, m->nb, t, pp, n_in_block, m->kmb, m->stream);
+	return KMX_OK;
+}
+// what is left of the job a finished block handed on: emitted in a launch of its own (the k-mers it points at are about to
+// be overwritten, the build ends, or no late round can host it)
+static int kmback_job_flush(kmx_model *m)
+{
+	KmbackJob &j = m->kmb_job;
+	if (j.n_lists <= 0) return KMX_OK;
+	const u64 lo = (u64)j.i0 * KMX_BUCKET, nbk = (u64)j.n_in_block;
+	TRY(kmback_reserve(m, nbk > lo ? std::min<u64>(nbk - lo, (u64)j.n_lists * KMX_BUCKET) : 0));
+	kmxk::kmback_emit(m->md, m->bd, j.kmers, j.surv, j.i0, j.n_lists, 0, 0, j.n_in_block, m->kmb, m->stream);
+	j.n_lists = 0;
 	return KMX_OK;
 }
 
@@ -708,7 +733,7 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 		u64 o_Un = carve((u64)KMX_NSLOW * nb * KMX_CTR_STRIDE * 4), o_R = carve((u64)nb * KMX_RSIZE * 8);
 		u64 o_tc0 = carve((u64)nb * KMX_NTILES * 4), o_tc1 = carve((u64)nb * KMX_NTILES * 4);
 		const u64 cl_bins = m->nh <= 8 ? KMX_CL_BINS(8) : KMX_CL_BINS(16);
-		u64 o_surv = carve(blk);
+		u64 o_surv = carve(blk), o_surv1 = carve(blk);
 		u64 o_um = carve(blk * 2), o_cl_tup = carve((u64)nb * cl_bins * (u64)(m->nh <= 8 ? KMX_CL_CAP_OF(8) : KMX_CL_CAP_OF(16)) * 8), o_cl_cnt = carve((u64)nb * KMX_CL_MAXBINS * 4), o_cl_ovf = carve((u64)nb * 4);
 		HIPCHK(hipMalloc(&m->d_block_scratch, off));
 		HIPCHK(hipMemsetAsync(m->d_block_scratch, 0, off, m->stream));     // R starts at epoch 0; epochs only grow
@@ -723,6 +748,7 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 		bd.Un = (int *)(base + o_Un); bd.R = (u64 *)(base + o_R);
 		bd.tile_cnt[0] = (int *)(base + o_tc0); bd.tile_cnt[1] = (int *)(base + o_tc1);
 		bd.surv = (unsigned char *)(base + o_surv);
+		m->d_surv[0] = bd.surv; m->d_surv[1] = (unsigned char *)(base + o_surv1);   // block b flags into d_surv[b & 1]
 		bd.um = (unsigned short *)(base + o_um); bd.cl_tup = (u64 *)(base + o_cl_tup);
 		bd.cl_cnt = (int *)(base + o_cl_cnt); bd.cl_ovf = (int *)(base + o_cl_ovf);      // zeroed with the slab; the kernels keep them zero between rounds
 		bd.stats = m->d_stats;
@@ -830,11 +856,27 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 	const int nb = m->nb;
 	m->bd.kmers = m->d_stg_kmers + head * m->W;
 	m->bd.counts = m->d_stg_counts + head;
+	m->bd.surv = m->d_surv[m->blocks & 1];                        // (the previous block's flags stay readable for its job)
 	int pp = 0;
 	kmxk::block_init(m->bd, nb, pp, (int)n_in_block, m->stream);
 	steer_passes(m);
+	// The previous block's km_back emission rides along with the check launches of this block's last two rounds (the
+	// first of them takes the larger share of the lists: its check is the longer one).
+	KmbackJob &job = m->kmb_job;
+	const int host_a = nb >= 2 && kmxk::round_can_host(nb, nb - 2, m->dbg_flags) ? nb - 2 : -1;
+	const int host_b = kmxk::round_can_host(nb, nb - 1, m->dbg_flags) ? nb - 1 : -1;
+	if (job.n_lists > 0 && host_b < 0) TRY(kmback_job_flush(m));
 	for (int t = 0; t < nb; t++) {
-		kmxk::round(m->md, m->bd, t, pp, passes_of_round(m, t), &m->epoch, m->dbg_flags, m->stream, &m->prof);
+		KmbackJob part = {nullptr, nullptr, 0, 0, 0};
+		if (job.n_lists > 0 && (t == host_a || t == host_b)) {
+			part = job;
+			if (t == host_a && host_b >= 0) part.n_lists = (job.n_lists + 1) / 2;
+			const u64 lo = (u64)part.i0 * KMX_BUCKET, nbk = (u64)part.n_in_block;
+			TRY(kmback_reserve(m, nbk > lo ? std::min<u64>(nbk - lo, (u64)part.n_lists * KMX_BUCKET) : 0));
+			job.i0 += part.n_lists;
+			job.n_lists -= part.n_lists;
+		}
+		kmxk::round(m->md, m->bd, t, pp, passes_of_round(m, t), &m->epoch, m->dbg_flags, m->stream, &m->prof, part.n_lists ? &part : nullptr, &m->kmb);
 		pp ^= 1;
 		m->rounds++;
 	}
@@ -846,7 +888,14 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 			                   (const int *)m->d_stale_counts, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stats);
 	}
 	kmxk::rest_append(m->md, m->bd, pp, 0, nb, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream);
-	TRY(kmback_emit(m, 0, pp, (int)n_in_block, n_in_block));     // km_back insert of everything the block inserted (kmodel.hpp:548-550)
+	// km_back insert of everything the block inserted (kmodel.hpp:548-550): handed to the next block's late rounds, or
+	// done here when nothing can host it
+	if (m->kmb_deferred) {
+		if (m->dbg_kmb_host && !final_partial && host_b >= 0) {
+			job.kmers = m->bd.kmers; job.surv = m->bd.surv; job.n_in_block = (int)n_in_block; job.i0 = 0; job.n_lists = nb;
+			m->hosted_kmers += n_in_block;
+		} else TRY(kmback_emit(m, 0, pp, (int)n_in_block, n_in_block));
+	}
 	m->blocks++;
 	HIPCHK(hipGetLastError());
 	return KMX_OK;
@@ -913,6 +962,7 @@ static int kmx_insert_batch_dev_impl(kmx_model *m, const uint64_t *d_kmers, cons
 			TRY(process_block(m, head, blk, false));
 			head += blk;
 		}
+		TRY(kmback_job_flush(m));                                // (the next scatter overwrites the k-mers the job points at)
 		if (head) {                                              // carry the remainder (< one block) to the front
 			const u64 rem = m->stg_n - head;
 			if (rem) {
@@ -1493,7 +1543,7 @@ static int kmx_ring_round_dev_impl(kmx_model *m, int t, const kmx_ring_list *lis
 	if (t == 0) steer_passes(m);
 	kmxk::ring_import(m->md, m->bd, rl, m->d_stg_kmers, m->d_stg_counts, m->stream);
 	// (a rank holds one or two of the round's lists: nothing to pipeline)
-	kmxk::round(m->md, m->bd, t, 0, passes_of_round(m, t), &m->epoch, m->dbg_flags & ~(15 << KMX_ROUND_PIPE_SHIFT), m->stream, &m->prof);
+	kmxk::round(m->md, m->bd, t, 0, passes_of_round(m, t), &m->epoch, m->dbg_flags & ~(15 << KMX_ROUND_PIPE_SHIFT), m->stream, &m->prof, nullptr, nullptr);
 	TRY(kmback_emit(m, t, 0, -1, (u64)n_lists * KMX_BUCKET));
 	m->rounds++;
 	bool any_out = false;
@@ -2016,6 +2066,7 @@ static int kmx_get_stats_impl(kmx_model *m, kmx_stats *st)
 	st->rest_entries = m->rest.entries; st->km_byte_size = m->km_byte_size; st->byte_km_back = m->byte_km_back;
 	st->blocks = m->blocks; st->rounds = m->rounds;
 	st->piped_attempts = m->h_stats[ST_PIPE_ATTEMPTS]; st->piped_commits = m->h_stats[ST_PIPE_SUCC];
+	st->hosted_attempts = m->h_stats[ST_HOST_ATTEMPTS]; st->hosted_kmers = m->hosted_kmers;
 	st->rest_bytes = m->rest.suff_bin_size + 4 * m->rest.entries + 4 * (u64)m->rest.pre_buffer_size + 4 * (u64)m->rest.map_size;
 	st->k = m->k; st->ci = m->ci; st->cs = m->cs; st->nh = m->nh; st->nb = m->nb; st->bf_num = m->bf_num; st->device = m->device;
 	return KMX_OK;

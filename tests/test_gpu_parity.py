@@ -248,7 +248,7 @@ def test_both_finisher_paths_bit_exact(cfg, monkeypatch):
         monkeypatch.delenv(v)
 
 
-@pytest.mark.parametrize("cfg", [(31, 1, 1023, 7, 5, 1500000), (40, 3, 4095, 9, 4, 600000)], ids=lambda c: "k%d_ci%d_nh%d_n%d" % (c[0], c[1], c[3], c[5]))
+@pytest.mark.parametrize("cfg", [(31, 1, 1023, 7, 5, 3000000), (40, 3, 4095, 9, 4, 600000), (27, 1, 1023, 6, 3, 2500000)], ids=lambda c: "k%d_ci%d_nh%d_n%d" % (c[0], c[1], c[3], c[5]))
 def test_partitioned_bit_sets_at_every_depth(cfg, monkeypatch):
     """km_back and the Bloom slab are set by partitioned bit-sets: one tile per bin (the sizes of every other test), several
     tiles swept by one workgroup, or -- filters above 256 MB -- a second partition level (k_bs_split / k_bs_apply2).
@@ -259,8 +259,9 @@ def test_partitioned_bit_sets_at_every_depth(cfg, monkeypatch):
     o = O.OracleModel(ci, cs, nh, nb)
     o.build(k, km, cnt)
     so = o.stats()
-    for tlog2 in (10, 11, 13, 20):
+    for tlog2, host in ((10, 1), (11, 0), (13, 1), (20, 0), (20, 1)):
         monkeypatch.setenv("KMX_BS_TILE_LOG2", str(tlog2))
+        monkeypatch.setenv("KMX_KMB_HOST", str(host))            # km_back emission riding along with the next block's late rounds, or not
         m = KModel(ci, cs, nh, nb)
         m.build_packed(k, km, cnt)
         st = m.stats()
@@ -268,6 +269,7 @@ def test_partitioned_bit_sets_at_every_depth(cfg, monkeypatch):
         assert (st.attempts, st.successes, st.rest_entries) == (so.attempts, so.successes, so.rest_entries)
         del m
     monkeypatch.delenv("KMX_BS_TILE_LOG2")
+    monkeypatch.delenv("KMX_KMB_HOST")
 
 
 def test_error_behaviour():
