@@ -162,7 +162,8 @@ int kmx_occubin(int cs, int nh, uint32_t *bin_of_occ, uint32_t *mean_of_bin);
  * 1 64-bit atomic OR (agent scope, what the insert uses), 2 byte stores, 3 byte loads, 4 8-byte stores,
  * 5 32-bit atomic OR (what the insert uses on its 4-byte cells), 6 64-bit atomic OR at workgroup scope, 7 64-bit atomic OR
  * returning the old word, 8 4-byte loads (what the insert's check uses); 9 / 10 / 11 the same non-temporal / agent-scope
- * (sc1) / with 16 loads in flight per lane; 12 32-bit atomic OR with 3/8 of the lanes active (`touches` counts all lanes). */
+ * (sc1) / with 16 loads in flight per lane; 12 32-bit atomic OR with 3/8 of the lanes active (`touches` counts all lanes);
+ * 20 modes 8 and 5 side by side on two streams, each on its own buffer of `bytes` (seconds until both are done).          */
 int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds);
 
 /* Per-kernel-class timing with HIP events recorded on the model's stream around each launch (off by default).
