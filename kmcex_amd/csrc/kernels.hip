@@ -23,6 +23,9 @@
 //                    larger than what its registers hold.
 //   R  reorder       applies what the finisher decided, then the reference's unstable compaction
 //                    (kmodel.hpp:529-540) in one launch with lazily filled holes.
+//   Fused launches: in rounds 0 and 1 one group of lists commits beside the check of the next (k_round_commit_check:
+//   memory-side atomics and gathers side by side); the check launches of a block's last two rounds carry the km_back
+//   emission of the previous block as extra workgroups (k_round_check_kmback: they are latency-bound and leave the chip idle).
 #include "kmx_types.h"
 #include <cstdlib>
 
@@ -700,14 +703,20 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit(
 //   check(G0) detect(G0) [commit(G0)|check(G1)] detect(G1) ... commit(G_last)          G = a group of lists
 // One list is a single residency wave of workgroups on this chip, so a per-list pipeline is latency-bound and loses
 // (84.0 ms against 77.9 for whole-round kernels); two groups, the bigger first, is the split that pays (76.1-76.6 ms):
-// gathers ride almost free beside atomics, not the other way round.  Even workgroups commit, odd ones check, so both
-// kinds are resident on every CU from the first wave of workgroups on (all of one kind first: no gain).
+// gathers ride almost free beside atomics, not the other way round.  The layout of the two kinds over the grid matters:
+// all of one kind first gains nothing; even/odd workgroups within a list row (so that the third committing list ran
+// last, alone) 17.3 ms per build in these launches; every list of both kinds advancing at the same pace 15.8 ms.
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit_check(ModelDev md, BlockDev bd, int t, int pp, u64 epoch, int i_commit, int n_commit, int i_check, int n_check)
 {
 	__shared__ __align__(16) unsigned char lds[CHECK_LDS_BYTES(NHM)];
-	const int bx = (int)(blockIdx.x >> 1), gx = (int)(gridDim.x >> 1), y = (int)blockIdx.y;
-	if (blockIdx.x & 1) { if (y < n_check) check_emit_body<W, NHM>(md, bd, t, pp, i_check + y, bx, gx, lds, ST_PIPE_ATTEMPTS); }
-	else if (y < n_commit) commit_body<W, NHM>(md, bd, t, pp, epoch, i_commit + y, bx, gx, lds);
+	// consecutive workgroups cycle through the lists of both kinds (commit, check, commit, check, ..., then what is left of
+	// the larger group), so every list advances at the same pace and the launch ends on a mix, not on a tail of atomics
+	const int per = n_commit + n_check, gx = (int)gridDim.x / per;
+	const int r = (int)blockIdx.x % per, bx = (int)blockIdx.x / per, k = n_commit < n_check ? n_commit : n_check;
+	const bool checks = r < 2 * k ? (r & 1) : (n_check > n_commit);
+	const int l = r < 2 * k ? (r >> 1) : (r - k);
+	if (checks) check_emit_body<W, NHM>(md, bd, t, pp, i_check + l, bx, gx, lds, ST_PIPE_ATTEMPTS);
+	else commit_body<W, NHM>(md, bd, t, pp, epoch, i_commit + l, bx, gx, lds);
 }
 
 // ------------------------------------------------------------------------------------------ S: ordered slow path
@@ -2242,7 +2251,7 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 			const int nc = lo(g + 1) - lo(g), nk = lo(g + 2) - lo(g + 1);
 			detect(lo(g), nc);
 			KPROF_BEGIN(prof, KC_COMMIT_CHECK, st);
-			DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit_check<W, NHM>), dim3(2 * gx, nc > nk ? nc : nk), blk, 0, st, md, bd, t, pp, eb, lo(g), nc, lo(g + 1), nk));
+			DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit_check<W, NHM>), dim3((nc + nk) * gx, 1), blk, 0, st, md, bd, t, pp, eb, lo(g), nc, lo(g + 1), nk));
 			KPROF_END(prof, st);
 		}
 		piped_commits = lo(groups - 1);
