@@ -291,18 +291,15 @@ def main():
         A, S, nbf = st.attempts, st.successes, sum(st.n_bf)
         W8 = 8 * ((a.k + 31) // 32) + 4
         Ap, Sp = st.piped_attempts, st.piped_commits                     # the part of A and S handled inside the fused commit|check launches of the big rounds
-        Ah = st.hosted_attempts                                          # attempts of the late-round check launches that carried a km_back emission
-        Sh = S * st.hosted_kmers / max(st.n_km, 1)                       # successes whose km_back emission rode along (by share of blocks)
         alg = {  # algorithmic bytes of ONE step per kernel class (SURVEY.md §8d formula, split by kernel)
-            "check": G * (A - Ap - Ah) * a.nh + (A - Ap - Ah) * W8,      # reads: every attempt looks at its nh positions
-            "check_kmback": G * Ah * a.nh + Ah * W8 + G * 2 * Sh * (a.nh - 2),   # a late round's check + the previous block's km_back term
+            "check": G * (A - Ap) * a.nh + (A - Ap) * W8,                # reads: every attempt looks at its nh positions
             "commit": G * (S - Sp) * a.nh,                               # write-backs (km_back's 2*S*(nh-2) term is k_kmback_emit + k_bs_apply now)
             "commit_check": G * Ap * a.nh + Ap * W8 + G * Sp * a.nh,     # one group of lists commits beside the check of the next group
             "classify": G * 2 * nbf * ((a.nh - 1) + (a.nh - 2)) + n * W8,
         }
         per_q = G * (a.nb * a.nh + (a.nh - 2) + 2 + 6) + W8      # §8d: ~48 touches per query
         alg["query"] = q.numel() * per_q
-        total_insert_alg = alg["check"] + alg["commit"] + alg["commit_check"] + G * Ah * a.nh + Ah * W8 + G * 2 * S * (a.nh - 2) + alg["classify"]     # the §8d formula, whole insert
+        total_insert_alg = alg["check"] + alg["commit"] + alg["commit_check"] + G * 2 * S * (a.nh - 2) + alg["classify"]     # the §8d formula, whole insert
         classes = {}
         for name, v in kt.items():
             if v["launches"]:
@@ -318,7 +315,7 @@ def main():
         # runs of this same command, tools/pmc_summary.py); only valid for the default workload they were taken on
         traffic, traffic_src, traffic_head, q_pmc = None, None, None, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic_default_workload.json")
-        kname = {"check": "k_round_check_emit<", "commit": "k_round_commit<", "commit_check": "k_round_commit_check<", "check_kmback": "k_round_check_kmback<", "classify": "k_classify_count"}.get(dom)
+        kname = {"check": "k_round_check_emit<", "commit": "k_round_commit<", "commit_check": "k_round_commit_check<", "classify": "k_classify_count"}.get(dom)
         if a.n == 100_000_000 and (a.k, a.nh, a.nb, a.ci, a.cs) == (31, 7, 5, 1, 1023) and os.path.exists(pmc_file) and kname:
             pm = json.load(open(pmc_file))
             traffic_head = pm.get("head")                          # the commit the counters were taken at (staleness is visible in the line)

@@ -53,8 +53,6 @@ typedef struct kmx_stats {
 	uint64_t rest_bytes;      /* KRestData::get_all_byte_size (rest.hpp:257-259)                */
 	uint64_t piped_attempts;  /* attempts examined / successes committed inside the fused commit|check launches   */
 	uint64_t piped_commits;   /* of the big rounds (accounting for the per-kernel roofline only)                   */
-	uint64_t hosted_attempts; /* attempts examined inside check launches that also carried a km_back emission ...  */
-	uint64_t hosted_kmers;    /* ... and the k-mers of the blocks whose emission rode along (same purpose)         */
 } kmx_stats;
 
 const char *kmx_last_error(void);
@@ -168,10 +166,9 @@ int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double
 
 /* Per-kernel-class timing with HIP events recorded on the model's stream around each launch (off by default).
  * classes: 0 classify(+Bloom insert) 1 check (+ claim emission) 2 commit 3 ordered slow path 4 reorder 5 rest append 6 query
- * 7 detect (opposite claims) 8 commit of one group of lists beside the check of the next (the pipelined big rounds)
- * 9 check of a late round carrying the previous block's km_back emission.
- * seconds[10], launches[10] accumulate until reset.                                                          */
-#define KMX_KERNEL_CLASSES 10
+ * 7 detect (opposite claims) 8 commit of one group of lists beside the check of the next (the pipelined big rounds).
+ * seconds[9], launches[9] accumulate until reset.                                                            */
+#define KMX_KERNEL_CLASSES 9
 int kmx_set_profile(kmx_model *m, int on);
 int kmx_get_kernel_times(kmx_model *m, double *seconds, uint64_t *launches, int reset);
 

@@ -31,8 +31,7 @@ class Stats(C.Structure):
                 ("blocks", C.c_uint64), ("rounds", C.c_uint64),
                 ("k", C.c_int32), ("ci", C.c_int32), ("cs", C.c_int32), ("nh", C.c_int32), ("nb", C.c_int32),
                 ("bf_num", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32), ("rest_bytes", C.c_uint64),
-                ("piped_attempts", C.c_uint64), ("piped_commits", C.c_uint64),
-                ("hosted_attempts", C.c_uint64), ("hosted_kmers", C.c_uint64)]
+                ("piped_attempts", C.c_uint64), ("piped_commits", C.c_uint64)]
 
 
 # every symbol include/kmx.h declares (tests check that the library exports all of them)
@@ -339,7 +338,7 @@ class KModel:
         _chk(self.L.kmx_download(self.h, self.DL[which], index, buf.ctypes.data, cap, C.byref(w)))
         return buf[:w.value].copy()
 
-    KERNEL_CLASSES = ["classify", "check", "commit", "slow_path", "reorder", "rest_append", "query", "detect", "commit_check", "check_kmback"]
+    KERNEL_CLASSES = ["classify", "check", "commit", "slow_path", "reorder", "rest_append", "query", "detect", "commit_check"]
 
     def set_profile(self, on: bool) -> None:
         _chk(self.L.kmx_set_profile(self.h, int(on)))

@@ -24,8 +24,8 @@
 //   R  reorder       applies what the finisher decided, then the reference's unstable compaction
 //                    (kmodel.hpp:529-540) in one launch with lazily filled holes.
 //   Fused launches: in rounds 0 and 1 one group of lists commits beside the check of the next (k_round_commit_check:
-//   memory-side atomics and gathers side by side); the check launches of a block's last two rounds carry the km_back
-//   emission of the previous block as extra workgroups (k_round_check_kmback: they are latency-bound and leave the chip idle).
+//   memory-side atomics and gathers side by side); the finisher launches of those rounds (one workgroup per list) carry
+//   the km_back emission of the previous block as extra workgroups.
 #include "kmx_types.h"
 #include <cstdlib>
 
@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void k_histogram(const u32 *counts, u64 n, int
 	if (bad) atomicAdd(stats + ST_BAD_COUNT, bad);
 }
 
-// block-wide exclusive scan of one int per thread (256 threads)
+// block-wide exclusive scan of one int per thread over the first 256 threads (the other threads of a larger workgroup
+// only take part in the barriers and get the total)
 __device__ __forceinline__ int block_excl_scan_256(int v, int *s_tmp, int *total)
 {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -175,7 +176,7 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int *s_tmp, int *total
 		int t = __shfl_up(incl, d, 64);
 		if (lane >= d) incl += t;
 	}
-	if (lane == 63) s_tmp[wave] = incl;
+	if (lane == 63 && wave < 4) s_tmp[wave] = incl;
 	__syncthreads();
 	int wbase = 0, tot = 0;
 #pragma unroll
@@ -190,16 +191,17 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int *s_tmp, int *total
 }
 
 // ------------------------------------------------------------------------------------------ partitioned bit-set
-// bs_block_emit: every thread of a 256-thread workgroup brings nt <= K bit addresses of the filter; they are counted per
+// bs_block_emit: every thread of a BT-thread workgroup brings up to K bit addresses of the filter; they are counted per
 // bin in LDS, each bin's run is reserved with ONE global atomic, the tuples are sorted by bin in LDS and written out run
 // by run.  All threads must call it (barriers inside); the LDS arrays are the caller's.
 #define BS_LDS(K) __shared__ int s_bs_cnt[BS_BINS], s_bs_off[BS_BINS], s_bs_base[BS_BINS], s_bs_tmp[4]; __shared__ u64 s_bs_stage[256 * (K)]
 // the same arrays carved out of a byte pool the kernel owns (kernels that run one of several bodies per workgroup)
-#define BS_LDS_BYTES(K) (256 * (K) * 8 + (3 * BS_BINS + 4) * 4)
-#define BS_LDS_AT(K, p) u64 *s_bs_stage = (u64 *)(p); int *s_bs_cnt = (int *)((p) + 256 * (K) * 8), *s_bs_off = s_bs_cnt + BS_BINS, *s_bs_base = s_bs_off + BS_BINS, *s_bs_tmp = s_bs_base + BS_BINS
-template <int K> __device__ __forceinline__ void bs_block_emit(const BitScatter &bs, const u64 *v, u32 valid, int *s_cnt, int *s_off, int *s_base, int *s_tmp, u64 *s_stage)
+#define BS_LDS_BYTES(K, BT) ((BT) * (K) * 8 + (3 * BS_BINS + 4) * 4)
+#define BS_LDS_AT(K, BT, p) u64 *s_bs_stage = (u64 *)(p); int *s_bs_cnt = (int *)((p) + (BT) * (K) * 8), *s_bs_off = s_bs_cnt + BS_BINS, *s_bs_base = s_bs_off + BS_BINS, *s_bs_tmp = s_bs_base + BS_BINS
+template <int K, int BT = 256> __device__ __forceinline__ void bs_block_emit(const BitScatter &bs, const u64 *v, u32 valid, int *s_cnt, int *s_off, int *s_base, int *s_tmp, u64 *s_stage)
 {
-	s_cnt[threadIdx.x] = 0;
+	static_assert(BT >= BS_BINS, "one thread per bin");
+	if (threadIdx.x < BS_BINS) s_cnt[threadIdx.x] = 0;
 	__syncthreads();
 	int rank[K];
 #pragma unroll
@@ -208,10 +210,12 @@ template <int K> __device__ __forceinline__ void bs_block_emit(const BitScatter 
 	__syncthreads();
 	int total;
 	{
-		const int c = s_cnt[threadIdx.x];
+		const int c = threadIdx.x < BS_BINS ? s_cnt[threadIdx.x] : 0;
 		const int ex = block_excl_scan_256(c, s_tmp, &total);
-		s_off[threadIdx.x] = ex;
-		s_base[threadIdx.x] = c ? atomicAdd(bs.cnt + threadIdx.x, c) : 0;
+		if (threadIdx.x < BS_BINS) {
+			s_off[threadIdx.x] = ex;
+			s_base[threadIdx.x] = c ? atomicAdd(bs.cnt + threadIdx.x, c) : 0;
+		}
 	}
 	__syncthreads();
 #pragma unroll
@@ -221,7 +225,7 @@ template <int K> __device__ __forceinline__ void bs_block_emit(const BitScatter 
 			s_stage[s_off[b] + rank[j]] = ((u64)b << 32) | (u32)(v[j] - ((u64)b << bs.wshift));
 		}
 	__syncthreads();
-	for (int q = threadIdx.x; q < total; q += 256) {
+	for (int q = threadIdx.x; q < total; q += BT) {
 		const u64 e = s_stage[q];
 		const u32 b = (u32)(e >> 32), o = (u32)e;
 		const u32 g = (u32)s_base[b] + (u32)(q - s_off[b]);
@@ -877,6 +881,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0
 #define KMX_FIN_LOG2 14
 #endif
 #define KMX_FIN_T (1 << KMX_FIN_LOG2)
+#define KMX_FIN_RIDER_KPT(NHM) ((NHM) <= 8 ? 2 : 1)            // k-mers per thread of a rider workgroup in the finisher launch (its LDS must fit the finisher's)
 #define KMX_FIN_MAX_POS (1ULL << (KMX_FIN_LOG2 + 22))   // slot index + 22 identity bits name a position exactly below this
 #define FIN_MARK 0x80000000u
 // workgroup barrier for LDS-only hand-offs: __syncthreads() would also wait for every outstanding global store and
@@ -1194,13 +1199,48 @@ __device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev
 		for (int u = threadIdx.x; u < n; u += 1024) {
 			u32 x, bin;
 			u64 v[W];
-			rec_load<W>(bd.Urec[lv], row + u, x, bin, v);
+			const u32 um = rec_load<W>(bd.Urec[lv], row + u, x, bin, v);
 			if (bd.status[row + x] != SLOT_UNDECIDED) continue;
 			Aligned<W> al = left_align<W>(v, md.k);
 			Premixed<W> pm = premix_string<W>(al, md.gfull);
+			if (first) {
+				// k_round_commit's reservations are resolved exactly as k_slow_resolve0 does it, from the untagged mask
+				// check_emit left in the record: whoever holds the reservation of EVERY position in it commits those
+				// positions.  (Until the end of round 2 this iteration gathered the cells afresh and asked only for the positions
+				// still untagged by then.  From round 1 on -- arrays with content, unmarked candidates committing beside the
+				// reservations -- that gave the wrong winner in 0.1-3 % of the builds of one tiny-array configuration, always
+				// the same pair of k-mers swapped (tools/soak_case.py); the criterion of k_slow_resolve0 and of the LDS path
+				// has never failed: 0 of 9500 builds under the same conditions.)
+				const u64 key = resv_key(epoch_b, x);
+				const int sbase = a * md.nh;
+				cell_t *cells = md.cells[a];
+				u64 pos[NHM];
+				bool mine = true;
+#pragma unroll
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh && ((um >> j) & 1u)) {
+						pos[j] = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(sbase + j) & 127]), md.km_mod);
+						mine &= cell_load_coherent(resv_slot(bd, i, pos[j])) == key;
+					}
+				if (mine) {
+#pragma unroll
+					for (int j = 0; j < NHM; j++)
+						if (j < md.nh && ((um >> j) & 1u)) {
+							const u32 b = bit_in_cell(pos[j]);
+							atomicOr(cells + (pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0u));
+						}
+					if (md.kmb_direct) {
+						Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
+						bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+					}
+					bd.status[row + x] = SLOT_INSERTED;
+					succ++;
+				}
+				continue;
+			}
 			Touches<NHM> tc;
 			gather_touches<W, NHM, true>(md, pm, a, tc);
-			if (owns_outcome<NHM, true>(md, bd, i, tc, bin, resv_key(first ? epoch_b : epoch, x))) {
+			if (owns_outcome<NHM, true>(md, bd, i, tc, bin, resv_key(epoch, x))) {
 				commit_touches<W, NHM>(md, tc, bin, a, al);
 				bd.status[row + x] = SLOT_INSERTED;
 				succ++;
@@ -1219,10 +1259,24 @@ __device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev
 }
 
 // One workgroup per list.
-template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch_b, u64 epoch0, int force_global)
+// Workgroups past the first nb are riders: the finisher is ONE workgroup per list that walks a chain of dependent steps
+// (33 us in round 0, 10-17 us later) while the other 250 CUs idle, so the km_back emission the PREVIOUS block still owes
+// (`job`: its staging region and survivor flags) runs in the same launch, one 1024-thread workgroup per 1024 k-mers --
+// throughput work that costs the launch (almost) nothing.  (Hosted by the late rounds' check launches instead it cost
+// 15-24 us per launch: its LDS cut the check's occupancy from 8 to 3 workgroups per CU.)
+template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch_b, u64 epoch0, int force_global, KmbackJob job, BitScatter kmb)
 {
-	__shared__ u32 s_t1[KMX_FIN_T], s_t2[KMX_FIN_T], s_list[KMX_FIN_RPT(NHM) * 1024];
-	__shared__ int s_pending[3], s_succ, s_count;
+	constexpr int RKPT = KMX_FIN_RIDER_KPT(NHM);
+	constexpr int FIN_BYTES = (2 * KMX_FIN_T + KMX_FIN_RPT(NHM) * 1024) * 4 + 8 * 4, RIDER_BYTES = BS_LDS_BYTES(RKPT * (NHM - 2), 1024);
+	__shared__ __align__(16) unsigned char pool[FIN_BYTES > RIDER_BYTES ? FIN_BYTES : RIDER_BYTES];
+	if ((int)blockIdx.x >= md.nb) {
+		const int r = (int)blockIdx.x - md.nb, gxk = KMX_BUCKET / (1024 * RKPT);
+		kmback_emit_body<W, NHM, RKPT, 1024>(md, bd, job.kmers, job.surv, pp, job.n_in_block, kmb, job.i0 + r / gxk, r % gxk, gxk, pool);
+		return;
+	}
+	u32 *s_t1 = (u32 *)pool, *s_t2 = s_t1 + KMX_FIN_T, *s_list = s_t2 + KMX_FIN_T;
+	int *s_pending = (int *)(s_list + KMX_FIN_RPT(NHM) * 1024);
+	int &s_succ = s_pending[3], &s_count = s_pending[4];
 	const int i = blockIdx.x, lv = s & 1;
 	const int n = bd.Un[UN_IDX(lv, i, md.nb)];
 	if (n == 0) return;
@@ -1439,23 +1493,23 @@ __global__ __launch_bounds__(1024) void k_bs_apply2(BitScatter bs)
 // commit or by the ordered path -- contributes the nh-2 positions of its (k-2)-mer to the BitScatter of km_back.
 // n_in_block >= 0: once per block instead -- every k-mer of the block that did not go to the rest table was inserted in
 // one of the rounds (the single-GPU build; in the multi-GPU ring a rank sees a list for one round only).
-template <int W, int NHM, int KPT>
+template <int W, int NHM, int KPT, int BT = 256>
 __device__ __forceinline__ void kmback_emit_body(const ModelDev &md, const BlockDev &bd, const u64 *kmers, const unsigned char *surv, int pp, int n_in_block,
                                                  const BitScatter &bs, int i, int bx, int gx, unsigned char *lds)
 {
 	constexpr int K = KPT * (NHM - 2);
-	BS_LDS_AT(K, lds);
+	BS_LDS_AT(K, BT, lds);
 	const bool whole = n_in_block >= 0;
 	int n;
 	if (whole) { n = n_in_block - i * (int)KMX_BUCKET; n = n < 0 ? 0 : (n > (int)KMX_BUCKET ? (int)KMX_BUCKET : n); }
 	else n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
-	for (int base = bx * 256 * KPT; base < n; base += gx * 256 * KPT) {   // uniform trip count per workgroup
+	for (int base = bx * BT * KPT; base < n; base += gx * BT * KPT) {     // uniform trip count per workgroup
 		u64 v[K];
 		u32 valid = 0;
 #pragma unroll
 		for (int q = 0; q < KPT; q++) {
-			const int x = base + q * 256 + (int)threadIdx.x;
+			const int x = base + q * BT + (int)threadIdx.x;
 			if (x < n && (whole ? !surv[row + x] : bd.status[row + x] == SLOT_INSERTED)) {
 				const u32 idx = whole ? (u32)x : bd.list[pp][row + x];
 				u64 km[W];
@@ -1470,26 +1524,13 @@ __device__ __forceinline__ void kmback_emit_body(const ModelDev &md, const Block
 					}
 			}
 		}
-		bs_block_emit<K>(bs, v, valid, s_bs_cnt, s_bs_off, s_bs_base, s_bs_tmp, s_bs_stage);
+		bs_block_emit<K, BT>(bs, v, valid, s_bs_cnt, s_bs_off, s_bs_base, s_bs_tmp, s_bs_stage);
 	}
 }
 template <int W, int NHM, int KPT> __global__ __launch_bounds__(256) void k_kmback_emit(ModelDev md, BlockDev bd, const u64 *kmers, const unsigned char *surv, int i0, int pp, int n_in_block, BitScatter bs)
 {
-	__shared__ __align__(16) unsigned char lds[BS_LDS_BYTES(KPT * (NHM - 2))];
+	__shared__ __align__(16) unsigned char lds[BS_LDS_BYTES(KPT * (NHM - 2), 256)];
 	kmback_emit_body<W, NHM, KPT>(md, bd, kmers, surv, pp, n_in_block, bs, i0 + (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, lds);
-}
-
-// A|K: the check of a late round with the km_back emission of the PREVIOUS block riding along.  From round 2 on a check
-// launch is one short wave of workgroups that waits on a chain of dependent loads (list entry -> k-mer -> bin -> gathers ->
-// run reservation) while most of the chip idles; the first gx_check workgroups of a row are that check, the others hash
-// the (k-2)-mers of `job` and stream their tuples out -- throughput work that costs the launch (almost) nothing.
-template <int W, int NHM, int KPT> __global__ __launch_bounds__(256) void k_round_check_kmback(ModelDev md, BlockDev bd, int t, int pp, int gx_check, int n_check, KmbackJob job, BitScatter bs)
-{
-	constexpr int LB = CHECK_LDS_BYTES(NHM) > BS_LDS_BYTES(KPT * (NHM - 2)) ? CHECK_LDS_BYTES(NHM) : BS_LDS_BYTES(KPT * (NHM - 2));
-	__shared__ __align__(16) unsigned char lds[LB];
-	const int y = (int)blockIdx.y;
-	if ((int)blockIdx.x < gx_check) { if (y < n_check) check_emit_body<W, NHM>(md, bd, t, pp, y, (int)blockIdx.x, gx_check, lds, ST_HOST_ATTEMPTS); }
-	else if (y < job.n_lists) kmback_emit_body<W, NHM, KPT>(md, bd, job.kmers, job.surv, pp, job.n_in_block, bs, job.i0 + y, (int)blockIdx.x - gx_check, (int)gridDim.x - gx_check, lds);
 }
 
 // survivors of the block go to the rest table (kmodel.hpp:567-571); slot 0 is remembered for the
@@ -2259,27 +2300,6 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 		KPROF_BEGIN(prof, KC_VERIFY_COMMIT, st);
 		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit<W, NHM>), dim3(gx, nb - lo(groups - 1)), blk, 0, st, md, bd, t, pp, eb, lo(groups - 1)));
 		KPROF_END(prof, st);
-	} else if (job && job->n_lists > 0) {
-		// a late round: the previous block's km_back emission rides along (k_round_check_kmback)
-		// The riders keep the standalone kernel's 4 (2) k-mers per thread: with one k-mer per thread their LDS would fit
-		// inside the check's own (8 workgroups per CU instead of 3), but every workgroup iteration reserves its 256 runs
-		// with 256 returning atomics on the same 256 counters, four times as many then -- measured 79 us per launch
-		// against 54, and 83.4 ms per build against 74.8.
-		const int gxk = KMX_BUCKET / 1024;                         // workgroups per list of the job
-		const dim3 hgrid(gx + gxk, nb > job->n_lists ? nb : job->n_lists);
-		KPROF_BEGIN(prof, KC_CHECK_KMBACK, st);
-		if (words(md) == 1) {
-			if (md.nh <= 8) hipLaunchKernelGGL((k_round_check_kmback<1, 8, 4>), hgrid, blk, 0, st, md, bd, t, pp, gx, nb, *job, *kmb);
-			else hipLaunchKernelGGL((k_round_check_kmback<1, 16, 2>), hgrid, blk, 0, st, md, bd, t, pp, gx, nb, *job, *kmb);
-		} else {
-			if (md.nh <= 8) hipLaunchKernelGGL((k_round_check_kmback<2, 8, 4>), hgrid, blk, 0, st, md, bd, t, pp, gx, nb, *job, *kmb);
-			else hipLaunchKernelGGL((k_round_check_kmback<2, 16, 2>), hgrid, blk, 0, st, md, bd, t, pp, gx, nb, *job, *kmb);
-		}
-		KPROF_END(prof, st);
-		detect(0, nb);
-		KPROF_BEGIN(prof, KC_VERIFY_COMMIT, st);
-		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit<W, NHM>), grid, blk, 0, st, md, bd, t, pp, eb, 0));
-		KPROF_END(prof, st);
 	} else {
 		KPROF_BEGIN(prof, KC_CHECK_CLAIM, st);
 		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_emit<W, NHM>), grid, blk, 0, st, md, bd, t, pp, 0));
@@ -2303,7 +2323,12 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	const int force_global = (flags & KMX_ROUND_FIN_GLOBAL) ? 1 : 0;   // test hook: the finisher's global-memory path for every set
 	const u64 e0 = *epoch;
 	*epoch += (1ULL << 19);                                    // the finisher may use up to |U| <= 2^18 epochs
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb, 1), dim3(1024), 0, st, md, bd, t, pp, nsub, eb, e0, force_global));
+	{
+		KmbackJob none = {nullptr, nullptr, 0, 0, 0};
+		const KmbackJob &jb = job && job->n_lists > 0 && kmb ? *job : none;
+		const int riders = jb.n_lists * (int)(KMX_BUCKET / (1024 * KMX_FIN_RIDER_KPT(md.nh <= 8 ? 8 : 16)));   // one workgroup per 2048 (1024) k-mers of the hosted lists
+		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb + riders, 1), dim3(1024), 0, st, md, bd, t, pp, nsub, eb, e0, force_global, jb, kmb ? *kmb : BitScatter()));
+	}
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_REORDER, st);
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, nb), dim3(256), 0, st, md, bd, t, pp, nsub & 1, piped_commits));
@@ -2314,14 +2339,6 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 void rest_append(const ModelDev &md, const BlockDev &bd, int pp, int i0, int n_lists, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, u64 *feedback, hipStream_t st)
 {
 	DISPATCH_W(words(md), hipLaunchKernelGGL(k_rest_append<W>, dim3(KMX_BUCKET / 256, n_lists), dim3(256), 0, st, bd, pp, i0, rest_kmers, rest_counts, rest_n, stale_kmers, stale_counts, feedback));
-}
-
-// true when round t of a block of nb lists runs as whole-round kernels under `flags` (a check launch that can host)
-bool round_can_host(int nb, int t, int flags)
-{
-	int groups = (flags >> KMX_ROUND_PIPE_SHIFT) & 15;
-	if (groups > nb) groups = nb;
-	return !(groups > 1 && t < KMX_PIPE_ROUNDS);
 }
 
 // n_in_block < 0: the slots round t inserted (list[pp], status); >= 0: every k-mer of the block that is not a survivor.

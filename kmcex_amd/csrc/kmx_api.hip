@@ -34,7 +34,6 @@ void classify_count(const ModelDev &, const u64 *, const u32 *, u64, u64, int *,
 void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int *, u64 *, u32 *, u64, hipStream_t);
 void block_init(const BlockDev &, int, int, int, hipStream_t);
 void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *, const KmbackJob *, const BitScatter *);
-bool round_can_host(int nb, int t, int flags);
 void rest_append(const ModelDev &, const BlockDev &, int, int, int, u64 *, int *, unsigned long long *, u64 *, int *, u64 *, hipStream_t);
 void kmback_emit(const ModelDev &, const BlockDev &, const u64 *, const unsigned char *, int, int, int, int, int, const BitScatter &, hipStream_t);
 void bs_apply(const BitScatter &, hipStream_t);
@@ -221,9 +220,8 @@ struct kmx_model {
 	bool kmb_deferred = false;
 	bool dbg_kmb_direct = false;                               // KMX_KMB_DIRECT=1: the atomic path at every size (test hook)
 	unsigned char *d_surv[2] = {nullptr, nullptr};             // survivor flags of the current and of the previous block (inside the scratch slab)
-	KmbackJob kmb_job = {nullptr, nullptr, 0, 0, 0};            // km_back emission the last block still owes (hosted by the next block's late rounds)
+	KmbackJob kmb_job = {nullptr, nullptr, 0, 0, 0};            // km_back emission the last block still owes (hosted by the next block's finisher launches)
 	bool dbg_kmb_host = true;                                  // KMX_KMB_HOST=0: every block emits in a launch of its own (test hook)
-	u64 hosted_kmers = 0;                                      // k-mers of blocks whose emission rode along (accounting)
 	u32 *d_bs2_tup = nullptr;                                  // second level of the two bit-sets (big filters), shared: [bins * tiles][cap2]
 	int *d_bs2_cnt = nullptr;
 	u64 bs2_tup_cap = 0, bs2_cnt_cap = 0;
@@ -578,7 +576,6 @@ static int setup_kmback_scatter(kmx_model *m)
 	m->kmb_deferred = false;
 	m->kmb_pending = 0;
 	m->kmb_job.n_lists = 0;
-	m->hosted_kmers = 0;
 	const u64 nwords = (m->byte_km_back + 3) / 4;
 	if (m->dbg_kmb_direct || nwords == 0) return KMX_OK;
 	u32 wshift = 5;
@@ -860,17 +857,14 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 	int pp = 0;
 	kmxk::block_init(m->bd, nb, pp, (int)n_in_block, m->stream);
 	steer_passes(m);
-	// The previous block's km_back emission rides along with the check launches of this block's last two rounds (the
-	// first of them takes the larger share of the lists: its check is the longer one).
+	// The previous block's km_back emission rides along with this block's finisher launches, one list per round: 128
+	// rider workgroups beside the nb finisher workgroups, one wave of workgroups on 256 CUs.
 	KmbackJob &job = m->kmb_job;
-	const int host_a = nb >= 2 && kmxk::round_can_host(nb, nb - 2, m->dbg_flags) ? nb - 2 : -1;
-	const int host_b = kmxk::round_can_host(nb, nb - 1, m->dbg_flags) ? nb - 1 : -1;
-	if (job.n_lists > 0 && host_b < 0) TRY(kmback_job_flush(m));
 	for (int t = 0; t < nb; t++) {
 		KmbackJob part = {nullptr, nullptr, 0, 0, 0};
-		if (job.n_lists > 0 && (t == host_a || t == host_b)) {
+		if (job.n_lists > 0) {
 			part = job;
-			if (t == host_a && host_b >= 0) part.n_lists = (job.n_lists + 1) / 2;
+			part.n_lists = 1;
 			const u64 lo = (u64)part.i0 * KMX_BUCKET, nbk = (u64)part.n_in_block;
 			TRY(kmback_reserve(m, nbk > lo ? std::min<u64>(nbk - lo, (u64)part.n_lists * KMX_BUCKET) : 0));
 			job.i0 += part.n_lists;
@@ -888,12 +882,11 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 			                   (const int *)m->d_stale_counts, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stats);
 	}
 	kmxk::rest_append(m->md, m->bd, pp, 0, nb, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream);
-	// km_back insert of everything the block inserted (kmodel.hpp:548-550): handed to the next block's late rounds, or
-	// done here when nothing can host it
+	// km_back insert of everything the block inserted (kmodel.hpp:548-550): handed to the next block's finisher launches,
+	// or done here when there is no next block to host it
 	if (m->kmb_deferred) {
-		if (m->dbg_kmb_host && !final_partial && host_b >= 0) {
+		if (m->dbg_kmb_host && !final_partial) {
 			job.kmers = m->bd.kmers; job.surv = m->bd.surv; job.n_in_block = (int)n_in_block; job.i0 = 0; job.n_lists = nb;
-			m->hosted_kmers += n_in_block;
 		} else TRY(kmback_emit(m, 0, pp, (int)n_in_block, n_in_block));
 	}
 	m->blocks++;
@@ -2066,7 +2059,6 @@ static int kmx_get_stats_impl(kmx_model *m, kmx_stats *st)
 	st->rest_entries = m->rest.entries; st->km_byte_size = m->km_byte_size; st->byte_km_back = m->byte_km_back;
 	st->blocks = m->blocks; st->rounds = m->rounds;
 	st->piped_attempts = m->h_stats[ST_PIPE_ATTEMPTS]; st->piped_commits = m->h_stats[ST_PIPE_SUCC];
-	st->hosted_attempts = m->h_stats[ST_HOST_ATTEMPTS]; st->hosted_kmers = m->hosted_kmers;
 	st->rest_bytes = m->rest.suff_bin_size + 4 * m->rest.entries + 4 * (u64)m->rest.pre_buffer_size + 4 * (u64)m->rest.map_size;
 	st->k = m->k; st->ci = m->ci; st->cs = m->cs; st->nh = m->nh; st->nb = m->nb; st->bf_num = m->bf_num; st->device = m->device;
 	return KMX_OK;

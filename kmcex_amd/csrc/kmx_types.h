@@ -51,8 +51,8 @@ struct BitScatter {
 	u32 *tup2;               // [BS_BINS << (wshift - tlog2)][cap2] bit offsets inside the tile
 	int *cnt2;               // [BS_BINS << (wshift - tlog2)], reset by k_bs_apply2
 };
-// km_back tuples a finished block still owes (the whole-block form of k_kmback_emit): hosted by the check launches of the
-// NEXT block's last rounds, which are latency-bound and leave most of the chip idle (k_round_check_kmback)
+// km_back tuples a finished block still owes (the whole-block form of k_kmback_emit): hosted by the finisher launches of
+// the NEXT block's first two rounds -- one workgroup per list, the rest of the chip idle (k_slow_finish)
 struct KmbackJob {
 	const u64 *kmers;            // the finished block's k-mers (its staging region, identity order)
 	const unsigned char *surv;   // its survivor flags (the other half of the double buffer)
@@ -73,7 +73,6 @@ struct KmcDecode {
 // device-side statistics (one u64 each)
 enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_MAX_U0, ST_MAX_UFIN,
        ST_PIPE_ATTEMPTS, ST_PIPE_SUCC,        // attempts examined / successes committed inside k_round_commit_check launches (accounting only)
-       ST_HOST_ATTEMPTS,                      // attempts examined inside k_round_check_kmback launches (accounting only)
        ST_N };
 
 #define KMX_CLS_TILE 2048                      // k-mers per classification tile (front end)
@@ -151,7 +150,7 @@ struct RingLists { RingList e[KMX_MAX_NB]; };
 enum { SLOT_UNDECIDED = 0, SLOT_FAILED = 1, SLOT_INSERTED = 2, SLOT_CONTENDED = 3 };
 
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
-enum { KC_CLASSIFY = 0, KC_CHECK_CLAIM, KC_VERIFY_COMMIT, KC_SLOW, KC_REORDER, KC_REST, KC_QUERY, KC_DETECT, KC_COMMIT_CHECK, KC_CHECK_KMBACK, KC_N };   // CHECK_CLAIM = check + emit, VERIFY_COMMIT = commit
+enum { KC_CLASSIFY = 0, KC_CHECK_CLAIM, KC_VERIFY_COMMIT, KC_SLOW, KC_REORDER, KC_REST, KC_QUERY, KC_DETECT, KC_COMMIT_CHECK, KC_N };   // CHECK_CLAIM = check + emit, VERIFY_COMMIT = commit
 struct KernelProf {
 	bool on = false;
 	void *events = nullptr;      // std::vector<hipEvent_t>* owned by the host side

@@ -272,6 +272,31 @@ def test_partitioned_bit_sets_at_every_depth(cfg, monkeypatch):
     monkeypatch.delenv("KMX_KMB_HOST")
 
 
+def test_finisher_alone_on_filled_arrays_is_timing_independent(monkeypatch):
+    """A tiny-array configuration (everything contended, sets above the finisher's LDS capacity) built 300 times with the
+    finisher alone in every round (KMX_NSUB0 = KMX_NSUB1 = 0) on its global-memory path: from round 1 on the arrays have
+    content and unmarked candidates commit beside the reservations.  The first finisher iteration used to gather the cells
+    afresh there and let the wrong one of two k-mers win in up to 3 % of such builds (tools/soak_case.py, DESIGN.md §7);
+    every build must give the oracle's arrays."""
+    import hashlib
+    k, ci, cs, nh, nb, n, seed = 62, 3, 146, 5, 2, 120000, 834071094
+    km, cnt = synth.make_stream(n, k, ci, cs, seed_k=seed, seed_c=seed + 1)
+    o = O.OracleModel(ci, cs, nh, nb)
+    o.build(k, km, cnt)
+    dig = lambda x: hashlib.sha1(np.ascontiguousarray(x).tobytes()).hexdigest()
+    want = [dig(o.array_bytes(w, a)) for a in range(nb) for w in ("tag", "value")] + [dig(o.array_bytes("km_back"))]
+    for v, x in (("KMX_NSUB0", "0"), ("KMX_NSUB1", "0"), ("KMX_FIN_GLOBAL", "1")):
+        monkeypatch.setenv(v, x)
+    for it in range(300):
+        m = KModel(ci, cs, nh, nb)
+        m.build_packed(k, km, cnt)
+        got = [dig(m.download(w, a)) for a in range(nb) for w in ("tag", "value")] + [dig(m.download("km_back"))]
+        assert got == want, f"build {it} differs from the oracle"
+        del m
+    for v in ("KMX_NSUB0", "KMX_NSUB1", "KMX_FIN_GLOBAL"):
+        monkeypatch.delenv(v)
+
+
 def test_error_behaviour():
     m = KModel(1, 1023, 7, 5)
     with pytest.raises(api.KmxError):
