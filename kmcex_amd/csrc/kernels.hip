@@ -1207,10 +1207,9 @@ __device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev
 				// k_round_commit's reservations are resolved exactly as k_slow_resolve0 does it, from the untagged mask
 				// check_emit left in the record: whoever holds the reservation of EVERY position in it commits those
 				// positions.  (Until the end of round 2 this iteration gathered the cells afresh and asked only for the positions
-				// still untagged by then.  From round 1 on -- arrays with content, unmarked candidates committing beside the
-				// reservations -- that gave the wrong winner in 0.1-3 % of the builds of one tiny-array configuration, always
-				// the same pair of k-mers swapped (tools/soak_case.py); the criterion of k_slow_resolve0 and of the LDS path
-				// has never failed: 0 of 9500 builds under the same conditions.)
+				// still untagged by then.  In round 1 of one tiny-array configuration that gave a different set of winners in
+				// 0.1-3 % of the builds, always the same alternative outcome (tools/soak_case.py); the criterion of
+				// k_slow_resolve0 and of the LDS path has never failed: 0 of 9500 builds under the same conditions.)
 				const u64 key = resv_key(epoch_b, x);
 				const int sbase = a * md.nh;
 				cell_t *cells = md.cells[a];

@@ -273,11 +273,10 @@ def test_partitioned_bit_sets_at_every_depth(cfg, monkeypatch):
 
 
 def test_finisher_alone_on_filled_arrays_is_timing_independent(monkeypatch):
-    """A tiny-array configuration (everything contended, sets above the finisher's LDS capacity) built 300 times with the
-    finisher alone in every round (KMX_NSUB0 = KMX_NSUB1 = 0) on its global-memory path: from round 1 on the arrays have
-    content and unmarked candidates commit beside the reservations.  The first finisher iteration used to gather the cells
-    afresh there and let the wrong one of two k-mers win in up to 3 % of such builds (tools/soak_case.py, DESIGN.md §7);
-    every build must give the oracle's arrays."""
+    """A tiny-array configuration (nearly everything contended, sets above the finisher's LDS capacity) built 300 times
+    with the finisher alone in every round (KMX_NSUB0 = KMX_NSUB1 = 0) on its global-memory path.  The first finisher
+    iteration used to gather the cells afresh and gave a different set of winners in round 1 in up to 3 % of such builds
+    (tools/soak_case.py); every build must give the oracle's arrays."""
     import hashlib
     k, ci, cs, nh, nb, n, seed = 62, 3, 146, 5, 2, 120000, 834071094
     km, cnt = synth.make_stream(n, k, ci, cs, seed_k=seed, seed_c=seed + 1)
