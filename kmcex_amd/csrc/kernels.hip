@@ -132,6 +132,20 @@ template <int NHM> __device__ __forceinline__ bool touches_conflict(const ModelD
 	return fail;
 }
 
+// The value a k-mer leaves at the position of its hash j: a k-mer may hit one position with several of its hashes, and the
+// reference's set loop ORs their value bits (kmodel.hpp:611-618).  Every atomic for that position must carry the FINAL
+// value: set with one atomic per hash (tag|0, then tag|1), the position is for a moment tagged with value 0, a concurrent
+// gatherer that wants 0 there takes it for settled, drops it from what it must hold, and wins ahead of its turn -- the
+// timing-dependent result of tools/soak_case.py.  `among`: the hashes that take part (bit mask).
+template <int NHM> __device__ __forceinline__ u32 value_at_position(const ModelDev &md, const u64 *pos, u32 among, u32 bin, int j)
+{
+	u32 v = (bin >> j) & 1u;
+#pragma unroll
+	for (int j2 = 0; j2 < NHM; j2++)
+		if (j2 < md.nh && j2 != j && ((among >> j2) & 1u) && pos[j2] == pos[j]) v |= (bin >> j2) & 1u;
+	return v;
+}
+
 // kmodel.hpp:611-618 + :548-550: set tag (and value) bits, then the (k-2)-mer goes into km_back
 template <int W, int NHM>
 __device__ __forceinline__ void commit_touches(const ModelDev &md, const Touches<NHM> &t, u32 bin, int a, const Aligned<W> &al)
@@ -142,7 +156,7 @@ __device__ __forceinline__ void commit_touches(const ModelDev &md, const Touches
 		if (j < md.nh) {
 			u32 b = bit_in_cell(t.pos[j]);
 			if (!((t.cell[j] >> (16 + b)) & 1u))          // already tagged => already carries this value
-				atomicOr(cells + (t.pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0u));
+				atomicOr(cells + (t.pos[j] >> 4), CELL_TAG(b) | (value_at_position<NHM>(md, t.pos, ~0u, bin, j) ? CELL_VAL(b) : 0u));
 		}
 	if (md.kmb_direct) {
 		Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
@@ -833,7 +847,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0
 				for (int j = 0; j < NHM; j++)
 					if (j < md.nh && ((um >> j) & 1u)) {
 						const u32 b = bit_in_cell(pos[j]);
-						atomicOr(cells + (pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0u));
+						atomicOr(cells + (pos[j] >> 4), CELL_TAG(b) | (value_at_position<NHM>(md, pos, um, bin, j) ? CELL_VAL(b) : 0u));
 					}
 				if (md.kmb_direct) {
 					Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
@@ -1206,10 +1220,9 @@ __device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev
 			if (first) {
 				// k_round_commit's reservations are resolved exactly as k_slow_resolve0 does it, from the untagged mask
 				// check_emit left in the record: whoever holds the reservation of EVERY position in it commits those
-				// positions.  (Until the end of round 2 this iteration gathered the cells afresh and asked only for the positions
-				// still untagged by then.  In round 1 of one tiny-array configuration that gave a different set of winners in
-				// 0.1-3 % of the builds, always the same alternative outcome (tools/soak_case.py); the criterion of
-				// k_slow_resolve0 and of the LDS path has never failed: 0 of 9500 builds under the same conditions.)
+				// positions -- no gather.  (Until the end of round 2 this iteration gathered the cells afresh and asked only
+				// for the positions still untagged by then; that is sound too, now that a position is committed with its
+				// final value in one atomic -- see value_at_position -- but it costs a gather the snapshot makes unnecessary.)
 				const u64 key = resv_key(epoch_b, x);
 				const int sbase = a * md.nh;
 				cell_t *cells = md.cells[a];
@@ -1226,7 +1239,7 @@ __device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev
 					for (int j = 0; j < NHM; j++)
 						if (j < md.nh && ((um >> j) & 1u)) {
 							const u32 b = bit_in_cell(pos[j]);
-							atomicOr(cells + (pos[j] >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0u));
+							atomicOr(cells + (pos[j] >> 4), CELL_TAG(b) | (value_at_position<NHM>(md, pos, um, bin, j) ? CELL_VAL(b) : 0u));
 						}
 					if (md.kmb_direct) {
 						Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);

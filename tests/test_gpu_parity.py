@@ -274,9 +274,10 @@ def test_partitioned_bit_sets_at_every_depth(cfg, monkeypatch):
 
 def test_finisher_alone_on_filled_arrays_is_timing_independent(monkeypatch):
     """A tiny-array configuration (nearly everything contended, sets above the finisher's LDS capacity) built 300 times
-    with the finisher alone in every round (KMX_NSUB0 = KMX_NSUB1 = 0) on its global-memory path.  The first finisher
-    iteration used to gather the cells afresh and gave a different set of winners in round 1 in up to 3 % of such builds
-    (tools/soak_case.py); every build must give the oracle's arrays."""
+    with the finisher alone in every round (KMX_NSUB0 = KMX_NSUB1 = 0) on its global-memory path.  Up to 3 % of such
+    builds used to give a different set of winners: a position that one k-mer hits with two hashes was set with one atomic
+    per hash (tag|0, then tag|1) and a concurrent gatherer could see the value in between (tools/soak_case.py, DESIGN.md
+    §3.1); every build must give the oracle's arrays."""
     import hashlib
     k, ci, cs, nh, nb, n, seed = 62, 3, 146, 5, 2, 120000, 834071094
     km, cnt = synth.make_stream(n, k, ci, cs, seed_k=seed, seed_c=seed + 1)
