@@ -28,6 +28,20 @@ def test_library_exports_every_declared_symbol():
     assert L.kmx_last_error() is not None
 
 
+def test_struct_layouts_match_the_header(tmp_path):
+    """kmx_stats and kmx_ring_list as gcc lays them out from include/kmx.h have the size of their ctypes mirrors (a mirror
+    that is too small lets kmx_get_stats write past it)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "kmx.h"\nint main(void){ printf("%zu %zu %d\\n", sizeof(kmx_stats), sizeof(kmx_ring_list), KMX_KERNEL_CLASSES); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    a, b, c = (int(x) for x in subprocess.check_output([str(exe)]).split())
+    assert a == ctypes.sizeof(api.Stats) and b == ctypes.sizeof(api.RingList)
+    assert c == len(api.KModel.KERNEL_CLASSES)
+
+
 def test_occubin_host_table_matches_oracle():
     import oracle_lib as O
     for cs, nh in ((1023, 7), (4095, 9), (255, 7), (1023, 6)):
