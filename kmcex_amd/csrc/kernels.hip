@@ -249,6 +249,11 @@ template <int K, int BT = 256> __device__ __forceinline__ void bs_block_emit(con
 	__syncthreads();
 }
 
+// (defined with k_kmback_emit; the finisher launch runs it too, as rider workgroups)
+template <int W, int NHM, int KPT, int BT = 256>
+__device__ __forceinline__ void kmback_emit_body(const ModelDev &md, const BlockDev &bd, const u64 *kmers, const unsigned char *surv, int pp, int n_in_block,
+                                                 const BitScatter &bs, int i, int bx, int gx, unsigned char *lds);
+
 // ------------------------------------------------------------------------------------------ classification
 // Pass 2 front end (kmodel.hpp:70-73): Bloom-class k-mers are inserted right here (commutative ORs, any
 // order); coupled-array k-mers are compacted, in listing order, into the staging stream.
@@ -1505,7 +1510,7 @@ __global__ __launch_bounds__(1024) void k_bs_apply2(BitScatter bs)
 // commit or by the ordered path -- contributes the nh-2 positions of its (k-2)-mer to the BitScatter of km_back.
 // n_in_block >= 0: once per block instead -- every k-mer of the block that did not go to the rest table was inserted in
 // one of the rounds (the single-GPU build; in the multi-GPU ring a rank sees a list for one round only).
-template <int W, int NHM, int KPT, int BT = 256>
+template <int W, int NHM, int KPT, int BT>
 __device__ __forceinline__ void kmback_emit_body(const ModelDev &md, const BlockDev &bd, const u64 *kmers, const unsigned char *surv, int pp, int n_in_block,
                                                  const BitScatter &bs, int i, int bx, int gx, unsigned char *lds)
 {
