@@ -11,11 +11,13 @@ are timed in a second, separately bracketed region.  `value` is the insert rate 
 whole job); the query rate is reported beside it.
 
 Workload at N=1: BASELINE.json configs[1] -- synthetic 100 M distinct canonical 31-mers, nh=7 nb=5 ci=1
-cs=1023, D1 counts.  N>1: `value` = one independent stream + model per rank (weak scaling, no
-data-path collective); beside it `single_model` = ONE model over the concatenation of the N streams, built by the N
-ranks together (kmcex_amd/dist.py: k-mer routing all-to-all, ring of arrays over send/recv, OR-merged filters,
-replica queries; see DESIGN.md §multi-GPU).  `init_db` (N=1) times the reference's real entry point, KModel::init on a
-KMC database of the same stream in tmpfs (kmodel.hpp:57-86), host feed included.
+cs=1023, D1 counts.  N>1: `value` = ONE model (kmodel.hpp:57-86 is one model) over the concatenation of
+the N ranks' streams, built by the N ranks together (kmcex_amd/dist.py: k-mer routing all-to-all, ring of arrays over
+send/recv, OR-merged filters, replica queries) -- weak scaling, N * kmers_per_gpu k-mers in
+the model; `replica_value` beside it = N independent models, one per rank (no data-path collective).  At N=1 the two
+coincide and `value` is the plain build; `single_model` keeps the ring code's N=1 figure.  `init_db` (N=1) times the
+reference's real entry point, KModel::init on a KMC database of the same stream in tmpfs (kmodel.hpp:57-86), host feed
+included.
 """
 import argparse
 import json
@@ -51,7 +53,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-init-db", action="store_true", help="skip the KModel::init(database) leg")
     ap.add_argument("--no-single-model", action="store_true", help="skip the one-model-over-all-ranks leg")
-    ap.add_argument("--single-model-steps", type=int, default=2)
+    ap.add_argument("--single-model-steps", type=int, default=0, help="0: --steps when N > 1 (it is the headline there), 2 at N = 1")
     return ap.parse_args()
 
 
@@ -174,6 +176,20 @@ def headline(a, world, n, q, n_all, nq_all, t_ins, t_q, st, roof, cpu, extra, in
     return line
 
 
+def promote_single_model(line, single, world):
+    """N > 1: the headline is the ONE model the N ranks build together; the N independent models become `replica_value`."""
+    line["single_model"] = single
+    if world == 1 or not single or "value" not in single:
+        return line
+    line["replica_value"], line["replica_ms_per_step"], line["replica_query_value"] = line["value"], line["ms_per_step"], line["query_value"]
+    line["value"], line["ms_per_step"], line["query_value"] = single["value"], single["ms_per_build"], single["query_value"]
+    line["steps"] = single["steps"]
+    line["value_is"] = "k-mers/s encoded into ONE model by all ranks together (single_model); replica_value = N independent models"
+    line["config"]["parallelism"] = (f"one model over {world} ranks: routing all-to-all + ring of whole arrays (min({world}, nb) array owners) + "
+                                     f"OR-merged filters + replica queries; replica_value = {world} independent models")
+    return line
+
+
 def single_model_leg(a, m, km, cnt, q, out, rank, world, dev, rehearsal, distributed):
     """ONE model over the concatenation of all ranks' streams (rank order = listing order), built by the ranks together
     and queried over replicas.  Weak scaling: world * kmers_per_gpu k-mers in one model."""
@@ -181,7 +197,8 @@ def single_model_leg(a, m, km, cnt, q, out, rank, world, dev, rehearsal, distrib
     comm = kd.Comm()
     eng = kd.DeviceEngine(m, dev)
     bf_num = 1 if a.ci == 1 else 3
-    info = kd.build_sharded(eng, comm, a.k, a.nb, bf_num, km, cnt)                      # warm-up (allocations)
+    for _ in range(max(1, a.warmup if world > 1 else 1)):
+        info = kd.build_sharded(eng, comm, a.k, a.nb, bf_num, km, cnt)                  # warm-up (allocations)
     sync_all(distributed)
     t0 = time.perf_counter()
     for _ in range(a.single_model_steps):
@@ -206,6 +223,8 @@ def single_model_leg(a, m, km, cnt, q, out, rank, world, dev, rehearsal, distrib
 
 def main():
     a = parse()
+    if a.single_model_steps <= 0:
+        a.single_model_steps = a.steps if a.gpus > 1 else 2
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started bare: run the N-rank job as a child (nothing has touched the GPU in this process) and pass on its status
         import socket
@@ -363,13 +382,15 @@ def main():
             if done.is_set():
                 return
             if rank == 0:
-                partial["single_model"] = {"error": "no result after 300 s: exchange presumed hung"}
+                partial["single_model"] = {"error": "no result within the watchdog limit: exchange presumed hung"}
+                if world > 1:
+                    partial["replica_value"], partial["value"] = partial["value"], None     # the headline (one model) was NOT measured
                 print(json.dumps(partial), flush=True)
-            os._exit(0)
+            os._exit(3)                                                 # a hung exchange is a failed run on every rank
         partial = {}
         if rank == 0:
             partial = headline(a, world, n, q, n_all, nq_all, t_ins, t_q, st, roof, None, extra, init_db)
-        wd = threading.Timer(300.0, give_up)
+        wd = threading.Timer(300.0 + 30.0 * (a.single_model_steps + a.warmup), give_up)
         wd.daemon = True
         wd.start()
         try:
@@ -386,8 +407,7 @@ def main():
             cpu = {"error": repr(e)}
     if rank == 0:
         line = headline(a, world, n, q, n_all, nq_all, t_ins, t_q, st, roof, cpu, extra, init_db)
-        line["single_model"] = single
-        print(json.dumps(line), flush=True)
+        print(json.dumps(promote_single_model(line, single, world)), flush=True)
     if distributed:
         dist.barrier()                      # rank 0 may still have been in its roofline leg: leave together
         dist.destroy_process_group()

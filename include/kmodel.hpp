@@ -16,18 +16,37 @@
 #ifndef KMODEL_H
 #define KMODEL_H
 
+// Everything the reference header makes visible to its includers (kmodel.hpp:6-21): main.cpp uses ifstream, strncmp,
+// sprintf and system without including their headers itself.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
+#include <fstream>
 #include <iostream>
+#include <stdint.h>
+#include <stdio.h>
 #include <string>
 #include <vector>
 
 #include "kmx.h"
 
+// kmc_api/kmer_defs.h:27-28 (pulled in through kmc_api/kmc_file.h, kmodel.hpp:14): main.cpp's entry point is `_tmain`
+#ifndef _WIN32
+#ifndef _tmain
+#define _TCHAR char
+#define _tmain main
+#endif
+#endif
+
 // The reference header leaks `using namespace std;` and its README snippets and main.cpp rely on it (unqualified string,
 // vector<string>, cout); a drop-in has to leak it too.
 using namespace std;
+
+const string BASE_CHAR = "ACGT";          // kmodel.hpp:23-24 (visible to includers of the reference header)
+const int BLOACK_SIZE = 1 << 19;
 
 // the one helper of tools.hpp that main.cpp uses outside the class (tools.hpp:102-105)
 class Tools {

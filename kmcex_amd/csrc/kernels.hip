@@ -1604,7 +1604,7 @@ template <int W> __global__ __launch_bounds__(256) void k_ring_import(BlockDev b
 		const u64 *src_k = e.n_host >= 0 ? e.src_kmers : e.src_msg + KMX_MSG_HDR;
 		const u32 *src_c = e.n_host >= 0 ? e.src_counts : (const u32 *)(e.src_msg + KMX_MSG_HDR + (u64)KMX_BUCKET * W);
 		n = e.n_host >= 0 ? e.n_host : (int)e.src_msg[0];
-		if (n > (int)KMX_BUCKET) n = (int)KMX_BUCKET;               // a malformed header must not walk out of the buffers
+		n = n < 0 ? 0 : (n > (int)KMX_BUCKET ? (int)KMX_BUCKET : n);   // a malformed header must not walk out of the buffers (or give a negative length)
 		if (x < n) {
 			u64 v[W];
 			load_kmer<W>(src_k, (u64)x, v);

@@ -50,3 +50,48 @@ def test_facade_vector_of_strings_gives_reference_answers(tmp_path):
     p = subprocess.run([exe, tiny, os.path.join(tiny, "queries.txt")], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout[-300:] + p.stderr
     assert p.stdout.split() == open(os.path.join(tiny, "occ.txt")).read().split()
+
+
+REF_MAIN = "/root/reference/main.cpp"
+FACADE_EXE = os.path.join(ROOT, "oracle", "_ref", "kmcEx_facade")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="the reference is only present in the build container")
+def test_reference_main_cpp_compiles_against_the_facade(tmp_path):
+    """The reference's own caller (main.cpp:11-13, 56-62, 74, 155) compiles UNMODIFIED against include/kmodel.hpp with the
+    reference's flags (makefile:4) and links libkmx.so.  The copy lives in tmp_path only; next to it there is no
+    reference kmodel.hpp, so `#include "kmodel.hpp"` can only resolve to the facade."""
+    import shutil
+    api.load_library()
+    src = str(tmp_path / "main.cpp")
+    shutil.copyfile(REF_MAIN, src)
+    exe = str(tmp_path / "kmcEx")
+    subprocess.check_call(["g++", "-O3", "-m64", "-fopenmp", "-std=c++11", "-w", "-I" + os.path.join(ROOT, "include"), src,
+                           "-L" + os.path.join(ROOT, "kmcex_amd"), "-lkmx", "-Wl,-rpath," + os.path.join(ROOT, "kmcex_amd"), "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert "kmcEx [options] <input_file_name> <output_file_name> <working_directory>" in p.stdout      # read_me(), main.cpp:30-55
+    # the committed recipe builds the same thing into oracle/_ref (it travels to the GPU box; the source does not)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "facade"])
+    assert os.path.exists(FACADE_EXE)
+
+
+@pytest.mark.gpu
+def test_reference_main_cpp_binary_reproduces_reference_model_files(tmp_path):
+    """oracle/_ref/kmcEx_facade = /root/reference/main.cpp compiled against the facade (oracle/Makefile `facade`): run the
+    way the README runs kmcEx, on the tiny golden database, it writes the reference's three files.  (main.cpp:140 shells
+    out to ./kmc_api/kmc, absent like in the reference snapshot; `run` ignores that and opens the database that is there.
+    main.cpp:150 has no return statement, so the exit status is not the reference's to define: only the files are compared.)"""
+    if not os.path.exists(FACADE_EXE):
+        pytest.skip("oracle/_ref/kmcEx_facade was not built (no reference at build time)")
+    import shutil
+    tiny = os.path.join(ROOT, "tests", "golden", "tiny")
+    work = tmp_path / "work"
+    work.mkdir()
+    for ext in (".kmc_pre", ".kmc_suf"):
+        shutil.copyfile(os.path.join(tiny, "db" + ext), str(tmp_path / ("db" + ext)))
+    p = subprocess.run([FACADE_EXE, "-k31", "-nh7", "-nb5", "-ci1", "-cs1023", "reads.fq", str(tmp_path / "db"), str(work)],
+                       capture_output=True, text=True, cwd=str(tmp_path))
+    out = work / "db"
+    for f in ("header", "km.bin", "rest.bin"):
+        assert os.path.exists(str(out / f)), p.stdout[-500:] + p.stderr[-500:]
+        assert sha_file(str(out / f)) == sha_file(os.path.join(tiny, f)), f
