@@ -63,7 +63,8 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    path = os.environ.get("KMX_LIBRARY")        # a specially built variant (tools/stress_small_tables.py); never set in normal use
+    # a specially built variant (tools/stress_small_tables.py): a test hook like the library's own, honoured only with KMX_TEST_HOOKS=1
+    path = os.environ.get("KMX_LIBRARY") if os.environ.get("KMX_TEST_HOOKS") == "1" else None
     if path:
         if not os.path.exists(path):
             raise KmxError(-2, f"KMX_LIBRARY={path} does not exist")

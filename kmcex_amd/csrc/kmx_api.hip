@@ -57,6 +57,15 @@ void rest_suffix_bytes(const u64 *, u64, int, int, unsigned char *, hipStream_t)
 
 // ------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
+
+// Every behaviour-changing environment variable of this library is a TEST HOOK (forced code paths, shrunken tables): they
+// are read only when KMX_TEST_HOOKS=1 is set as well, so that a stray variable cannot move a user onto an untuned path.
+// (KMX_INIT_TRACE only prints phase times and is not gated.)
+static const char *hook_env(const char *name)
+{
+	static const bool on = [] { const char *e = getenv("KMX_TEST_HOOKS"); return e && atoi(e) != 0; }();
+	return on ? getenv(name) : nullptr;
+}
 static int fail(int code, const char *fmt, ...)
 {
 	va_list ap;
@@ -398,7 +407,7 @@ static int create_device_side(kmx_model *m)
 	HIPCHK(hipHostGetDevicePointer((void **)&m->d_feedback, m->h_feedback, 0));
 	m->h_feedback[0] = ~0ULL; m->h_feedback[1] = 0;
 	{
-		auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+		auto env_int = [](const char *name, int dflt) { const char *v = hook_env(name); return v ? atoi(v) : dflt; };
 		m->dbg_nsub0 = env_int("KMX_NSUB0", -1);
 		m->dbg_nsub1 = env_int("KMX_NSUB1", -1);
 		m->dbg_flags = (env_int("KMX_FIN_GLOBAL", 0) ? KMX_ROUND_FIN_GLOBAL : 0) | (env_int("KMX_RESOLVE_GATHER", 0) ? KMX_ROUND_RESOLVE_GATHER : 0)
@@ -532,12 +541,12 @@ static const u32 kBsMaxTileShift = 3;
 // KMX_BS_TILE_LOG2=<t> (10..20) shrinks the tiles, so that small filters take the multi-tile and the two-level sweeps
 static u64 bs_cap_hook()
 {
-	static const u64 v = [] { const char *e = getenv("KMX_BS_CAP"); const long long x = e ? atoll(e) : 0; return x > 0 ? (u64)std::min<long long>(x, 1 << 18) : 0ull; }();
+	static const u64 v = [] { const char *e = hook_env("KMX_BS_CAP"); const long long x = e ? atoll(e) : 0; return x > 0 ? (u64)std::min<long long>(x, 1 << 18) : 0ull; }();
 	return v;
 }
 static u32 bs_tile_log2()
 {
-	const char *e = getenv("KMX_BS_TILE_LOG2");                    // (read at every kmx_begin, so one test process can try several)
+	const char *e = hook_env("KMX_BS_TILE_LOG2");                    // (read at every kmx_begin, so one test process can try several)
 	const int x = e ? atoi(e) : 20;
 	return (u32)std::min(std::max(x, 10), 20);
 }
@@ -1293,7 +1302,7 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 	const size_t rb = db.record_bytes();
 	HIPCHK(hipSetDevice(m->device));
 	lap("database open");
-	const char *force_host = getenv("KMX_KMC_HOST_DECODE");
+	const char *force_host = hook_env("KMX_KMC_HOST_DECODE");
 	bool gpu_decode = !(force_host && atoi(force_host));
 	FeedSlot slot[2];
 	auto &F = m->feed;

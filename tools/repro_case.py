@@ -1,5 +1,6 @@
 """Re-run ONE configuration of tools/stress_parity.py under several hook settings and report which arrays differ from the oracle.
 usage: python tools/repro_case.py k ci cs nh nb n seed"""
+import os as _os; _os.environ.setdefault("KMX_TEST_HOOKS", "1")   # forced code paths are test hooks
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

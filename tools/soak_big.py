@@ -1,5 +1,6 @@
 """The bench configuration built over and over on the production path (default hooks): every build must leave the same
 arrays (digests of tag/value arrays and km_back).  usage: python tools/soak_big.py [n] [builds]"""
+import os as _os; _os.environ.setdefault("KMX_TEST_HOOKS", "1")   # forced code paths are test hooks
 import hashlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,5 +1,6 @@
 """Soak ONE configuration: build it many times under a hook setting and compare every build with the CPU oracle (arrays by
 digest).  Finds timing-dependent results.  usage: python tools/soak_case.py k ci cs nh nb n seed forced iters [ENV=VAL ...]"""
+import os as _os; _os.environ.setdefault("KMX_TEST_HOOKS", "1")   # forced code paths are test hooks
 import hashlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,6 +1,7 @@
 """Randomised configurations like tools/stress_parity.py, but every configuration is built many times under each hook
 setting and every build is compared with the CPU oracle by digest: hunts timing-dependent results.
 usage: python tools/soak_stress.py [seconds] [seed] [builds per hook setting]"""
+import os as _os; _os.environ.setdefault("KMX_TEST_HOOKS", "1")   # forced code paths are test hooks
 import hashlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

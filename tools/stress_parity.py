@@ -1,6 +1,7 @@
 """One-off randomized stress of the ordered insert against the CPU oracle: many small and mid-size configurations,
 biased to heavy contention (everything into the coupled arrays, tiny arrays), every forced code path.
 usage: python tools/stress_parity.py [seconds] [seed] [big|small]   (small: at most 30 000 k-mers, for libraries built to overflow)"""
+import os as _os; _os.environ.setdefault("KMX_TEST_HOOKS", "1")   # forced code paths are test hooks
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -9,6 +9,7 @@
     KMX_LIBRARY=kmcex_amd/libkmx_smalltab.so python tools/stress_parity.py 300            # on the GPU box
     KMX_LIBRARY=kmcex_amd/libkmx_smallcap.so KMX_BS_CAP=64 python tools/stress_parity.py 200 5 small
 """
+import os as _os; _os.environ.setdefault("KMX_TEST_HOOKS", "1")   # forced code paths are test hooks
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = os.path.join(root, "kmcex_amd/csrc")
