@@ -312,8 +312,8 @@ def main():
         Ap, Sp = st.piped_attempts, st.piped_commits                     # the part of A and S handled inside the fused commit|check launches of the big rounds
         alg = {  # algorithmic bytes of ONE step per kernel class (SURVEY.md §8d formula, split by kernel)
             "check": G * (A - Ap) * a.nh + (A - Ap) * W8,                # reads: every attempt looks at its nh positions
-            "commit": G * (S - Sp) * a.nh,                               # write-backs (km_back's 2*S*(nh-2) term is k_kmback_emit + k_bs_apply now)
-            "commit_check": G * Ap * a.nh + Ap * W8 + G * Sp * a.nh,     # one group of lists commits beside the check of the next group
+            "commit": G * max(st.fast_commits - Sp, 0) * a.nh,           # write-backs in launches of their own (km_back's 2*S*(nh-2) term is k_kmback_emit + k_bs_apply now)
+            "commit_check": G * Ap * a.nh + Ap * W8 + G * Sp * a.nh,     # the winners of round r-1 commit beside the check of round r
             "classify": G * 2 * nbf * ((a.nh - 1) + (a.nh - 2)) + n * W8,
         }
         per_q = G * (a.nb * a.nh + (a.nh - 2) + 2 + 6) + W8      # §8d: ~48 touches per query

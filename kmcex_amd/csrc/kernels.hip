@@ -146,9 +146,10 @@ template <int NHM> __device__ __forceinline__ u32 value_at_position(const ModelD
 	return v;
 }
 
-// kmodel.hpp:611-618 + :548-550: set tag (and value) bits, then the (k-2)-mer goes into km_back
+// kmodel.hpp:611-618: set tag (and value) bits.  (The (k-2)-mer of a success goes into km_back -- :548-550 -- once per block
+// or per ring round: k_kmback_emit.)
 template <int W, int NHM>
-__device__ __forceinline__ void commit_touches(const ModelDev &md, const Touches<NHM> &t, u32 bin, int a, const Aligned<W> &al)
+__device__ __forceinline__ void commit_touches(const ModelDev &md, const Touches<NHM> &t, u32 bin, int a)
 {
 	cell_t *cells = md.cells[a];
 #pragma unroll
@@ -158,10 +159,6 @@ __device__ __forceinline__ void commit_touches(const ModelDev &md, const Touches
 			if (!((t.cell[j] >> (16 + b)) & 1u))          // already tagged => already carries this value
 				atomicOr(cells + (t.pos[j] >> 4), CELL_TAG(b) | (value_at_position<NHM>(md, t.pos, ~0u, bin, j) ? CELL_VAL(b) : 0u));
 		}
-	if (md.kmb_direct) {
-		Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-		bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
-	}
 }
 
 // ------------------------------------------------------------------------------------------ pass 1
@@ -424,19 +421,43 @@ __global__ __launch_bounds__(256) void k_block_init(BlockDev bd, int nb, int pp,
 }
 
 // ------------------------------------------------------------------------------------------ A: check + emit claims
-// Claims are a partitioned stream, not atomics on the cells.  A candidate (no conflict with the committed state) emits
+// Claims are a partitioned stream, not atomics on the cells.  A candidate (no conflict with the state it saw) emits
 // one tuple (position, wanted value, list slot) per position it saw untagged.  The tuples are hash-partitioned by position
 // into KMX_CL_BINS bins per list: inside a workgroup they are counted per bin in LDS, each run is reserved with ONE global
 // atomic per (workgroup, bin), the tuples are sorted by bin in LDS and written out run by run -- LDS-staged write combining:
 // the memory system sees 8-byte stores that fill lines instead of one memory-side atomic per claimed position.
 // k_round_detect then finds, bin by bin in an LDS table, the positions wanted with both values.
+//
+// The state a check sees may be STALE by exactly one visit: the winners of the previous visit to the same array (round
+// r-1: list i+1) commit in the very launch that checks round r (k_round_commit_check: memory-side atomics and gathers side
+// by side).  That is sound because the state is monotone (kmodel.hpp:604-618 never clears a bit): a conflict seen is final,
+// and the verdict of a candidate can only be changed by tags it did not see yet -- exactly the claim tuples of those
+// winners, which k_round_detect enters into its tables as SETTLED positions before it looks at this round's claims.
+// For that the identity of a position inside a table must be exact: bin and fingerprint are the two halves of ONE
+// bijective mix of the position (37 bits: arrays of up to 2^37 positions; above that the host commits before it checks).
 #define CL_POS_BITS 44
 #define CL_TUPLE(pos, want, x) ((u64)(pos) | ((u64)(want) << CL_POS_BITS) | ((u64)(x) << (CL_POS_BITS + 1)))
 #define CL_POS(tp) ((tp) & ((1ULL << CL_POS_BITS) - 1))
 #define CL_WANT(tp) ((u32)((tp) >> CL_POS_BITS) & 1u)
 #define CL_X(tp) ((u32)((tp) >> (CL_POS_BITS + 1)) & (KMX_BUCKET - 1))
-__device__ __forceinline__ u64 cl_hash(u64 pos) { return pos * 0x9E3779B97F4A7C15ULL; }
-template <int NHM> __device__ __forceinline__ u32 cl_bin(u64 h) { return (u32)(h >> (64 - KMX_CL_BINS_LOG2(NHM))); }
+#define CL_MIX_BITS KMX_CL_MIX_BITS
+#define CL_FP_BITS (CL_MIX_BITS - 8)
+static_assert(KMX_CL_BINS_LOG2(8) == 8 && KMX_CL_BINS_LOG2(16) == 8 && CL_FP_BITS + 3 == 32, "bin (8 bits) + fingerprint (29 bits) = the mixed position; an entry = fingerprint + 3 flags");
+// multiply by an odd constant and xor-shift right are bijections on 37-bit integers: distinct positions below 2^37 get
+// distinct (bin, fingerprint) pairs
+__device__ __forceinline__ u64 cl_mix(u64 pos)
+{
+	constexpr u64 MASK = (1ULL << CL_MIX_BITS) - 1;
+	u64 m = (pos * 0x9E3779B97F4A7C15ULL) & MASK;
+	m ^= m >> 19;
+	m = (m * 0xD6E8FEB86659FD93ULL) & MASK;
+	m ^= m >> 18;
+	return m;
+}
+__device__ __forceinline__ u32 cl_bin(u64 m) { return (u32)(m >> CL_FP_BITS); }
+__device__ __forceinline__ u32 cl_fp(u64 m) { return (u32)m & ((1u << CL_FP_BITS) - 1); }
+// position & 15 <-> bit of the cell (device_common.h bit_in_cell)
+__device__ __forceinline__ u32 bit_of_nibble(u32 nib) { return 8 * ((nib >> 3) & 1) + 7 - (nib & 7); }
 
 // (bx of gx workgroups work on list i: the kernels below map their grids onto these bodies)
 // LDS of one check_emit workgroup, carved out of a byte pool the kernel owns (kernels that run one of several bodies per workgroup)
@@ -448,16 +469,17 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 	int *s_cnt = (int *)(lds + 256 * NHM * 8), *s_off = s_cnt + NBIN, *s_base = s_off + NBIN, *s_tmp = s_base + NBIN;
 	int &s_fail = s_tmp[4];
 	const int n = bd.n[pp][i];
-	const u64 row = (u64)i * KMX_BUCKET;
+	const u64 row = (u64)i * KMX_BUCKET, plane = (u64)md.nb * KMX_BUCKET;
 	const int a = (i + t) % md.nb;                                  // kmodel.hpp:563
 	if (bx == 0 && threadIdx.x == 0) {
 		if (n) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
 		if (stat_slot && n) atomicAdd(bd.stats + stat_slot, (u64)n);   // accounting: attempts examined inside fused launches
-		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, md.nb)] = 0;   // k_round_commit files this round's records
+		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, md.nb)] = 0;   // k_round_file files this round's records
 	}
 	constexpr int CAP = KMX_CL_CAP_OF(NHM);
-	u64 *tup = bd.cl_tup + (u64)i * NBIN * CAP;
-	int *gcnt = bd.cl_cnt + i * KMX_CL_MAXBINS;
+	u64 *tup = bd.cl_tup[pp] + (u64)i * NBIN * CAP;
+	int *gcnt = bd.cl_cnt[pp] + i * KMX_CL_MAXBINS;
+	unsigned char *status = bd.status[pp] + row;
 	// grid-stride over the list: later rounds are launched with fewer workgroups (lists shrink round by round)
 	for (int base = bx * 256; base < n; base += gx * 256) {
 		if (threadIdx.x == 0) s_fail = 0;
@@ -467,6 +489,7 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 		bool failed = false;
 		u32 um = 0, bin = 0;
 		int rank[NHM];
+		u32 cb[NHM];
 		Touches<NHM> tc;
 		if (x < n) {
 			const u32 raw = bd.list[pp][row + x];
@@ -478,18 +501,24 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
 			gather_touches<W, NHM, false>(md, pm, a, tc);
 			failed = touches_conflict<NHM>(md, tc, bin);
-			bd.status[row + x] = failed ? SLOT_FAILED : SLOT_UNDECIDED;
+			status[x] = failed ? SLOT_FAILED : SLOT_UNDECIDED;
 			if (!failed) {
+				u64 nib = 0;
 #pragma unroll
 				for (int j = 0; j < NHM; j++)
 					if (j < md.nh) {
 						const u32 b = bit_in_cell(tc.pos[j]);
+						nib |= (tc.pos[j] & 15) << (4 * j);
+						bd.cidx[pp][(u64)j * plane + row + x] = (u32)(tc.pos[j] >> 4);   // what the deferred commit needs: no k-mer, no hash
 						if (!((tc.cell[j] >> (16 + b)) & 1u)) {
 							um |= 1u << j;
-							rank[j] = atomicAdd(&s_cnt[cl_bin<NHM>(cl_hash(tc.pos[j]))], 1);
+							cb[j] = cl_bin(cl_mix(tc.pos[j]));
+							rank[j] = atomicAdd(&s_cnt[cb[j]], 1);
 						}
 					}
-				bd.um[row + x] = (unsigned short)um;
+				bd.um[pp][row + x] = (unsigned short)um;
+				bd.want[pp][row + x] = (unsigned short)bin;
+				bd.cnib[pp][row + x] = nib;
 			}
 		}
 		// survivors are counted per 1024-slot tile as they fail, so the reorder needs no counting pass
@@ -512,12 +541,12 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
 				if (j < md.nh && ((um >> j) & 1u))
-					s_tup[s_off[cl_bin<NHM>(cl_hash(tc.pos[j]))] + rank[j]] = CL_TUPLE(tc.pos[j], (bin >> j) & 1u, x);
+					s_tup[s_off[cb[j]] + rank[j]] = CL_TUPLE(tc.pos[j], (bin >> j) & 1u, x);
 		}
 		__syncthreads();
 		for (int q = threadIdx.x; q < total; q += 256) {               // consecutive lanes, consecutive tuples of a run
 			const u64 tp = s_tup[q];
-			const u32 b = cl_bin<NHM>(cl_hash(CL_POS(tp)));
+			const u32 b = cl_bin(cl_mix(CL_POS(tp)));
 			const int g = s_base[b] + (q - s_off[b]);
 			if (g < CAP) tup[(u64)b * CAP + g] = tp;
 			else bd.cl_ovf[i] = 1;                                     // the whole list takes the ordered path this round
@@ -525,81 +554,148 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 		__syncthreads();
 	}
 }
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_emit(ModelDev md, BlockDev bd, int t, int pp, int i0)
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_emit(ModelDev md, BlockDev bd, int t, int pp)
 {
 	__shared__ __align__(16) unsigned char lds[CHECK_LDS_BYTES(NHM)];
-	check_emit_body<W, NHM>(md, bd, t, pp, i0 + (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, lds, 0);
+	check_emit_body<W, NHM>(md, bd, t, pp, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, lds, 0);
 }
 
-// ------------------------------------------------------------------------------------------ D: opposite claims, bin by bin
-// One workgroup per (bin, list): every tuple of the bin goes into an open-addressing table in LDS keyed by a 30-bit
-// fingerprint of its position (the bin and the slot take other bits of the same hash, so two positions that share an
-// entry agree in 52 hash bits: it happens once in ~10^9 builds and only sends a k-mer down the ordered path, which is
-// exact for any superset of the truly contended k-mers).  An entry collects which values are wanted there; a second pass
-// marks every candidate that meets the opposite value on one of its positions as contended.
-template <int NHM, int BT> __global__ __launch_bounds__(BT) void k_round_detect(BlockDev bd, int i0)
+// ------------------------------------------------------------------------------------------ D: settled positions and opposite claims, bin by bin
+// One workgroup per (bin, list).  An LDS table entry = fingerprint of a position (exact within the bin, see cl_mix) + 3 flags:
+//   bit 0 / bit 1   value 0 / value 1 is wanted there by a candidate of this round
+//   bit 2           SETTLED: a winner of the previous visit to this array tagged the position after (or while) this round's
+//                   check looked at it; bits 0/1 then say with which value
+// Phase 0 (use_delta): the claim tuples of the previous round's list i+1 -- the list that visited this array -- whose slot
+//   ended the round as an uncontended winner (status 0: its commit rides with this round's check) become settled entries.
+// Phase 1: this round's tuples; a settled entry is left alone.
+// Phase 2: every tuple looks its position up: settled with the other value -> the candidate has failed after all (dfail);
+//   wanted with both values by candidates -> those candidates take the ordered path (SLOT_CONTENDED).  A settled position
+//   causes no contention: everybody who wants the other value there fails, the others are compatible with it.
+// A bin of more tuples than 3/4 of the table is taken in passes over a secondary hash of the fingerprint.
+#define DT_SETTLED 4u
+// keep_own: this round's winners will be committed beside the next round's check, whose k_round_detect reads (and resets) the bins.
+template <int NHM, int BT> __global__ __launch_bounds__(BT) void k_round_detect(BlockDev bd, int nb, int pp, int use_delta, int keep_own)
 {
 	constexpr int NBIN = KMX_CL_BINS(NHM), TBITS = KMX_CL_TBITS(NHM), T = 1 << TBITS, CAP = KMX_CL_CAP_OF(NHM);
-	static_assert(T > CAP, "the table of a bin must take every tuple of a full bin");
 	__shared__ u32 s_t[T];
-	const int i = i0 + (int)blockIdx.y, b = blockIdx.x;
-	int *gc = bd.cl_cnt + i * KMX_CL_MAXBINS + b;
-	int cnt = *gc;
-	if (cnt == 0) return;                                            // uniform: nothing was emitted into this bin
+	__shared__ int s_sub[64];
+	__shared__ int s_full;
+	const int i = (int)blockIdx.y, b = blockIdx.x;
+	const int id = (i + 1) % nb;                                     // list that visited this array one round earlier
+	int *gc = bd.cl_cnt[pp] + i * KMX_CL_MAXBINS + b;
+	int *gd = bd.cl_cnt[pp ^ 1] + id * KMX_CL_MAXBINS + b;
+	int cnt = *gc, dcnt = *gd;
 	if (cnt > CAP) cnt = CAP;                                        // check_emit has raised cl_ovf[i]
-	int tb = 10;
-	while ((1 << tb) < 4 * cnt && tb < TBITS) tb++;                  // load <= 1/4 (<= 3/4 for a full bin): short probe chains
-	const u32 tmask = (1u << tb) - 1;
-	for (int q = threadIdx.x; q < (1 << tb); q += BT) s_t[q] = 0;
-	__syncthreads();
-	const u64 *tp = bd.cl_tup + ((u64)i * NBIN + b) * CAP;
-	const u64 row = (u64)i * KMX_BUCKET;
-	constexpr int U = 8;                                             // tuples per thread in flight: the loads of a batch are issued together
-	auto insert = [&](u64 e) {
-		const u64 h = cl_hash(CL_POS(e));
-		const u32 fp = (u32)(h >> 11) & 0x3FFFFFFFu, w = 1u << CL_WANT(e);
-		u32 slot = (u32)(h >> 41) & tmask;
-		for (;;) {                                                   // a free slot always exists: 2^TBITS > capacity
-			const u32 old = atomicCAS(&s_t[slot], 0u, (fp << 2) | w);
-			if (old == 0) break;
-			if ((old >> 2) == fp) { if (!(old & w)) atomicOr(&s_t[slot], w); break; }
-			slot = (slot + 1) & tmask;
-		}
-	};
-	auto lookup = [&](u64 e) {
-		const u64 h = cl_hash(CL_POS(e));
-		const u32 fp = (u32)(h >> 11) & 0x3FFFFFFFu;
-		u32 slot = (u32)(h >> 41) & tmask, cur;
-		while (((cur = s_t[slot]) >> 2) != fp) slot = (slot + 1) & tmask;
-		if (cur & (2u >> CL_WANT(e))) bd.status[row + CL_X(e)] = SLOT_CONTENDED;   // the other value is wanted there too
-	};
-	if (cnt <= U * BT) {                                             // the usual case: the bin's tuples stay in registers between the passes
-		u64 e[U];
-#pragma unroll
-		for (int u = 0; u < U; u++) { const int q = u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
-#pragma unroll
-		for (int u = 0; u < U; u++) if (e[u] != ~0ULL) insert(e[u]);
-		__syncthreads();
-#pragma unroll
-		for (int u = 0; u < U; u++) if (e[u] != ~0ULL) lookup(e[u]);
-	} else {
-		for (int q0 = 0; q0 < cnt; q0 += U * BT) {
-			u64 e[U];
-#pragma unroll
-			for (int u = 0; u < U; u++) { const int q = q0 + u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
-#pragma unroll
-			for (int u = 0; u < U; u++) if (e[u] != ~0ULL) insert(e[u]);
-		}
-		__syncthreads();
-		for (int q0 = 0; q0 < cnt; q0 += U * BT) {
-			u64 e[U];
-#pragma unroll
-			for (int u = 0; u < U; u++) { const int q = q0 + u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
-#pragma unroll
-			for (int u = 0; u < U; u++) if (e[u] != ~0ULL) lookup(e[u]);
+	if (dcnt > CAP) dcnt = CAP;                                      // (that list had no uncontended winner then: nothing of it passes the filter)
+	__syncthreads();                                                 // every thread has read the counters
+	if (threadIdx.x == 0) {
+		*gd = 0;                                                     // last reader of the previous round's bin: ready for round r+1
+		if (!keep_own) *gc = 0;                                      // nobody will read this round's tuples again
+	}
+	if (!use_delta) dcnt = 0;
+	if (cnt == 0) return;                                            // uniform: no candidate claimed a position of this bin
+	const u64 *tp = bd.cl_tup[pp] + ((u64)i * NBIN + b) * CAP;
+	const u64 *dp = bd.cl_tup[pp ^ 1] + ((u64)id * NBIN + b) * CAP;
+	const unsigned char *dstatus = bd.status[pp ^ 1] + (u64)id * KMX_BUCKET;
+	unsigned char *status = bd.status[pp] + (u64)i * KMX_BUCKET, *dfail = bd.dfail + (u64)i * KMX_BUCKET;
+	// passes: P = 1 unless the bin holds more than 3/4 of the table
+	int P = 1;
+	if (cnt + dcnt > T * 3 / 4) {
+		for (P = 2; P < 64; P <<= 1) {                               // uniform: counts come from LDS after barriers
+			if (threadIdx.x < 64) s_sub[threadIdx.x] = 0;
+			__syncthreads();
+			for (int q = threadIdx.x; q < cnt + dcnt; q += BT) {
+				const u64 e = q < cnt ? tp[q] : dp[q - cnt];
+				atomicAdd(&s_sub[(cl_fp(cl_mix(CL_POS(e))) * 0x85EBCA6Bu) >> 26 & (P - 1)], 1);
+			}
+			__syncthreads();
+			int mx = 0;
+			for (int q = 0; q < P; q++) mx = max(mx, s_sub[q]);
+			__syncthreads();
+			if (mx <= T * 3 / 4) break;
 		}
 	}
-	if (threadIdx.x == 0) *gc = 0;                                   // (every thread has read it) ready for the next round
+	if (threadIdx.x == 0) s_full = 0;
+	for (int pass = 0; pass < P; pass++) {
+		const int load = P == 1 ? cnt + dcnt : T * 3 / 4;
+		int tb = 10;
+		while ((1 << tb) < 4 * load && tb < TBITS) tb++;             // load <= 1/4 in the usual case: short probe chains
+		const u32 tmask = (1u << tb) - 1;
+		for (int q = threadIdx.x; q < (1 << tb); q += BT) s_t[q] = 0;
+		__syncthreads();
+		auto mine = [&](u32 fp) { return P == 1 || (int)((fp * 0x85EBCA6Bu) >> 26 & (u32)(P - 1)) == pass; };
+		auto home = [&](u32 fp) { return ((fp * 0x9E3779B1u) >> (32 - TBITS)) & tmask; };
+		// find the entry of fp or the free slot it should take (bounded: a table can only fill up if the passes above failed)
+		auto insert = [&](u32 fp, u32 flags, bool settled) {
+			u32 slot = home(fp);
+			for (int probes = 0; probes <= (int)tmask; probes++) {
+				const u32 old = atomicCAS(&s_t[slot], 0u, (fp << 3) | flags);
+				if (old == 0) return;
+				if ((old >> 3) == fp) {
+					if (settled) atomicOr(&s_t[slot], flags);          // (two winners on one position want the same value)
+					else if (!(old & DT_SETTLED) && (old & flags) != flags) {
+						// not settled when read; if a settled insert raced us the flag we add is one of its own value bits or is
+						// ignored by the lookup (phase 0 is over before phase 1 starts: barrier below)
+						atomicOr(&s_t[slot], flags);
+					}
+					return;
+				}
+				slot = (slot + 1) & tmask;
+			}
+			s_full = 1;
+		};
+		// phase 0: settled positions
+		for (int q = threadIdx.x; q < dcnt; q += BT) {
+			const u64 e = dp[q];
+			const u32 fp = cl_fp(cl_mix(CL_POS(e)));
+			if (mine(fp) && dstatus[CL_X(e)] == SLOT_UNDECIDED) insert(fp, DT_SETTLED | (1u << CL_WANT(e)), true);
+		}
+		__syncthreads();
+		// phase 1 + 2: this round's claims
+		constexpr int U = 8;                                         // tuples per thread in flight: the loads of a batch are issued together
+		auto lookup = [&](u64 e, u32 fp) {
+			u32 slot = home(fp), cur = 0;
+			for (int probes = 0; probes <= (int)tmask; probes++) {
+				cur = s_t[slot];
+				if ((cur >> 3) == fp || cur == 0) break;
+				slot = (slot + 1) & tmask;
+			}
+			if ((cur >> 3) != fp) return;                            // (table full: reported below)
+			const u32 w = CL_WANT(e);
+			if (cur & DT_SETTLED) { if (!((cur >> w) & 1u)) dfail[CL_X(e)] = 1; }          // tagged meanwhile with the other value
+			else if ((cur >> (w ^ 1u)) & 1u) status[CL_X(e)] = SLOT_CONTENDED;             // the other value is wanted there too
+		};
+		if (cnt <= U * BT) {                                         // the usual case: the bin's tuples stay in registers between the phases
+			u64 e[U];
+			u32 fp[U];
+#pragma unroll
+			for (int u = 0; u < U; u++) { const int q = u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
+#pragma unroll
+			for (int u = 0; u < U; u++) {
+				if (e[u] == ~0ULL) continue;
+				fp[u] = cl_fp(cl_mix(CL_POS(e[u])));
+				if (!mine(fp[u])) { e[u] = ~0ULL; continue; }
+				insert(fp[u], 1u << CL_WANT(e[u]), false);
+			}
+			__syncthreads();
+#pragma unroll
+			for (int u = 0; u < U; u++) if (e[u] != ~0ULL) lookup(e[u], fp[u]);
+		} else {
+			for (int q = threadIdx.x; q < cnt; q += BT) {
+				const u64 e = tp[q];
+				const u32 fp = cl_fp(cl_mix(CL_POS(e)));
+				if (mine(fp)) insert(fp, 1u << CL_WANT(e), false);
+			}
+			__syncthreads();
+			for (int q = threadIdx.x; q < cnt; q += BT) {
+				const u64 e = tp[q];
+				const u32 fp = cl_fp(cl_mix(CL_POS(e)));
+				if (mine(fp)) lookup(e, fp);
+			}
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0 && s_full) atomicAdd(bd.stats + ST_TABLE_FULL, 1ULL);
 }
 
 // ------------------------------------------------------------------------------------------ S: ordered slow path (helpers)
@@ -607,7 +703,7 @@ __device__ __forceinline__ u64 resv_key(u64 epoch, u32 x) { return (epoch << 20)
 __device__ __forceinline__ u64 *resv_slot(const BlockDev &bd, int i, u64 pos) { return bd.R + (u64)i * KMX_RSIZE + (pos & (KMX_RSIZE - 1)); }
 __device__ __forceinline__ void mark_failed(const BlockDev &bd, int pp, int i, u64 row, u32 x)
 {
-	bd.status[row + x] = SLOT_FAILED;
+	bd.status[pp][row + x] = SLOT_FAILED;
 	atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (x >> 10), 1);      // contended k-mers only: rare
 }
 template <int NHM> __device__ __forceinline__ void reserve_untagged(const ModelDev &md, const BlockDev &bd, int i, const Touches<NHM> &tc, u64 key)
@@ -658,88 +754,124 @@ template <int W> __device__ __forceinline__ u32 rec_load(const u64 *rec, u64 slo
 	return (u32)(h >> 48);
 }
 
-// ------------------------------------------------------------------------------------------ B: commit
-// Candidates that k_round_detect left alone cannot interact with any other candidate of the list (no position of theirs
-// is wanted with the other value), so they commit in parallel: one atomic OR per position they saw untagged (tag + value
-// in one word, kmodel.hpp:611-618) and the km_back insert (:548-550) -- no second look at the cells.  Contended ones file
-// a record in U[0] (with the untagged mask of the check) and place their reservations right away (epoch `epoch`), which
-// saves the first reserve pass of the ordered slow path.
-template <int W, int NHM> __device__ __forceinline__ void commit_body(const ModelDev &md, const BlockDev &bd, int t, int pp, u64 epoch, int i, int bx, int gx, unsigned char *lds)
+// ------------------------------------------------------------------------------------------ F: file the contended candidates
+// After k_round_detect every slot of the round has its verdict spread over two bytes: status (undecided / failed /
+// contended) and dfail.  A dfail slot becomes a failure (counted for the reorder like the ones check_emit found); a contended
+// one -- every candidate of a list whose claims overflowed a bin -- files a record in U[0] (slot, bin, packed k-mer, untagged
+// mask of the check) and places its priority reservations (epoch `epoch`), which saves the first reserve pass of the
+// ordered slow path.  What stays SLOT_UNDECIDED is a winner: nobody wants the other value on any of its positions.
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_file(ModelDev md, BlockDev bd, int pp, u64 epoch)
 {
-	int &s_cnt = ((int *)lds)[0], &s_base = ((int *)lds)[1];
+	__shared__ int s_cnt, s_base, s_fail, s_df;
+	const int i = blockIdx.y, bx = blockIdx.x, gx = gridDim.x;
 	const int n = bd.n[pp][i];
-	const u64 row = (u64)i * KMX_BUCKET;
-	const int a = (i + t) % md.nb;
-	const int sbase = a * md.nh;
-	cell_t *cells = md.cells[a];
+	const u64 row = (u64)i * KMX_BUCKET, plane = (u64)md.nb * KMX_BUCKET;
 	const bool all_contended = bd.cl_ovf[i] != 0;
+	unsigned char *status = bd.status[pp] + row;
+	if (threadIdx.x == 0) s_df = 0;
 	for (int base = bx * 256; base < n; base += gx * 256) {
-		if (threadIdx.x == 0) s_cnt = 0;
+		if (threadIdx.x == 0) { s_cnt = 0; s_fail = 0; }
 		__syncthreads();
 		const int x = base + threadIdx.x;
-		const int st = x < n ? (int)bd.status[row + x] : (int)SLOT_FAILED;
-		const bool active = st == SLOT_UNDECIDED || st == SLOT_CONTENDED;
-		const bool contended = active && (st == SLOT_CONTENDED || all_contended);
+		int st = x < n ? (int)status[x] : (int)SLOT_FAILED;
+		bool newly_failed = false;
+		if (st != SLOT_FAILED && bd.dfail[row + x]) {               // (only candidates emit claims, so only they can be flagged)
+			bd.dfail[row + x] = 0;
+			status[x] = SLOT_FAILED;
+			st = SLOT_FAILED;
+			newly_failed = true;
+		}
+		const bool contended = st == SLOT_CONTENDED || (st == SLOT_UNDECIDED && all_contended);
 		u64 v[W];
 		u32 bin = 0, um = 0;
-		if (active) {
+		if (contended) {
 			const u32 idx = bd.list[pp][row + x];
 			load_kmer<W>(bd.kmers, row + idx, v);
-			bin = md.bin_of_occ[bd.counts[row + idx]];
-			um = bd.um[row + x];
-			Aligned<W> al = left_align<W>(v, md.k);
-			Premixed<W> pm = premix_string<W>(al, md.gfull);
+			bin = bd.want[pp][row + x];
+			um = bd.um[pp][row + x];
+			const u64 nib = bd.cnib[pp][row + x];
 			const u64 key = resv_key(epoch, (u32)x);
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
 				if (j < md.nh && ((um >> j) & 1u)) {
-					const u64 pos = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(sbase + j) & 127]), md.km_mod);
-					if (contended) atomicMax(resv_slot(bd, i, pos), key);
-					else {
-						const u32 b = bit_in_cell(pos);
-						atomicOr(cells + (pos >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0u));
-					}
+					const u64 pos = ((u64)bd.cidx[pp][(u64)j * plane + row + x] << 4) | ((nib >> (4 * j)) & 15);
+					atomicMax(resv_slot(bd, i, pos), key);
 				}
-			if (!contended) {
-				if (md.kmb_direct) {
-					Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-					bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
-				}
-				bd.status[row + x] = SLOT_INSERTED;
-			} else bd.status[row + x] = SLOT_UNDECIDED;              // the ordered path decides it
+			status[x] = SLOT_UNDECIDED;                                // the ordered path decides it
 		}
+		const u64 fm = __ballot(newly_failed);
+		if ((threadIdx.x & 63) == 0 && fm) atomicAdd(&s_fail, (int)__popcll(fm));
 		const int p = block_append_slot(bd.Un + UN_IDX(0, i, md.nb), contended, &s_cnt, &s_base);
 		if (contended) rec_store<W>(bd.Urec[0], row + p, (u32)x, bin, v, um);
+		if (threadIdx.x == 0 && s_fail) { atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (base >> 10), s_fail); s_df += s_fail; }
 		__syncthreads();
 	}
-}
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit(ModelDev md, BlockDev bd, int t, int pp, u64 epoch, int i0)
-{
-	__shared__ __align__(16) unsigned char lds[16];
-	commit_body<W, NHM>(md, bd, t, pp, epoch, i0 + (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, lds);
+	if (threadIdx.x == 0 && s_df) atomicAdd(bd.stats + ST_DELTA_FAILS, (u64)s_df);
 }
 
-// ------------------------------------------------------------------------------------------ B|A: commit of one list beside the check of the next
-// The lists of a round work on different arrays, so list i can commit while list i+1 is examined.  The check is bound by
-// random 4-byte gathers, the commit by memory-side atomics; side by side the two take ~3/4 of what they take one after
-// the other (tools/microbench_pair.py), so the big rounds run as a software pipeline over the lists:
-//   check(G0) detect(G0) [commit(G0)|check(G1)] detect(G1) ... commit(G_last)          G = a group of lists
-// One list is a single residency wave of workgroups on this chip, so a per-list pipeline is latency-bound and loses
-// (84.0 ms against 77.9 for whole-round kernels); two groups, the bigger first, is the split that pays (76.1-76.6 ms):
-// gathers ride almost free beside atomics, not the other way round.  The layout of the two kinds over the grid matters:
-// all of one kind first gains nothing; even/odd workgroups within a list row (so that the third committing list ran
-// last, alone) 17.3 ms per build in these launches; every list of both kinds advancing at the same pace 15.8 ms.
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit_check(ModelDev md, BlockDev bd, int t, int pp, u64 epoch, int i_commit, int n_commit, int i_check, int n_check)
+// ------------------------------------------------------------------------------------------ B: commit
+// The winners k_round_file left undecided cannot interact with any other candidate of their list (no position of theirs
+// is wanted with the other value), so they commit in parallel: one atomic OR per position they saw untagged (tag + value
+// in one word, kmodel.hpp:611-618) -- straight from what check_emit stored per slot (cell indices, low position bits,
+// wanted values): no k-mer, no hash, no second look at the cells.  Deferred by one round: the commit of round r rides with
+// the check of round r+1 (k_round_commit_check), whose detect treats these positions as settled.
+// (a = the array list i visited in the round being committed; pp = that round's parity)
+template <int NHM> __device__ __forceinline__ void commit_body(const ModelDev &md, const BlockDev &bd, int a, int pp, int i, int bx, int gx, unsigned char *lds, int stat_slot)
+{
+	int &s_cnt = ((int *)lds)[0];
+	const int n = bd.n[pp][i];
+	const u64 row = (u64)i * KMX_BUCKET, plane = (u64)md.nb * KMX_BUCKET;
+	cell_t *cells = md.cells[a];
+	const unsigned char *status = bd.status[pp] + row;
+	if (stat_slot && threadIdx.x == 0) s_cnt = 0;
+	if (stat_slot) __syncthreads();
+	for (int base = bx * 256; base < n; base += gx * 256) {
+		const int x = base + threadIdx.x;
+		const bool win = x < n && status[x] == SLOT_UNDECIDED;
+		if (win) {
+			const u32 um = bd.um[pp][row + x], want = bd.want[pp][row + x];
+			const u64 nib = bd.cnib[pp][row + x];
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((um >> j) & 1u)) {
+					const u32 b = bit_of_nibble((u32)(nib >> (4 * j)) & 15u);
+					atomicOr(cells + bd.cidx[pp][(u64)j * plane + row + x], CELL_TAG(b) | (((want >> j) & 1u) ? CELL_VAL(b) : 0u));
+				}
+		}
+		if (stat_slot) {
+			const u64 wm = __ballot(win);
+			if ((threadIdx.x & 63) == 0 && wm) atomicAdd(&s_cnt, (int)__popcll(wm));
+		}
+	}
+	if (stat_slot) {
+		__syncthreads();
+		if (threadIdx.x == 0 && s_cnt) atomicAdd(bd.stats + stat_slot, (u64)s_cnt);
+	}
+}
+// commit of the round with parity pp, whose list i visited array (i + t) % nb
+template <int NHM> __global__ __launch_bounds__(256) void k_round_commit(ModelDev md, BlockDev bd, int t, int pp)
+{
+	__shared__ __align__(16) unsigned char lds[16];
+	commit_body<NHM>(md, bd, ((int)blockIdx.y + t) % md.nb, pp, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, lds, 0);
+}
+
+// ------------------------------------------------------------------------------------------ B|A: the commit of round r-1 beside the check of round r
+// The check is bound by random 4-byte gathers, the commit by memory-side atomics; side by side the two take ~3/4 of what
+// they take one after the other (tools/microbench_pair.py: 4.8 ms + 9.9 ms alone, 10.9 ms together).  Round 2 overlapped
+// two groups of lists inside a round; now the whole previous round commits under the whole check: list i is examined on array
+// (i + t) % nb while list i + 1 commits on that very array -- what the check misses of it, k_round_detect supplies.
+// t: the round being checked (parity pp); the round being committed is the one before it (parity pp ^ 1; across a block
+// boundary: the last round of the previous block), whose list i visited array (i + t + nb - 1) % nb.
+// Consecutive workgroups alternate between the two kinds and cycle through the lists, so every list advances at the same
+// pace, both kinds are resident on every CU from the first wave of workgroups to the last, and the launch does not end on a
+// tail of atomics.
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit_check(ModelDev md, BlockDev bd, int t, int pp)
 {
 	__shared__ __align__(16) unsigned char lds[CHECK_LDS_BYTES(NHM)];
-	// consecutive workgroups cycle through the lists of both kinds (commit, check, commit, check, ..., then what is left of
-	// the larger group), so every list advances at the same pace and the launch ends on a mix, not on a tail of atomics
-	const int per = n_commit + n_check, gx = (int)gridDim.x / per;
-	const int r = (int)blockIdx.x % per, bx = (int)blockIdx.x / per, k = n_commit < n_check ? n_commit : n_check;
-	const bool checks = r < 2 * k ? (r & 1) : (n_check > n_commit);
-	const int l = r < 2 * k ? (r >> 1) : (r - k);
-	if (checks) check_emit_body<W, NHM>(md, bd, t, pp, i_check + l, bx, gx, lds, ST_PIPE_ATTEMPTS);
-	else commit_body<W, NHM>(md, bd, t, pp, epoch, i_commit + l, bx, gx, lds);
+	const int nb = md.nb, per = 2 * nb, gx = (int)gridDim.x / per;
+	const int r = (int)blockIdx.x % per, bx = (int)blockIdx.x / per, l = r >> 1;
+	if (r & 1) check_emit_body<W, NHM>(md, bd, t, pp, l, bx, gx, lds, ST_PIPE_ATTEMPTS);
+	else commit_body<NHM>(md, bd, (l + t + nb - 1) % nb, pp ^ 1, l, bx, gx, lds, ST_PIPE_SUCC);
 }
 
 // ------------------------------------------------------------------------------------------ S: ordered slow path
@@ -764,8 +896,8 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_reserve(
 	}
 }
 
-// resolve pass of level s: winners commit, the rest move to level s+1.  Level 0 holds k_round_commit's reservations.
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch)
+// resolve pass of level s: winners commit, the rest move to level s+1.  Level 0 holds k_round_file's reservations.
+template <int W, int NHM> __device__ __forceinline__ void slow_resolve_body(const ModelDev &md, const BlockDev &bd, int t, int pp, int s, u64 epoch)
 {
 	__shared__ int s_cnt, s_base, s_succ;
 	const int i = blockIdx.y, lv = s & 1;
@@ -785,15 +917,15 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve(
 		u64 v[W];
 		if (u < cnt) {
 			rec_load<W>(bd.Urec[lv], row + u, x, bin, v);
-			if (bd.status[row + x] == SLOT_UNDECIDED) {
+			if (bd.status[pp][row + x] == SLOT_UNDECIDED) {
 				Aligned<W> al = left_align<W>(v, md.k);
 				Premixed<W> pm = premix_string<W>(al, md.gfull);
 				Touches<NHM> tc;
 				gather_touches<W, NHM, false>(md, pm, a, tc);
 				mine = owns_outcome<NHM, false>(md, bd, i, tc, bin, resv_key(epoch, x));
 				if (mine) {
-					commit_touches<W, NHM>(md, tc, bin, a, al);
-					bd.status[row + x] = SLOT_INSERTED;
+					commit_touches<W, NHM>(md, tc, bin, a);
+					bd.status[pp][row + x] = SLOT_INSERTED;
 				}
 				defer = !mine;
 			}
@@ -807,6 +939,16 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve(
 	__syncthreads();
 	if (threadIdx.x == 0 && s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)s_succ);
 }
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch)
+{
+	slow_resolve_body<W, NHM>(md, bd, t, pp, s, epoch);
+}
+
+// The untagged mask of the check is a sound basis for the ordered path as long as every claim of the list went through
+// k_round_detect: a position in it is still untagged, or was tagged since by a still-uncommitted winner of the previous
+// visit with the value this k-mer wants (anything else made it a dfail).  A list whose claims overflowed a bin lost tuples,
+// so its masks are unchecked against those winners: it takes the gathering forms (the commits are visible by then).
+__device__ __forceinline__ bool snapshot_ok(const BlockDev &bd, int i) { return bd.cl_ovf[i] == 0; }
 
 // resolve pass of level 0 without a gather: the untagged mask check_emit left in the record is still right for
 // this purpose (see finish_lds), so a k-mer that holds the reservation of every position in it commits, and one that
@@ -815,6 +957,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0
 {
 	__shared__ int s_cnt, s_base, s_succ;
 	const int i = blockIdx.y;
+	if (!snapshot_ok(bd, i)) { slow_resolve_body<W, NHM>(md, bd, t, pp, 0, epoch); return; }
 	const int cnt = bd.Un[UN_IDX(0, i, md.nb)];
 	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;
@@ -854,11 +997,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0
 						const u32 b = bit_in_cell(pos[j]);
 						atomicOr(cells + (pos[j] >> 4), CELL_TAG(b) | (value_at_position<NHM>(md, pos, um, bin, j) ? CELL_VAL(b) : 0u));
 					}
-				if (md.kmb_direct) {
-					Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-					bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
-				}
-				bd.status[row + x] = SLOT_INSERTED;
+				bd.status[pp][row + x] = SLOT_INSERTED;
 			}
 			defer = !mine;
 		}
@@ -1067,7 +1206,7 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 							atomicOr(cells + cidx[r][j], CELL_TAG(b) | (((bin[r] >> j) & 1u) ? CELL_VAL(b) : 0u));
 						}
 				}
-				bd.status[row + x[r]] = SLOT_INSERTED;
+				bd.status[pp][row + x[r]] = SLOT_INSERTED;
 				live[r] = false;
 				won[r] = true;
 				succ++;
@@ -1114,17 +1253,7 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 #undef FIN_Q
 #pragma unroll
 	for (int r = 0; r < RPT; r++)
-		if (won[r]) {
-			u64 *hdr = bd.Urec[lv] + (row + rec[r]) * (1 + W);
-			if (defer) *hdr |= REC_WON;                                // k_reorder applies it
-			else if (md.kmb_direct) {                                  // kmodel.hpp:548-550
-				u32 x_, bin_;
-				u64 v[W];
-				rec_load<W>(bd.Urec[lv], row + rec[r], x_, bin_, v);
-				Premixed<W> pb = premix_string<W>(drop_first_base<W>(left_align<W>(v, md.k)), md.gback);
-				bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
-			}
-		}
+		if (won[r] && defer) bd.Urec[lv][(row + rec[r]) * (1 + W)] |= REC_WON;   // k_reorder applies it
 	if (!defer) drain_vmem();                                        // the next range gathers what this one committed
 	if (succ) atomicAdd(s_succ, succ);
 	return iters + 1;
@@ -1200,7 +1329,7 @@ __device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev
 				u32 x, bin;
 				u64 v[W];
 				rec_load<W>(bd.Urec[lv], row + u, x, bin, v);
-				if (bd.status[row + x] != SLOT_UNDECIDED) continue;
+				if (bd.status[pp][row + x] != SLOT_UNDECIDED) continue;
 				Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
 				Touches<NHM> tc;
 				gather_touches<W, NHM, true>(md, pm, a, tc);
@@ -1219,7 +1348,7 @@ __device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev
 			u32 x, bin;
 			u64 v[W];
 			const u32 um = rec_load<W>(bd.Urec[lv], row + u, x, bin, v);
-			if (bd.status[row + x] != SLOT_UNDECIDED) continue;
+			if (bd.status[pp][row + x] != SLOT_UNDECIDED) continue;
 			Aligned<W> al = left_align<W>(v, md.k);
 			Premixed<W> pm = premix_string<W>(al, md.gfull);
 			if (first) {
@@ -1246,11 +1375,7 @@ __device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev
 							const u32 b = bit_in_cell(pos[j]);
 							atomicOr(cells + (pos[j] >> 4), CELL_TAG(b) | (value_at_position<NHM>(md, pos, um, bin, j) ? CELL_VAL(b) : 0u));
 						}
-					if (md.kmb_direct) {
-						Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-						bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
-					}
-					bd.status[row + x] = SLOT_INSERTED;
+					bd.status[pp][row + x] = SLOT_INSERTED;
 					succ++;
 				}
 				continue;
@@ -1258,8 +1383,8 @@ __device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev
 			Touches<NHM> tc;
 			gather_touches<W, NHM, true>(md, pm, a, tc);
 			if (owns_outcome<NHM, true>(md, bd, i, tc, bin, resv_key(epoch, x))) {
-				commit_touches<W, NHM>(md, tc, bin, a, al);
-				bd.status[row + x] = SLOT_INSERTED;
+				commit_touches<W, NHM>(md, tc, bin, a);
+				bd.status[pp][row + x] = SLOT_INSERTED;
 				succ++;
 			}
 		}
@@ -1307,8 +1432,9 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 		if (s == 0) { atomicAdd(bd.stats + ST_CONTENDED, (u64)n); atomicMax(bd.stats + ST_MAX_U0, (u64)n); }
 	}
 	__syncthreads();
-	if (lds_path) finish_lds_ranges<W, NHM, RPT>(md, bd, pp, i, a, lv, n, s == 0, s_t1, s_t2, s_list, &s_count, s_pending, &s_succ);
-	else finish_global<W, NHM>(md, bd, pp, i, a, lv, n, s == 0, epoch_b, epoch0, s_pending, &s_succ);
+	const bool snap = s == 0 && snapshot_ok(bd, i);
+	if (lds_path) finish_lds_ranges<W, NHM, RPT>(md, bd, pp, i, a, lv, n, snap, s_t1, s_t2, s_list, &s_count, s_pending, &s_succ);
+	else finish_global<W, NHM>(md, bd, pp, i, a, lv, n, snap, epoch_b, epoch0, s_pending, &s_succ);
 }
 
 // ------------------------------------------------------------------------------------------ R: reorder
@@ -1319,7 +1445,7 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 // Also closes the round's books: successes = n - m.
 // Before that, it applies what the finisher decided but left undone (REC_WON records of level lv): tag/value bits
 // (kmodel.hpp:611-618, every position: an already tagged one carries the same value) and the km_back insert (:548-550).
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(ModelDev md, BlockDev bd, int t, int pp, int lv, int piped_commits)
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(ModelDev md, BlockDev bd, int t, int pp, int lv)
 {
 	__shared__ int s_tmp[4];
 	__shared__ int s_m, s_off;
@@ -1346,10 +1472,6 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 						const u32 b = bit_in_cell(pos);
 						atomicOr(cells + (pos >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0u));
 					}
-				if (md.kmb_direct) {
-					Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-					bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
-				}
 			}
 		}
 		return;
@@ -1367,7 +1489,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 #pragma unroll
 	for (int q = 0; q < 4; q++) {
 		int x = tile * KMX_TILE + threadIdx.x * 4 + q;
-		f[q] = (x < n && bd.status[row + x] == SLOT_FAILED) ? 1 : 0;
+		f[q] = (x < n && bd.status[pp][row + x] == SLOT_FAILED) ? 1 : 0;
 		c += f[q];
 	}
 	int before = block_excl_scan_256(c, s_tmp, nullptr) + s_off;
@@ -1387,7 +1509,6 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 	if (tile == 0 && threadIdx.x == 0) {
 		bd.cl_ovf[i] = 0;
 		if (n > m) atomicAdd(bd.stats + ST_SUCCESSES, (u64)(n - m));
-		if (n > m && i < piped_commits) atomicAdd(bd.stats + ST_PIPE_SUCC, (u64)(n - m));
 		bd.n[pp ^ 1][i] = m;                                       // (the record counters are reset by the next check_emit)
 	}
 }
@@ -1527,11 +1648,15 @@ __device__ __forceinline__ void kmback_emit_body(const ModelDev &md, const Block
 #pragma unroll
 		for (int q = 0; q < KPT; q++) {
 			const int x = base + q * BT + (int)threadIdx.x;
-			if (x < n && (whole ? !surv[row + x] : bd.status[row + x] == SLOT_INSERTED)) {
+			if (x < n && (whole ? !surv[row + x] : bd.status[pp][row + x] != SLOT_FAILED)) {
 				const u32 idx = whole ? (u32)x : bd.list[pp][row + x];
 				u64 km[W];
 				load_kmer<W>(kmers, row + idx, km);
 				Premixed<W> pb = premix_string<W>(drop_first_base<W>(left_align<W>(km, md.k)), md.gback);
+				if (md.kmb_direct) {                                     // filter too small or too big for the partitioned bit-set: test + atomic OR per bit
+					bloom_insert_pm<W>(pb, md.gback, md.km_back, md.km_back_mod, md.nh - 2);
+					continue;
+				}
 #pragma unroll
 				for (int j = 0; j < NHM - 2; j++)
 					if (j < md.nh - 2) {
@@ -1541,7 +1666,7 @@ __device__ __forceinline__ void kmback_emit_body(const ModelDev &md, const Block
 					}
 			}
 		}
-		bs_block_emit<K, BT>(bs, v, valid, s_bs_cnt, s_bs_off, s_bs_base, s_bs_tmp, s_bs_stage);
+		if (!md.kmb_direct) bs_block_emit<K, BT>(bs, v, valid, s_bs_cnt, s_bs_off, s_bs_base, s_bs_tmp, s_bs_stage);   // (uniform)
 	}
 }
 template <int W, int NHM, int KPT> __global__ __launch_bounds__(256) void k_kmback_emit(ModelDev md, BlockDev bd, const u64 *kmers, const unsigned char *surv, int i0, int pp, int n_in_block, BitScatter bs)
@@ -2278,54 +2403,40 @@ void block_init(const BlockDev &bd, int nb, int pp, int n_in_block, hipStream_t 
 	hipLaunchKernelGGL(k_block_init, dim3(KMX_BUCKET / 256, nb), dim3(256), 0, st, bd, nb, pp, n_in_block);
 }
 
-// one round t of one block: A, B, `nsub` grid-wide ordered sub-rounds, finisher, reorder.  `epoch` advances.
-// The single-workgroup finisher decides whatever the sub-rounds leave (everything when nsub == 0), so nsub only
-// trades launches for finisher iterations; the host picks it from the contention it has observed so far.
+// lists shrink by roughly half per round; the kernels are grid-stride, so a smaller grid is only a speed choice
+static inline int round_gx(int t) { return (int)(KMX_BUCKET / 256) >> (t < 4 ? t : 4); }
+
+// One round t (list parity pp) of one block: A check (+ the commit of the previous round beside it when
+// KMX_ROUND_PENDING: its winners are still uncommitted), D detect, F file, `nsub` grid-wide ordered sub-rounds, finisher,
+// reorder.  `epoch` advances.  The winners of THIS round stay uncommitted: the caller passes KMX_ROUND_PENDING to the next
+// round, or calls commit_flush.  The single-workgroup finisher decides whatever the sub-rounds leave (everything when
+// nsub == 0), so nsub only trades launches for finisher iterations; the host picks it from the contention it has observed.
+// t_prev: the round index of the pending commit (t - 1, or nb - 1 of the previous block).
 void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 *epoch, int flags, hipStream_t st, KernelProf *prof, const KmbackJob *job, const BitScatter *kmb)
 {
 	const int nb = md.nb;
 	if (nsub < 0) nsub = 0;
 	if (nsub > KMX_MAX_NSUB) nsub = KMX_MAX_NSUB;
-	// lists shrink by roughly half per round; the kernels are grid-stride, so a smaller grid is only a speed choice
-	const int gx = (KMX_BUCKET / 256) >> (t < 4 ? t : 4);
+	const int gx = round_gx(t);
 	const dim3 grid(gx, nb), blk(256), sgrid(SLOW_BLOCKS, nb);
-	const u64 eb = (*epoch)++;                                 // k_round_commit's reservations
-	auto detect = [&](int i0, int n_lists) {
-		KPROF_BEGIN(prof, KC_DETECT, st);
-		if (md.nh <= 8) hipLaunchKernelGGL((k_round_detect<8, 1024>), dim3(KMX_CL_BINS(8), n_lists), dim3(1024), 0, st, bd, i0);   // (256 threads for the late rounds' few
-		else hipLaunchKernelGGL((k_round_detect<16, 1024>), dim3(KMX_CL_BINS(16), n_lists), dim3(1024), 0, st, bd, i0);           //  hundred tuples per bin measured slower)
-		KPROF_END(prof, st);
-	};
-	int groups = (flags >> KMX_ROUND_PIPE_SHIFT) & 15;          // 0: whole-round kernels; P: the lists in P groups, pipelined
-	if (groups > nb) groups = nb;
-	int piped_commits = 0;                                     // lists [0, piped_commits) committed inside k_round_commit_check
-	if (groups > 1 && t < KMX_PIPE_ROUNDS) {
-		// software pipeline over groups of lists (k_round_commit_check); group g = lists [lo(g), lo(g+1)), the bigger groups first
-		auto lo = [&](int g) { return (g * nb + groups - 1) / groups; };
-		KPROF_BEGIN(prof, KC_CHECK_CLAIM, st);
-		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_emit<W, NHM>), dim3(gx, lo(1)), blk, 0, st, md, bd, t, pp, 0));
-		KPROF_END(prof, st);
-		for (int g = 0; g + 1 < groups; g++) {
-			const int nc = lo(g + 1) - lo(g), nk = lo(g + 2) - lo(g + 1);
-			detect(lo(g), nc);
-			KPROF_BEGIN(prof, KC_COMMIT_CHECK, st);
-			DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit_check<W, NHM>), dim3((nc + nk) * gx, 1), blk, 0, st, md, bd, t, pp, eb, lo(g), nc, lo(g + 1), nk));
-			KPROF_END(prof, st);
-		}
-		piped_commits = lo(groups - 1);
-		detect(lo(groups - 1), nb - lo(groups - 1));
-		KPROF_BEGIN(prof, KC_VERIFY_COMMIT, st);
-		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit<W, NHM>), dim3(gx, nb - lo(groups - 1)), blk, 0, st, md, bd, t, pp, eb, lo(groups - 1)));
+	const u64 eb = (*epoch)++;                                 // k_round_file's reservations
+	const int pending = (flags & KMX_ROUND_PENDING) ? 1 : 0;
+	if (pending) {
+		// the previous round's lists are about twice as long as this round's: the commit bodies stride over them
+		KPROF_BEGIN(prof, KC_COMMIT_CHECK, st);
+		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit_check<W, NHM>), dim3(2 * nb * gx, 1), blk, 0, st, md, bd, t, pp));
 		KPROF_END(prof, st);
 	} else {
 		KPROF_BEGIN(prof, KC_CHECK_CLAIM, st);
-		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_emit<W, NHM>), grid, blk, 0, st, md, bd, t, pp, 0));
-		KPROF_END(prof, st);
-		detect(0, nb);
-		KPROF_BEGIN(prof, KC_VERIFY_COMMIT, st);
-		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit<W, NHM>), grid, blk, 0, st, md, bd, t, pp, eb, 0));
+		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_emit<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
 		KPROF_END(prof, st);
 	}
+	KPROF_BEGIN(prof, KC_DETECT, st);
+	const int keep_own = (flags & KMX_ROUND_KEEP) ? 1 : 0;
+	if (md.nh <= 8) hipLaunchKernelGGL((k_round_detect<8, 1024>), dim3(KMX_CL_BINS(8), nb), dim3(1024), 0, st, bd, nb, pp, pending, keep_own);   // (256 threads for the late rounds' few
+	else hipLaunchKernelGGL((k_round_detect<16, 1024>), dim3(KMX_CL_BINS(16), nb), dim3(1024), 0, st, bd, nb, pp, pending, keep_own);           //  hundred tuples per bin measured slower)
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_file<W, NHM>), grid, blk, 0, st, md, bd, pp, eb));
+	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_SLOW, st);
 	const bool legacy0 = flags & KMX_ROUND_RESOLVE_GATHER;      // test hook: the gathering resolve kernel for level 0 too
 	for (int s = 0; s < nsub; s++) {
@@ -2348,7 +2459,16 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	}
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_REORDER, st);
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, nb), dim3(256), 0, st, md, bd, t, pp, nsub & 1, piped_commits));
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, nb), dim3(256), 0, st, md, bd, t, pp, nsub & 1));
+	KPROF_END(prof, st);
+}
+
+// the commit of round t (parity pp) in a launch of its own: end of the build, or a caller that needs the arrays up to date
+void commit_flush(const ModelDev &md, const BlockDev &bd, int t, int pp, hipStream_t st, KernelProf *prof)
+{
+	KPROF_BEGIN(prof, KC_VERIFY_COMMIT, st);
+	if (md.nh <= 8) hipLaunchKernelGGL((k_round_commit<8>), dim3(round_gx(t), md.nb), dim3(256), 0, st, md, bd, t, pp);
+	else hipLaunchKernelGGL((k_round_commit<16>), dim3(round_gx(t), md.nb), dim3(256), 0, st, md, bd, t, pp);
 	KPROF_END(prof, st);
 }
 

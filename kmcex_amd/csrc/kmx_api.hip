@@ -34,6 +34,7 @@ void classify_count(const ModelDev &, const u64 *, const u32 *, u64, u64, int *,
 void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int *, u64 *, u32 *, u64, hipStream_t);
 void block_init(const BlockDev &, int, int, int, hipStream_t);
 void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *, const KmbackJob *, const BitScatter *);
+void commit_flush(const ModelDev &, const BlockDev &, int, int, hipStream_t, KernelProf *);
 void rest_append(const ModelDev &, const BlockDev &, int, int, int, u64 *, int *, unsigned long long *, u64 *, int *, u64 *, hipStream_t);
 void kmback_emit(const ModelDev &, const BlockDev &, const u64 *, const unsigned char *, int, int, int, int, int, const BitScatter &, hipStream_t);
 void bs_apply(const BitScatter &, hipStream_t);
@@ -247,6 +248,13 @@ struct kmx_model {
 	bool ring = false;                                         // built by several GPUs (kmx_shard_begin): this handle holds ONE rank's share
 	int ring_rank = 0, ring_world = 1;
 	int nsub = 1;                                              // grid-wide ordered passes in round 0 (see process_block)
+	// The winners of a round are committed beside the check of the NEXT round (k_round_commit_check), also across a block
+	// boundary: `pending` says that the round with list parity pp ^ 1 and round index pending_t still owes its commit.
+	int pp = 0;                                                // list / per-slot-state parity of the next round (alternates from round to round, never reset inside a build)
+	bool pending = false;
+	int pending_t = 0;
+	bool defer = true;                                         // false: every round commits in a launch of its own before the next check (arrays above 2^37 positions; KMX_PIPE=0)
+	bool dbg_no_defer = false;
 	// test hooks, read from the environment by kmx_begin: forced pass counts, forced older code
 	// paths (KMX_ROUND_* flags of kmx_types.h), a trace of the pass-count controller
 	int dbg_nsub0 = -1, dbg_nsub1 = -1, dbg_flags = 0;
@@ -410,8 +418,8 @@ static int create_device_side(kmx_model *m)
 		auto env_int = [](const char *name, int dflt) { const char *v = hook_env(name); return v ? atoi(v) : dflt; };
 		m->dbg_nsub0 = env_int("KMX_NSUB0", -1);
 		m->dbg_nsub1 = env_int("KMX_NSUB1", -1);
-		m->dbg_flags = (env_int("KMX_FIN_GLOBAL", 0) ? KMX_ROUND_FIN_GLOBAL : 0) | (env_int("KMX_RESOLVE_GATHER", 0) ? KMX_ROUND_RESOLVE_GATHER : 0)
-		               | ((env_int("KMX_PIPE", 2) & 15) << KMX_ROUND_PIPE_SHIFT);   // groups of lists the big rounds are pipelined over (0: off)   // KMX_PIPE=0: every round as whole-round kernels
+		m->dbg_flags = (env_int("KMX_FIN_GLOBAL", 0) ? KMX_ROUND_FIN_GLOBAL : 0) | (env_int("KMX_RESOLVE_GATHER", 0) ? KMX_ROUND_RESOLVE_GATHER : 0);
+		m->dbg_no_defer = env_int("KMX_PIPE", 1) == 0;                      // KMX_PIPE=0: commit after every round, check against the committed state only
 		m->dbg_ctrl = env_int("KMX_CTRL_DEBUG", 0) != 0;
 		m->dbg_kmb_direct = env_int("KMX_KMB_DIRECT", 0) != 0;
 		m->dbg_kmb_host = env_int("KMX_KMB_HOST", 1) != 0;
@@ -683,8 +691,7 @@ static int kmback_reserve(kmx_model *m, u64 bound)
 }
 static int kmback_emit(kmx_model *m, int t, int pp, int n_in_block, u64 bound)
 {
-	if (!m->kmb_deferred) return KMX_OK;
-	TRY(kmback_reserve(m, bound));
+	if (m->kmb_deferred) TRY(kmback_reserve(m, bound));          // (else: md.kmb_direct, the kernel ORs the bits in itself)
 	kmxk::kmback_emit(m->md, m->bd, m->bd.kmers, m->bd.surv, 0, m->nb, t, pp, n_in_block, m->kmb, m->stream);
 	return KMX_OK;
 }
@@ -733,14 +740,20 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 		u64 off = 0;
 		auto carve = [&](u64 bytes) { u64 o = off; off += (bytes + 255) & ~u64(255); return o; };
 		u64 o_list0 = carve(blk * 4), o_list1 = carve(blk * 4), o_mv0 = carve(blk * 4), o_mv1 = carve(blk * 4);
-		u64 o_n0 = carve(nb * 4), o_n1 = carve(nb * 4), o_status = carve(blk);
+		u64 o_n0 = carve(nb * 4), o_n1 = carve(nb * 4), o_status0 = carve(blk), o_status1 = carve(blk), o_dfail = carve(blk);
 		u64 o_U[KMX_NSLOW];
 		for (int s2 = 0; s2 < KMX_NSLOW; s2++) o_U[s2] = carve(blk * 8 * (1 + m->W));
 		u64 o_Un = carve((u64)KMX_NSLOW * nb * KMX_CTR_STRIDE * 4), o_R = carve((u64)nb * KMX_RSIZE * 8);
 		u64 o_tc0 = carve((u64)nb * KMX_NTILES * 4), o_tc1 = carve((u64)nb * KMX_NTILES * 4);
 		const u64 cl_bins = m->nh <= 8 ? KMX_CL_BINS(8) : KMX_CL_BINS(16);
 		u64 o_surv = carve(blk), o_surv1 = carve(blk);
-		u64 o_um = carve(blk * 2), o_cl_tup = carve((u64)nb * cl_bins * (u64)(m->nh <= 8 ? KMX_CL_CAP_OF(8) : KMX_CL_CAP_OF(16)) * 8), o_cl_cnt = carve((u64)nb * KMX_CL_MAXBINS * 4), o_cl_ovf = carve((u64)nb * 4);
+		const u64 cl_bytes = (u64)nb * cl_bins * (u64)(m->nh <= 8 ? KMX_CL_CAP_OF(8) : KMX_CL_CAP_OF(16)) * 8;
+		u64 o_um[2], o_want[2], o_cidx[2], o_cnib[2], o_cl_tup[2], o_cl_cnt[2];
+		for (int q = 0; q < 2; q++) {
+			o_um[q] = carve(blk * 2); o_want[q] = carve(blk * 2); o_cidx[q] = carve(blk * 4 * (u64)m->nh); o_cnib[q] = carve(blk * 8);
+			o_cl_tup[q] = carve(cl_bytes); o_cl_cnt[q] = carve((u64)nb * KMX_CL_MAXBINS * 4);
+		}
+		u64 o_cl_ovf = carve((u64)nb * 4);
 		HIPCHK(hipMalloc(&m->d_block_scratch, off));
 		HIPCHK(hipMemsetAsync(m->d_block_scratch, 0, off, m->stream));     // R starts at epoch 0; epochs only grow
 		m->scratch_bytes = off; m->scratch_nb = nb; m->scratch_W = m->W;
@@ -749,14 +762,19 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 		bd.kmers = nullptr; bd.counts = nullptr;
 		bd.list[0] = (u32 *)(base + o_list0); bd.list[1] = (u32 *)(base + o_list1);
 		bd.mover[0] = (u32 *)(base + o_mv0); bd.mover[1] = (u32 *)(base + o_mv1);
-		bd.n[0] = (int *)(base + o_n0); bd.n[1] = (int *)(base + o_n1); bd.status = (unsigned char *)(base + o_status);
+		bd.n[0] = (int *)(base + o_n0); bd.n[1] = (int *)(base + o_n1);
+		bd.status[0] = (unsigned char *)(base + o_status0); bd.status[1] = (unsigned char *)(base + o_status1); bd.dfail = (unsigned char *)(base + o_dfail);
 		for (int s2 = 0; s2 < KMX_NSLOW; s2++) bd.Urec[s2] = (u64 *)(base + o_U[s2]);
 		bd.Un = (int *)(base + o_Un); bd.R = (u64 *)(base + o_R);
 		bd.tile_cnt[0] = (int *)(base + o_tc0); bd.tile_cnt[1] = (int *)(base + o_tc1);
 		bd.surv = (unsigned char *)(base + o_surv);
 		m->d_surv[0] = bd.surv; m->d_surv[1] = (unsigned char *)(base + o_surv1);   // block b flags into d_surv[b & 1]
-		bd.um = (unsigned short *)(base + o_um); bd.cl_tup = (u64 *)(base + o_cl_tup);
-		bd.cl_cnt = (int *)(base + o_cl_cnt); bd.cl_ovf = (int *)(base + o_cl_ovf);      // zeroed with the slab; the kernels keep them zero between rounds
+		for (int q = 0; q < 2; q++) {
+			bd.um[q] = (unsigned short *)(base + o_um[q]); bd.want[q] = (unsigned short *)(base + o_want[q]);
+			bd.cidx[q] = (u32 *)(base + o_cidx[q]); bd.cnib[q] = (u64 *)(base + o_cnib[q]);
+			bd.cl_tup[q] = (u64 *)(base + o_cl_tup[q]); bd.cl_cnt[q] = (int *)(base + o_cl_cnt[q]);
+		}
+		bd.cl_ovf = (int *)(base + o_cl_ovf);                        // zeroed with the slab; the kernels keep it zero between rounds
 		bd.stats = m->d_stats;
 		TRY(dalloc(&m->d_rest_n, 1, false, m->stream));
 		TRY(dalloc(&m->d_stale_kmers, (u64)nb * 2, false, m->stream));
@@ -765,6 +783,12 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 		m->rest_cap = 0;
 	}
 	m->stg_n = 0;
+	// a build that ended on an error may have left claim counters or dfail marks behind
+	for (int q = 0; q < 2; q++) HIPCHK(hipMemsetAsync(m->bd.cl_cnt[q], 0, (u64)nb * KMX_CL_MAXBINS * 4, m->stream));
+	HIPCHK(hipMemsetAsync(m->bd.dfail, 0, blk, m->stream));
+	HIPCHK(hipMemsetAsync(m->bd.cl_ovf, 0, (u64)nb * 4, m->stream));
+	m->pp = 0; m->pending = false; m->pending_t = 0;
+	m->defer = !m->dbg_no_defer && m->km_byte_size * 8 <= (1ULL << KMX_CL_MIX_BITS);      // position identity inside a detect table is exact up to 2^37
 	// rest accumulators: grown on demand (see ensure_rest_capacity)
 	const u64 want_rest = std::max<u64>(m->n_km / 8, 2 * blk) + blk;
 	if (m->rest_cap < want_rest) {
@@ -857,14 +881,37 @@ static int passes_of_round(const kmx_model *m, int t)
 }
 
 // insert_with_thread (kmodel.hpp:557-573) for the block at staging offset `head`
+// the commit the last round still owes (see kmx_model::pending), in a launch of its own
+static int flush_pending_commit(kmx_model *m)
+{
+	if (!m->pending) return KMX_OK;
+	kmxk::commit_flush(m->md, m->bd, m->pending_t, m->pp ^ 1, m->stream, &m->prof);
+	m->pending = false;
+	HIPCHK(hipGetLastError());
+	return KMX_OK;
+}
+
+// one round of the block in m->bd (list parity m->pp): the previous round's commit rides with its check; its own winners
+// stay pending -- or are committed right away when the build does not defer (m->defer, or a rank of the multi-GPU ring)
+static int run_round(kmx_model *m, int t, bool defer, const KmbackJob *job)
+{
+	const int flags = m->dbg_flags | (m->pending ? KMX_ROUND_PENDING : 0) | (defer ? KMX_ROUND_KEEP : 0);
+	kmxk::round(m->md, m->bd, t, m->pp, passes_of_round(m, t), &m->epoch, flags, m->stream, &m->prof, job, &m->kmb);
+	m->pending = true; m->pending_t = t;
+	m->pp ^= 1;
+	m->rounds++;
+	if (!defer) TRY(flush_pending_commit(m));
+	return KMX_OK;
+}
+
+// insert_with_thread (kmodel.hpp:557-573) for the block at staging offset `head`
 static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_partial)
 {
 	const int nb = m->nb;
 	m->bd.kmers = m->d_stg_kmers + head * m->W;
 	m->bd.counts = m->d_stg_counts + head;
 	m->bd.surv = m->d_surv[m->blocks & 1];                        // (the previous block's flags stay readable for its job)
-	int pp = 0;
-	kmxk::block_init(m->bd, nb, pp, (int)n_in_block, m->stream);
+	kmxk::block_init(m->bd, nb, m->pp, (int)n_in_block, m->stream);   // (the pending commit of the previous block reads the OTHER parity)
 	steer_passes(m);
 	// The previous block's km_back emission rides along with this block's finisher launches, one list per round: 128
 	// rider workgroups beside the nb finisher workgroups, one wave of workgroups on 256 CUs.
@@ -879,10 +926,9 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 			job.i0 += part.n_lists;
 			job.n_lists -= part.n_lists;
 		}
-		kmxk::round(m->md, m->bd, t, pp, passes_of_round(m, t), &m->epoch, m->dbg_flags, m->stream, &m->prof, part.n_lists ? &part : nullptr, &m->kmb);
-		pp ^= 1;
-		m->rounds++;
+		TRY(run_round(m, t, m->defer, part.n_lists ? &part : nullptr));
 	}
+	const int pp = m->pp;                                          // the lists the last reorder wrote: the block's survivors
 	TRY(ensure_rest_capacity(m, n_in_block + (u64)nb));
 	if (final_partial) {
 		int row = (int)((n_in_block - 1) / KMX_BUCKET);
@@ -892,12 +938,10 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 	}
 	kmxk::rest_append(m->md, m->bd, pp, 0, nb, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream);
 	// km_back insert of everything the block inserted (kmodel.hpp:548-550): handed to the next block's finisher launches,
-	// or done here when there is no next block to host it
-	if (m->kmb_deferred) {
-		if (m->dbg_kmb_host && !final_partial) {
-			job.kmers = m->bd.kmers; job.surv = m->bd.surv; job.n_in_block = (int)n_in_block; job.i0 = 0; job.n_lists = nb;
-		} else TRY(kmback_emit(m, 0, pp, (int)n_in_block, n_in_block));
-	}
+	// or done here when there is no next block to host it (or the filter takes the direct path)
+	if (m->kmb_deferred && m->dbg_kmb_host && !final_partial) {
+		job.kmers = m->bd.kmers; job.surv = m->bd.surv; job.n_in_block = (int)n_in_block; job.i0 = 0; job.n_lists = nb;
+	} else TRY(kmback_emit(m, 0, pp, (int)n_in_block, n_in_block));
 	m->blocks++;
 	HIPCHK(hipGetLastError());
 	return KMX_OK;
@@ -1162,6 +1206,7 @@ static int kmx_finish_impl(kmx_model *m)
 	HIPCHK(hipSetDevice(m->device));
 	if (m->stg_n) TRY(process_block(m, 0, m->stg_n, true));   // push_last_to_array; an empty tail is skipped (divergence D1)
 	m->stg_n = 0;
+	TRY(flush_pending_commit(m));
 	TRY(kmback_flush(m));
 	unsigned long long n_rest = 0;
 	HIPCHK(hipMemcpyAsync(m->h_stats, m->d_stats, ST_N * 8, hipMemcpyDeviceToHost, m->stream));
@@ -1170,6 +1215,10 @@ static int kmx_finish_impl(kmx_model *m)
 	if (m->h_stats[ST_BAD_COUNT]) {
 		m->state = ST_EMPTY;
 		return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)m->h_stats[ST_BAD_COUNT], m->ci, m->cs);
+	}
+	if (m->h_stats[ST_TABLE_FULL]) {
+		m->state = ST_EMPTY;
+		return fail(KMX_E_STATE, "a claim table overflowed in %llu bins: the model is not exact and is dropped", (unsigned long long)m->h_stats[ST_TABLE_FULL]);
 	}
 	if (m->prof.on) {
 		double before = 0, after = 0;
@@ -1544,10 +1593,9 @@ static int kmx_ring_round_dev_impl(kmx_model *m, int t, const kmx_ring_list *lis
 	}
 	if (t == 0) steer_passes(m);
 	kmxk::ring_import(m->md, m->bd, rl, m->d_stg_kmers, m->d_stg_counts, m->stream);
-	// (a rank holds one or two of the round's lists: nothing to pipeline)
-	kmxk::round(m->md, m->bd, t, 0, passes_of_round(m, t), &m->epoch, m->dbg_flags & ~(15 << KMX_ROUND_PIPE_SHIFT), m->stream, &m->prof, nullptr, nullptr);
+	m->pp = 0;                                                    // (ring_import fills list[0]: a rank sees a list for one round)
+	TRY(run_round(m, t, false, nullptr));                         // committed at once: the arrays move on to other lists elsewhere
 	TRY(kmback_emit(m, t, 0, -1, (u64)n_lists * KMX_BUCKET));
-	m->rounds++;
 	bool any_out = false;
 	for (int i = 0; i < nb; i++) any_out |= rl.e[i].active && rl.e[i].dst_msg;
 	if (any_out) kmxk::ring_export(m->md, m->bd, rl, m->stream);
@@ -1587,6 +1635,7 @@ static int kmx_shard_local_impl(kmx_model *m, kmx_stats *partial, void **d_rest_
 	HIPCHK(hipMemcpyAsync(&n_rest, m->d_rest_n, 8, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipStreamSynchronize(m->stream));
 	if (m->h_stats[ST_BAD_COUNT]) return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)m->h_stats[ST_BAD_COUNT], m->ci, m->cs);
+	if (m->h_stats[ST_TABLE_FULL]) return fail(KMX_E_STATE, "a claim table overflowed in %llu bins: the model is not exact", (unsigned long long)m->h_stats[ST_TABLE_FULL]);
 	if (m->prof.on) prof_collect(m);
 	memset(partial, 0, sizeof *partial);
 	partial->attempts = m->h_stats[ST_ATTEMPTS]; partial->successes = m->h_stats[ST_SUCCESSES];

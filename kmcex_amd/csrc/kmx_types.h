@@ -72,7 +72,9 @@ struct KmcDecode {
 
 // device-side statistics (one u64 each)
 enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_MAX_U0, ST_MAX_UFIN,
-       ST_PIPE_ATTEMPTS, ST_PIPE_SUCC,        // attempts examined / successes committed inside k_round_commit_check launches (accounting only)
+       ST_PIPE_ATTEMPTS, ST_PIPE_SUCC,        // attempts examined / winners committed inside fused commit|check launches (accounting only)
+       ST_DELTA_FAILS,                        // candidates of a stale check that a still-uncommitted winner of the previous visit ruled out (k_round_detect)
+       ST_TABLE_FULL,                         // a detect table could not take a bin (never expected; the build fails loudly instead of guessing)
        ST_N };
 
 #define KMX_CLS_TILE 2048                      // k-mers per classification tile (front end)
@@ -82,10 +84,8 @@ enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, 
 #define KMX_FIN_RANGES 8                        // the finisher takes up to this many register loads, in index ranges
 #define KMX_APPLY_WGS 8                         // extra workgroups per list in k_reorder that apply the finisher's decisions
 enum { KMX_ROUND_FIN_GLOBAL = 1, KMX_ROUND_RESOLVE_GATHER = 2,     // test hooks of kmxk::round (older code paths)
-       KMX_ROUND_PIPE_SHIFT = 4 };                                   // bits 4..7: the big rounds as a software pipeline over this many groups of lists
-#ifndef KMX_PIPE_ROUNDS
-#define KMX_PIPE_ROUNDS 2                      // rounds 0 .. KMX_PIPE_ROUNDS-1 are pipelined (later lists are too short to pay for the launches)
-#endif
+       KMX_ROUND_PENDING = 4,                                        // the previous round's winners are not committed yet: their commit rides with this round's check
+       KMX_ROUND_KEEP = 8 };                                         // this round's winners will be committed beside the next round's check (its detect re-reads the claims)
 #define KMX_NSLOW 2                            // contended-record levels, ping-pong: pass s reads level s&1, defers to (s+1)&1
 #define KMX_MAX_NSUB 16                        // most grid-wide ordered passes per round
 #define KMX_CTR_STRIDE 32                      // ints between per-list counters: one 128-byte line each (same-line atomics serialise)
@@ -103,7 +103,12 @@ struct BlockDev {
 	u32 *mover[2];           // mover[pp][i*BUCKET + r] = r-th survivor from the right of the previous round
 	int *n[2];               // n[pp][i] current list lengths (buff_real_n, kmodel.hpp:277)
 	int *tile_cnt[2];        // tile_cnt[pp][i*NTILES + tile] survivors (failed slots) per 1024-slot tile, counted as they fail
-	unsigned char *status;   // [nb*BUCKET] per slot: 0 undecided, 1 failed (survivor), 2 inserted
+	// Per-slot state of a round, double-buffered by the round parity pp like the lists: the winners of round r are committed
+	// beside the check of round r+1 (k_round_commit_check), which writes the other half.
+	unsigned char *status[2]; // [nb*BUCKET] per slot: 0 undecided -- after the round: a winner nobody contended, committed one round
+	                          // later from cidx/cnib/want --, 1 failed (survivor), 2 inserted by the ordered path, 3 contended (transient)
+	unsigned char *dfail;    // [nb*BUCKET] set by k_round_detect: a winner of the previous visit to the array, not yet committed when
+	                          // this slot was checked, holds one of its positions with the other value; k_round_file makes it a failure
 	unsigned char *surv;     // [nb*BUCKET] per k-mer of the block: 1 = it went to the rest table (k_rest_append); the others were inserted
 	// contended k-mers; level (s & 1) = still undecided after s grid-wide resolve passes.  A record carries what the
 	// ordered slow path needs -- word 0 = slot | bin << 32, then the W packed k-mer words -- so that its latency-bound
@@ -113,9 +118,13 @@ struct BlockDev {
 	u64 *R;                  // [nb*KMX_RSIZE] epoch-tagged reservations
 	u64 *stats;              // [ST_N]
 	// claims of a round as a partitioned stream (k_round_check_emit -> k_round_detect -> k_round_commit)
-	unsigned short *um;      // [nb*BUCKET] per slot: positions a candidate saw untagged (bit j = hash j)
-	u64 *cl_tup;             // [nb][bins][KMX_CL_CAP] claim tuples, hash-partitioned by position
-	int *cl_cnt;             // [nb][KMX_CL_MAXBINS] tuples per bin (reset by k_round_detect)
+	unsigned short *um[2];   // [nb*BUCKET] per slot: positions a candidate saw untagged (bit j = hash j)
+	unsigned short *want[2]; // [nb*BUCKET] per slot: value wanted at the position of hash j (= the k-mer's occurrence bin)
+	u32 *cidx[2];            // [nh][nb*BUCKET] per candidate: cell index of the position of hash j (plane j)
+	u64 *cnib[2];            // [nb*BUCKET] per candidate: position & 15 of hash j in nibble j
+	u64 *cl_tup[2];          // [nb][bins][KMX_CL_CAP] claim tuples, hash-partitioned by position
+	int *cl_cnt[2];          // [nb][KMX_CL_MAXBINS] tuples per bin; a round's counts are reset by the NEXT round's k_round_detect, which reads
+	                         // the tuples once more as the delta of the still-uncommitted winners
 	int *cl_ovf;             // [nb] a bin of the list overflowed: every candidate of the round takes the ordered path (reset by k_reorder)
 };
 
@@ -123,6 +132,9 @@ struct BlockDev {
 #define KMX_CL_BINS_LOG2(NHM) 8
 #define KMX_CL_BINS(NHM) (1 << KMX_CL_BINS_LOG2(NHM))
 #define KMX_CL_MAXBINS 256
+// a position is identified inside a bin by the rest of a bijective 37-bit mix of it (kernels.hip cl_mix): exact for arrays
+// of up to 2^37 positions (1.5e11 k-mers at nh = 7 would need more) -- beyond that winners are committed before the next check
+#define KMX_CL_MIX_BITS 37
 // tuples per bin: 2^18 * nh / bins at most on average (7168 at nh = 7, 16384 at nh = 16), + 25 % and more
 #ifndef KMX_CL_CAP                             // (tools/stress_small_tables.py builds a library with a tiny capacity: the overflow path every round)
 #define KMX_CL_CAP_OF(NHM) ((NHM) <= 8 ? 12288 : 20480)

@@ -225,14 +225,15 @@ def test_both_finisher_paths_bit_exact(cfg, monkeypatch):
     sets).  Both must give the oracle's arrays on the same input: KMX_FIN_GLOBAL=1 sends every set through the second;
     KMX_NSUB0/1 force the number of grid-wide passes in front of it (0: the finisher alone, from check_emit's
     snapshot; 2: resolve + reserve/resolve first) and KMX_RESOLVE_GATHER=1 the gathering form of the first pass.  The
-    KMX_PIPE sets how many groups of lists the big rounds are pipelined over (0: whole-round kernels, 8: list by list;
-    the default is 2).  The hooks are read when the model is created."""
+    KMX_PIPE=0 commits the winners of every round in a launch of its own before the next check (the default lets them
+    commit beside the next round's check, whose detect tables take them as settled positions).  The hooks are read when
+    the model is created."""
     k, ci, cs, nh, nb, n = cfg
     km, cnt = synth.make_stream(n, k, ci, cs, seed_k=4242, seed_c=4243)
     o = O.OracleModel(ci, cs, nh, nb)
     o.build(k, km, cnt)
     so = o.stats()
-    for force_global, nsub0, gather, pipe in ((0, -1, 0, 2), (1, -1, 0, 0), (0, 0, 0, 8), (0, 2, 0, 3), (0, 2, 1, 2), (1, 1, 1, 8), (0, -1, 0, 0)):
+    for force_global, nsub0, gather, pipe in ((0, -1, 0, 1), (1, -1, 0, 0), (0, 0, 0, 1), (0, 2, 0, 1), (0, 2, 1, 0), (1, 1, 1, 1), (0, -1, 0, 0)):
         monkeypatch.setenv("KMX_PIPE", str(pipe))
         monkeypatch.setenv("KMX_FIN_GLOBAL", str(force_global))
         monkeypatch.setenv("KMX_NSUB0", str(nsub0))
