@@ -168,7 +168,7 @@ int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double
  * classes: 0 classify(+Bloom insert) 1 check (+ claim emission) 2 commit 3 ordered slow path 4 reorder 5 rest append 6 query
  * 7 detect (opposite claims) 8 commit of one group of lists beside the check of the next (the pipelined big rounds).
  * seconds[9], launches[9] accumulate until reset.                                                            */
-#define KMX_KERNEL_CLASSES 9
+#define KMX_KERNEL_CLASSES 10
 int kmx_set_profile(kmx_model *m, int on);
 int kmx_get_kernel_times(kmx_model *m, double *seconds, uint64_t *launches, int reset);
 

@@ -339,7 +339,7 @@ class KModel:
         _chk(self.L.kmx_download(self.h, self.DL[which], index, buf.ctypes.data, cap, C.byref(w)))
         return buf[:w.value].copy()
 
-    KERNEL_CLASSES = ["classify", "check", "commit", "slow_path", "reorder", "rest_append", "query", "detect", "commit_check"]
+    KERNEL_CLASSES = ["classify", "check", "commit", "slow_path", "reorder", "rest_append", "query", "detect", "commit_check", "file"]
 
     def set_profile(self, on: bool) -> None:
         _chk(self.L.kmx_set_profile(self.h, int(on)))

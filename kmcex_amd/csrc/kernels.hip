@@ -459,6 +459,61 @@ __device__ __forceinline__ u32 cl_fp(u64 m) { return (u32)m & ((1u << CL_FP_BITS
 // position & 15 <-> bit of the cell (device_common.h bit_in_cell)
 __device__ __forceinline__ u32 bit_of_nibble(u32 nib) { return 8 * ((nib >> 3) & 1) + 7 - (nib & 7); }
 
+// Per-slot record of a candidate: the cell index of each of its nh positions, then position & 15 of hash j in nibble j --
+// whole 16-byte groups, so that a wave writes (and the commit reads) full lines: 32 bytes per slot at nh = 7.
+__host__ __device__ __forceinline__ int crec_words(int nh) { return (nh + (nh <= 8 ? 1 : 2) + 3) & ~3; }
+template <int NHM> struct CRec { u32 w[(NHM + (NHM <= 8 ? 1 : 2) + 3) & ~3]; };
+template <int NHM> __device__ __forceinline__ void crec_store(u32 *dst, int nh, const u64 *pos)
+{
+	CRec<NHM> r;
+	constexpr int WMAX = sizeof(r.w) / 4;
+#pragma unroll
+	for (int q = 0; q < WMAX; q++) r.w[q] = 0;
+	u64 nib = 0;
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if (j < nh) { nib |= (pos[j] & 15) << (4 * j); }
+	// (nh is uniform: the selects below are scalar)
+#pragma unroll
+	for (int q = 0; q < WMAX; q++) {
+		u32 v = 0;
+		if (q < NHM && q < nh) v = (u32)(pos[q < NHM ? q : 0] >> 4);
+		else if (q == nh) v = (u32)nib;
+		else if (q == nh + 1 && nh > 8) v = (u32)(nib >> 32);
+		r.w[q] = v;
+	}
+	const int words = crec_words(nh);
+#pragma unroll
+	for (int q = 0; q < WMAX; q += 4)
+		if (q < words) *(uint4 *)(dst + q) = make_uint4(r.w[q], r.w[q + 1], r.w[q + 2], r.w[q + 3]);
+}
+template <int NHM> __device__ __forceinline__ CRec<NHM> crec_load(const u32 *src, int nh)
+{
+	CRec<NHM> r;
+	constexpr int WMAX = sizeof(r.w) / 4;
+	const int words = crec_words(nh);
+#pragma unroll
+	for (int q = 0; q < WMAX; q += 4) {
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (q < words) v = *(const uint4 *)(src + q);
+		r.w[q] = v.x; r.w[q + 1] = v.y; r.w[q + 2] = v.z; r.w[q + 3] = v.w;
+	}
+	return r;
+}
+// hash j of a record: cell index / position & 15
+template <int NHM> __device__ __forceinline__ u32 crec_cell(const CRec<NHM> &r, int j) { return r.w[j]; }
+template <int NHM> __device__ __forceinline__ u32 crec_nib(const CRec<NHM> &r, int nh, int j)
+{
+	constexpr int WMAX = sizeof(r.w) / 4;
+	u64 nib = 0;
+#pragma unroll
+	for (int q = 0; q < WMAX; q++) {
+		if (q == nh) nib |= r.w[q];
+		if (q == nh + 1 && nh > 8) nib |= (u64)r.w[q] << 32;
+	}
+	return (u32)(nib >> (4 * j)) & 15u;
+}
+
 // (bx of gx workgroups work on list i: the kernels below map their grids onto these bodies)
 // LDS of one check_emit workgroup, carved out of a byte pool the kernel owns (kernels that run one of several bodies per workgroup)
 #define CHECK_LDS_BYTES(NHM) (256 * (NHM) * 8 + (3 * KMX_CL_BINS(NHM) + 8) * 4)
@@ -469,7 +524,7 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 	int *s_cnt = (int *)(lds + 256 * NHM * 8), *s_off = s_cnt + NBIN, *s_base = s_off + NBIN, *s_tmp = s_base + NBIN;
 	int &s_fail = s_tmp[4];
 	const int n = bd.n[pp][i];
-	const u64 row = (u64)i * KMX_BUCKET, plane = (u64)md.nb * KMX_BUCKET;
+	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;                                  // kmodel.hpp:563
 	if (bx == 0 && threadIdx.x == 0) {
 		if (n) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
@@ -489,7 +544,6 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 		bool failed = false;
 		u32 um = 0, bin = 0;
 		int rank[NHM];
-		u32 cb[NHM];
 		Touches<NHM> tc;
 		if (x < n) {
 			const u32 raw = bd.list[pp][row + x];
@@ -503,22 +557,17 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 			failed = touches_conflict<NHM>(md, tc, bin);
 			status[x] = failed ? SLOT_FAILED : SLOT_UNDECIDED;
 			if (!failed) {
-				u64 nib = 0;
 #pragma unroll
 				for (int j = 0; j < NHM; j++)
 					if (j < md.nh) {
 						const u32 b = bit_in_cell(tc.pos[j]);
-						nib |= (tc.pos[j] & 15) << (4 * j);
-						bd.cidx[pp][(u64)j * plane + row + x] = (u32)(tc.pos[j] >> 4);   // what the deferred commit needs: no k-mer, no hash
 						if (!((tc.cell[j] >> (16 + b)) & 1u)) {
 							um |= 1u << j;
-							cb[j] = cl_bin(cl_mix(tc.pos[j]));
-							rank[j] = atomicAdd(&s_cnt[cb[j]], 1);
+							rank[j] = atomicAdd(&s_cnt[cl_bin(cl_mix(tc.pos[j]))], 1);
 						}
 					}
-				bd.um[pp][row + x] = (unsigned short)um;
-				bd.want[pp][row + x] = (unsigned short)bin;
-				bd.cnib[pp][row + x] = nib;
+				bd.uw[pp][row + x] = um | (bin << 16);
+				crec_store<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh, tc.pos);   // what the deferred commit needs: no k-mer, no hash
 			}
 		}
 		// survivors are counted per 1024-slot tile as they fail, so the reorder needs no counting pass
@@ -541,7 +590,7 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
 				if (j < md.nh && ((um >> j) & 1u))
-					s_tup[s_off[cb[j]] + rank[j]] = CL_TUPLE(tc.pos[j], (bin >> j) & 1u, x);
+					s_tup[s_off[cl_bin(cl_mix(tc.pos[j]))] + rank[j]] = CL_TUPLE(tc.pos[j], (bin >> j) & 1u, x);
 		}
 		__syncthreads();
 		for (int q = threadIdx.x; q < total; q += 256) {               // consecutive lanes, consecutive tuples of a run
@@ -573,13 +622,89 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_e
 //   causes no contention: everybody who wants the other value there fails, the others are compatible with it.
 // A bin of more tuples than 3/4 of the table is taken in passes over a secondary hash of the fingerprint.
 #define DT_SETTLED 4u
+// table operations; BOUNDED: give up (and report) after a full sweep instead of spinning -- only the multi-pass path needs it
+template <bool BOUNDED> __device__ __forceinline__ bool dt_insert(u32 *s_t, u32 tmask, u32 fp, u32 flags)
+{
+	u32 slot = fp & tmask;                                           // (the low bits of cl_mix are as good as any)
+	for (u32 probes = 0; !BOUNDED || probes <= tmask; probes++) {
+		const u32 old = atomicCAS(&s_t[slot], 0u, (fp << 3) | flags);
+		if (old == 0) return true;
+		if ((old >> 3) == fp) {
+			// a settled entry is complete after phase 0 (two winners on one position want the same value); a claim adds its value bit
+			if (!(old & DT_SETTLED) && (old & flags) != flags) atomicOr(&s_t[slot], flags);
+			return true;
+		}
+		slot = (slot + 1) & tmask;
+	}
+	return false;
+}
+template <bool BOUNDED> __device__ __forceinline__ void dt_lookup(const u32 *s_t, u32 tmask, u32 fp, u64 e, unsigned char *status, unsigned char *dfail)
+{
+	u32 slot = fp & tmask, cur = s_t[slot];
+	for (u32 probes = 0; (cur >> 3) != fp; probes++) {
+		if (BOUNDED && (cur == 0 || probes > tmask)) return;         // (the insert reported it)
+		slot = (slot + 1) & tmask;
+		cur = s_t[slot];
+	}
+	const u32 w = CL_WANT(e);
+	if (cur & DT_SETTLED) { if (!((cur >> w) & 1u)) dfail[CL_X(e)] = 1; }          // tagged meanwhile with the other value
+	else if ((cur >> (w ^ 1u)) & 1u) status[CL_X(e)] = SLOT_CONTENDED;             // the other value is wanted there too
+}
+// A bin (+ its delta) of more tuples than 3/4 of the table: taken in P passes over a secondary hash of the fingerprint.
+// Small arrays, where nearly every claim meets another, and the overflow libraries of tools/stress_small_tables.py get here.
+template <int BT, int TBITS> __device__ __forceinline__ void detect_multipass(u32 *s_t, const u64 *tp, int cnt, const u64 *dp, int dcnt, const unsigned char *dstatus,
+                                                                          unsigned char *status, unsigned char *dfail, u64 *table_full)
+{
+	constexpr int T = 1 << TBITS;
+	constexpr u32 tmask = T - 1;
+	int *s_sub = (int *)s_t;                                         // (the pass counters are done with before the table is cleared)
+	auto sub = [](u32 fp) { return (fp * 0x85EBCA6Bu) >> 26; };      // 6 bits
+	int P = 2;
+	for (; P < 64; P <<= 1) {                                        // uniform: the counts come from LDS after barriers
+		if (threadIdx.x < 64) s_sub[threadIdx.x] = 0;
+		__syncthreads();
+		for (int q = threadIdx.x; q < cnt + dcnt; q += BT) {
+			const u64 e = q < cnt ? tp[q] : dp[q - cnt];
+			atomicAdd(&s_sub[sub(cl_fp(cl_mix(CL_POS(e)))) & (u32)(P - 1)], 1);
+		}
+		__syncthreads();
+		int mx = 0;
+		for (int q = 0; q < P; q++) mx = max(mx, s_sub[q]);
+		__syncthreads();
+		if (mx <= T * 3 / 4) break;
+	}
+	bool full = false;
+	for (int pass = 0; pass < P; pass++) {
+		for (int q = threadIdx.x; q < T; q += BT) s_t[q] = 0;
+		__syncthreads();
+		for (int q = threadIdx.x; q < dcnt; q += BT) {
+			const u64 e = dp[q];
+			const u32 fp = cl_fp(cl_mix(CL_POS(e)));
+			if ((int)(sub(fp) & (u32)(P - 1)) == pass && dstatus[CL_X(e)] == SLOT_UNDECIDED) full |= !dt_insert<true>(s_t, tmask, fp, DT_SETTLED | (1u << CL_WANT(e)));
+		}
+		__syncthreads();
+		for (int q = threadIdx.x; q < cnt; q += BT) {
+			const u64 e = tp[q];
+			const u32 fp = cl_fp(cl_mix(CL_POS(e)));
+			if ((int)(sub(fp) & (u32)(P - 1)) == pass) full |= !dt_insert<true>(s_t, tmask, fp, 1u << CL_WANT(e));
+		}
+		__syncthreads();
+		for (int q = threadIdx.x; q < cnt; q += BT) {
+			const u64 e = tp[q];
+			const u32 fp = cl_fp(cl_mix(CL_POS(e)));
+			if ((int)(sub(fp) & (u32)(P - 1)) == pass) dt_lookup<true>(s_t, tmask, fp, e, status, dfail);
+		}
+		__syncthreads();
+	}
+	if (full) atomicAdd(table_full, 1ULL);                           // never expected: the build is then rejected (kmx_finish)
+}
+
 // keep_own: this round's winners will be committed beside the next round's check, whose k_round_detect reads (and resets) the bins.
-template <int NHM, int BT> __global__ __launch_bounds__(BT) void k_round_detect(BlockDev bd, int nb, int pp, int use_delta, int keep_own)
+template <int NHM, int BT> __global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(NHM <= 8 ? 8 : 4)))
+void k_round_detect(BlockDev bd, int nb, int pp, int use_delta, int keep_own)
 {
 	constexpr int NBIN = KMX_CL_BINS(NHM), TBITS = KMX_CL_TBITS(NHM), T = 1 << TBITS, CAP = KMX_CL_CAP_OF(NHM);
-	__shared__ u32 s_t[T];
-	__shared__ int s_sub[64];
-	__shared__ int s_full;
+	__shared__ u32 s_t[T];                                           // exactly 64 KB at nh <= 8: two workgroups per CU
 	const int i = (int)blockIdx.y, b = blockIdx.x;
 	const int id = (i + 1) % nb;                                     // list that visited this array one round earlier
 	int *gc = bd.cl_cnt[pp] + i * KMX_CL_MAXBINS + b;
@@ -587,115 +712,58 @@ template <int NHM, int BT> __global__ __launch_bounds__(BT) void k_round_detect(
 	int cnt = *gc, dcnt = *gd;
 	if (cnt > CAP) cnt = CAP;                                        // check_emit has raised cl_ovf[i]
 	if (dcnt > CAP) dcnt = CAP;                                      // (that list had no uncontended winner then: nothing of it passes the filter)
-	__syncthreads();                                                 // every thread has read the counters
+	if (!use_delta) dcnt = 0;
+	if (cnt) {                                                       // uniform
+		const u64 *tp = bd.cl_tup[pp] + ((u64)i * NBIN + b) * CAP;
+		const u64 *dp = bd.cl_tup[pp ^ 1] + ((u64)id * NBIN + b) * CAP;
+		const unsigned char *dstatus = bd.status[pp ^ 1] + (u64)id * KMX_BUCKET;
+		unsigned char *status = bd.status[pp] + (u64)i * KMX_BUCKET, *dfail = bd.dfail + (u64)i * KMX_BUCKET;
+		if (cnt + dcnt > T * 3 / 4) detect_multipass<BT, TBITS>(s_t, tp, cnt, dp, dcnt, dstatus, status, dfail, bd.stats + ST_TABLE_FULL);
+		else {
+			int tb = 10;
+			while ((1 << tb) < 4 * (cnt + dcnt) && tb < TBITS) tb++;     // load <= 1/4 in the usual case: short probe chains
+			const u32 tmask = (1u << tb) - 1;
+			for (int q = threadIdx.x; q < (1 << tb); q += BT) s_t[q] = 0;
+			constexpr int U = 8;                                         // tuples per thread in flight: the loads of a batch are issued together
+			if (cnt <= U * BT && dcnt <= U * BT / 2) {                   // the usual case: the bin's tuples stay in registers between the phases
+				u64 e[U], d[U / 2];
+#pragma unroll
+				for (int u = 0; u < U; u++) { const int q = u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
+#pragma unroll
+				for (int u = 0; u < U / 2; u++) { const int q = u * BT + (int)threadIdx.x; d[u] = q < dcnt ? dp[q] : ~0ULL; }
+				__syncthreads();
+				if (dcnt) {                                              // phase 0 (uniform): the settled positions
+					unsigned char ds[U / 2];
+#pragma unroll
+					for (int u = 0; u < U / 2; u++) ds[u] = d[u] != ~0ULL ? dstatus[CL_X(d[u])] : (unsigned char)SLOT_FAILED;
+#pragma unroll
+					for (int u = 0; u < U / 2; u++)
+						if (ds[u] == SLOT_UNDECIDED) dt_insert<false>(s_t, tmask, cl_fp(cl_mix(CL_POS(d[u]))), DT_SETTLED | (1u << CL_WANT(d[u])));
+					__syncthreads();
+				}
+#pragma unroll
+				for (int u = 0; u < U; u++) if (e[u] != ~0ULL) dt_insert<false>(s_t, tmask, cl_fp(cl_mix(CL_POS(e[u]))), 1u << CL_WANT(e[u]));
+				__syncthreads();
+#pragma unroll
+				for (int u = 0; u < U; u++) if (e[u] != ~0ULL) dt_lookup<false>(s_t, tmask, cl_fp(cl_mix(CL_POS(e[u]))), e[u], status, dfail);
+			} else {
+				__syncthreads();
+				for (int q = threadIdx.x; q < dcnt; q += BT) {
+					const u64 e = dp[q];
+					if (dstatus[CL_X(e)] == SLOT_UNDECIDED) dt_insert<false>(s_t, tmask, cl_fp(cl_mix(CL_POS(e))), DT_SETTLED | (1u << CL_WANT(e)));
+				}
+				__syncthreads();
+				for (int q = threadIdx.x; q < cnt; q += BT) { const u64 e = tp[q]; dt_insert<false>(s_t, tmask, cl_fp(cl_mix(CL_POS(e))), 1u << CL_WANT(e)); }
+				__syncthreads();
+				for (int q = threadIdx.x; q < cnt; q += BT) { const u64 e = tp[q]; dt_lookup<false>(s_t, tmask, cl_fp(cl_mix(CL_POS(e))), e, status, dfail); }
+			}
+		}
+	}
+	// (every thread has read the counters: barriers above, or nothing else happened)
 	if (threadIdx.x == 0) {
 		*gd = 0;                                                     // last reader of the previous round's bin: ready for round r+1
 		if (!keep_own) *gc = 0;                                      // nobody will read this round's tuples again
 	}
-	if (!use_delta) dcnt = 0;
-	if (cnt == 0) return;                                            // uniform: no candidate claimed a position of this bin
-	const u64 *tp = bd.cl_tup[pp] + ((u64)i * NBIN + b) * CAP;
-	const u64 *dp = bd.cl_tup[pp ^ 1] + ((u64)id * NBIN + b) * CAP;
-	const unsigned char *dstatus = bd.status[pp ^ 1] + (u64)id * KMX_BUCKET;
-	unsigned char *status = bd.status[pp] + (u64)i * KMX_BUCKET, *dfail = bd.dfail + (u64)i * KMX_BUCKET;
-	// passes: P = 1 unless the bin holds more than 3/4 of the table
-	int P = 1;
-	if (cnt + dcnt > T * 3 / 4) {
-		for (P = 2; P < 64; P <<= 1) {                               // uniform: counts come from LDS after barriers
-			if (threadIdx.x < 64) s_sub[threadIdx.x] = 0;
-			__syncthreads();
-			for (int q = threadIdx.x; q < cnt + dcnt; q += BT) {
-				const u64 e = q < cnt ? tp[q] : dp[q - cnt];
-				atomicAdd(&s_sub[(cl_fp(cl_mix(CL_POS(e))) * 0x85EBCA6Bu) >> 26 & (P - 1)], 1);
-			}
-			__syncthreads();
-			int mx = 0;
-			for (int q = 0; q < P; q++) mx = max(mx, s_sub[q]);
-			__syncthreads();
-			if (mx <= T * 3 / 4) break;
-		}
-	}
-	if (threadIdx.x == 0) s_full = 0;
-	for (int pass = 0; pass < P; pass++) {
-		const int load = P == 1 ? cnt + dcnt : T * 3 / 4;
-		int tb = 10;
-		while ((1 << tb) < 4 * load && tb < TBITS) tb++;             // load <= 1/4 in the usual case: short probe chains
-		const u32 tmask = (1u << tb) - 1;
-		for (int q = threadIdx.x; q < (1 << tb); q += BT) s_t[q] = 0;
-		__syncthreads();
-		auto mine = [&](u32 fp) { return P == 1 || (int)((fp * 0x85EBCA6Bu) >> 26 & (u32)(P - 1)) == pass; };
-		auto home = [&](u32 fp) { return ((fp * 0x9E3779B1u) >> (32 - TBITS)) & tmask; };
-		// find the entry of fp or the free slot it should take (bounded: a table can only fill up if the passes above failed)
-		auto insert = [&](u32 fp, u32 flags, bool settled) {
-			u32 slot = home(fp);
-			for (int probes = 0; probes <= (int)tmask; probes++) {
-				const u32 old = atomicCAS(&s_t[slot], 0u, (fp << 3) | flags);
-				if (old == 0) return;
-				if ((old >> 3) == fp) {
-					if (settled) atomicOr(&s_t[slot], flags);          // (two winners on one position want the same value)
-					else if (!(old & DT_SETTLED) && (old & flags) != flags) {
-						// not settled when read; if a settled insert raced us the flag we add is one of its own value bits or is
-						// ignored by the lookup (phase 0 is over before phase 1 starts: barrier below)
-						atomicOr(&s_t[slot], flags);
-					}
-					return;
-				}
-				slot = (slot + 1) & tmask;
-			}
-			s_full = 1;
-		};
-		// phase 0: settled positions
-		for (int q = threadIdx.x; q < dcnt; q += BT) {
-			const u64 e = dp[q];
-			const u32 fp = cl_fp(cl_mix(CL_POS(e)));
-			if (mine(fp) && dstatus[CL_X(e)] == SLOT_UNDECIDED) insert(fp, DT_SETTLED | (1u << CL_WANT(e)), true);
-		}
-		__syncthreads();
-		// phase 1 + 2: this round's claims
-		constexpr int U = 8;                                         // tuples per thread in flight: the loads of a batch are issued together
-		auto lookup = [&](u64 e, u32 fp) {
-			u32 slot = home(fp), cur = 0;
-			for (int probes = 0; probes <= (int)tmask; probes++) {
-				cur = s_t[slot];
-				if ((cur >> 3) == fp || cur == 0) break;
-				slot = (slot + 1) & tmask;
-			}
-			if ((cur >> 3) != fp) return;                            // (table full: reported below)
-			const u32 w = CL_WANT(e);
-			if (cur & DT_SETTLED) { if (!((cur >> w) & 1u)) dfail[CL_X(e)] = 1; }          // tagged meanwhile with the other value
-			else if ((cur >> (w ^ 1u)) & 1u) status[CL_X(e)] = SLOT_CONTENDED;             // the other value is wanted there too
-		};
-		if (cnt <= U * BT) {                                         // the usual case: the bin's tuples stay in registers between the phases
-			u64 e[U];
-			u32 fp[U];
-#pragma unroll
-			for (int u = 0; u < U; u++) { const int q = u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
-#pragma unroll
-			for (int u = 0; u < U; u++) {
-				if (e[u] == ~0ULL) continue;
-				fp[u] = cl_fp(cl_mix(CL_POS(e[u])));
-				if (!mine(fp[u])) { e[u] = ~0ULL; continue; }
-				insert(fp[u], 1u << CL_WANT(e[u]), false);
-			}
-			__syncthreads();
-#pragma unroll
-			for (int u = 0; u < U; u++) if (e[u] != ~0ULL) lookup(e[u], fp[u]);
-		} else {
-			for (int q = threadIdx.x; q < cnt; q += BT) {
-				const u64 e = tp[q];
-				const u32 fp = cl_fp(cl_mix(CL_POS(e)));
-				if (mine(fp)) insert(fp, 1u << CL_WANT(e), false);
-			}
-			__syncthreads();
-			for (int q = threadIdx.x; q < cnt; q += BT) {
-				const u64 e = tp[q];
-				const u32 fp = cl_fp(cl_mix(CL_POS(e)));
-				if (mine(fp)) lookup(e, fp);
-			}
-		}
-		__syncthreads();
-	}
-	if (threadIdx.x == 0 && s_full) atomicAdd(bd.stats + ST_TABLE_FULL, 1ULL);
 }
 
 // ------------------------------------------------------------------------------------------ S: ordered slow path (helpers)
@@ -760,50 +828,73 @@ template <int W> __device__ __forceinline__ u32 rec_load(const u64 *rec, u64 slo
 // one -- every candidate of a list whose claims overflowed a bin -- files a record in U[0] (slot, bin, packed k-mer, untagged
 // mask of the check) and places its priority reservations (epoch `epoch`), which saves the first reserve pass of the
 // ordered slow path.  What stays SLOT_UNDECIDED is a winner: nobody wants the other value on any of its positions.
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_file(ModelDev md, BlockDev bd, int pp, u64 epoch)
+// A scan with few, fat workgroups (a launch pays ~6 ns of dispatch per workgroup, and same-address atomics on the
+// record counter serialise at ~11 ns each): a workgroup takes chunks of 4096 slots, 4 consecutive ones per thread as one
+// 32-bit word of status and of dfail, collects the contended slots of the chunk in an LDS queue, reserves their records
+// with ONE global atomic, and files them.
+#define KMX_FILE_WGS 64                        // one chunk per workgroup at full length
+template <int W, int NHM> __global__ __launch_bounds__(1024) void k_round_file(ModelDev md, BlockDev bd, int pp, u64 epoch)
 {
-	__shared__ int s_cnt, s_base, s_fail, s_df;
-	const int i = blockIdx.y, bx = blockIdx.x, gx = gridDim.x;
+	__shared__ u32 s_q[4096];
+	__shared__ int s_nq, s_base, s_tf[4], s_df;
+	const int i = blockIdx.y;
 	const int n = bd.n[pp][i];
-	const u64 row = (u64)i * KMX_BUCKET, plane = (u64)md.nb * KMX_BUCKET;
+	const u64 row = (u64)i * KMX_BUCKET;
 	const bool all_contended = bd.cl_ovf[i] != 0;
-	unsigned char *status = bd.status[pp] + row;
-	if (threadIdx.x == 0) s_df = 0;
-	for (int base = bx * 256; base < n; base += gx * 256) {
-		if (threadIdx.x == 0) { s_cnt = 0; s_fail = 0; }
-		__syncthreads();
-		const int x = base + threadIdx.x;
-		int st = x < n ? (int)status[x] : (int)SLOT_FAILED;
-		bool newly_failed = false;
-		if (st != SLOT_FAILED && bd.dfail[row + x]) {               // (only candidates emit claims, so only they can be flagged)
-			bd.dfail[row + x] = 0;
-			status[x] = SLOT_FAILED;
-			st = SLOT_FAILED;
-			newly_failed = true;
+	u32 *status32 = (u32 *)(bd.status[pp] + row), *dfail32 = (u32 *)(bd.dfail + row);
+	if (threadIdx.x == 0) { s_df = 0; s_nq = 0; }
+	if (threadIdx.x < 4) s_tf[threadIdx.x] = 0;
+	__syncthreads();
+	for (int base = (int)blockIdx.x * 4096; base < n; base += KMX_FILE_WGS * 4096) {     // uniform trip count
+		const int x0 = base + 4 * (int)threadIdx.x;
+		if (x0 < n) {
+			const u32 st = status32[x0 >> 2], df = dfail32[x0 >> 2];
+			u32 st_new = st;
+			int nfail = 0;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				if (x0 + k >= n) break;
+				const u32 sk = (st >> (8 * k)) & 0xFFu;
+				if (sk == SLOT_FAILED) continue;
+				if ((df >> (8 * k)) & 0xFFu) {                           // (only candidates emit claims, so only they can be flagged)
+					st_new = (st_new & ~(0xFFu << (8 * k))) | ((u32)SLOT_FAILED << (8 * k));
+					nfail++;
+				} else if (sk == SLOT_CONTENDED || (sk == SLOT_UNDECIDED && all_contended)) {
+					st_new &= ~(0xFFu << (8 * k));                         // SLOT_UNDECIDED: the ordered path decides it
+					s_q[atomicAdd(&s_nq, 1)] = (u32)(x0 + k);
+				}
+			}
+			if (st_new != st) status32[x0 >> 2] = st_new;
+			if (df) dfail32[x0 >> 2] = 0;
+			if (nfail) atomicAdd(&s_tf[threadIdx.x >> 8], nfail);       // survivors are counted per 1024-slot tile (k_reorder)
 		}
-		const bool contended = st == SLOT_CONTENDED || (st == SLOT_UNDECIDED && all_contended);
-		u64 v[W];
-		u32 bin = 0, um = 0;
-		if (contended) {
+		__syncthreads();
+		const int nq = s_nq;
+		if (threadIdx.x == 0 && nq) s_base = atomicAdd(bd.Un + UN_IDX(0, i, md.nb), nq);
+		if (threadIdx.x < 4 && s_tf[threadIdx.x]) {
+			atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (base >> 10) + (int)threadIdx.x, s_tf[threadIdx.x]);
+			atomicAdd(&s_df, s_tf[threadIdx.x]);
+			s_tf[threadIdx.x] = 0;
+		}
+		__syncthreads();
+		for (int e = threadIdx.x; e < nq; e += 1024) {
+			const u32 x = s_q[e];
 			const u32 idx = bd.list[pp][row + x];
+			u64 v[W];
 			load_kmer<W>(bd.kmers, row + idx, v);
-			bin = bd.want[pp][row + x];
-			um = bd.um[pp][row + x];
-			const u64 nib = bd.cnib[pp][row + x];
-			const u64 key = resv_key(epoch, (u32)x);
+			const u32 uw = bd.uw[pp][row + x], um = uw & 0xFFFFu, bin = uw >> 16;
+			const CRec<NHM> rec = crec_load<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh);
+			const u64 key = resv_key(epoch, x);
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
 				if (j < md.nh && ((um >> j) & 1u)) {
-					const u64 pos = ((u64)bd.cidx[pp][(u64)j * plane + row + x] << 4) | ((nib >> (4 * j)) & 15);
+					const u64 pos = ((u64)crec_cell<NHM>(rec, j) << 4) | crec_nib<NHM>(rec, md.nh, j);
 					atomicMax(resv_slot(bd, i, pos), key);
 				}
-			status[x] = SLOT_UNDECIDED;                                // the ordered path decides it
+			rec_store<W>(bd.Urec[0], row + (u64)(s_base + e), x, bin, v, um);
 		}
-		const u64 fm = __ballot(newly_failed);
-		if ((threadIdx.x & 63) == 0 && fm) atomicAdd(&s_fail, (int)__popcll(fm));
-		const int p = block_append_slot(bd.Un + UN_IDX(0, i, md.nb), contended, &s_cnt, &s_base);
-		if (contended) rec_store<W>(bd.Urec[0], row + p, (u32)x, bin, v, um);
-		if (threadIdx.x == 0 && s_fail) { atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (base >> 10), s_fail); s_df += s_fail; }
+		__syncthreads();
+		if (threadIdx.x == 0) s_nq = 0;
 		__syncthreads();
 	}
 	if (threadIdx.x == 0 && s_df) atomicAdd(bd.stats + ST_DELTA_FAILS, (u64)s_df);
@@ -820,7 +911,7 @@ template <int NHM> __device__ __forceinline__ void commit_body(const ModelDev &m
 {
 	int &s_cnt = ((int *)lds)[0];
 	const int n = bd.n[pp][i];
-	const u64 row = (u64)i * KMX_BUCKET, plane = (u64)md.nb * KMX_BUCKET;
+	const u64 row = (u64)i * KMX_BUCKET;
 	cell_t *cells = md.cells[a];
 	const unsigned char *status = bd.status[pp] + row;
 	if (stat_slot && threadIdx.x == 0) s_cnt = 0;
@@ -829,13 +920,13 @@ template <int NHM> __device__ __forceinline__ void commit_body(const ModelDev &m
 		const int x = base + threadIdx.x;
 		const bool win = x < n && status[x] == SLOT_UNDECIDED;
 		if (win) {
-			const u32 um = bd.um[pp][row + x], want = bd.want[pp][row + x];
-			const u64 nib = bd.cnib[pp][row + x];
+			const u32 uw = bd.uw[pp][row + x], um = uw & 0xFFFFu, want = uw >> 16;
+			const CRec<NHM> rec = crec_load<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh);
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
 				if (j < md.nh && ((um >> j) & 1u)) {
-					const u32 b = bit_of_nibble((u32)(nib >> (4 * j)) & 15u);
-					atomicOr(cells + bd.cidx[pp][(u64)j * plane + row + x], CELL_TAG(b) | (((want >> j) & 1u) ? CELL_VAL(b) : 0u));
+					const u32 b = bit_of_nibble(crec_nib<NHM>(rec, md.nh, j));
+					atomicOr(cells + crec_cell<NHM>(rec, j), CELL_TAG(b) | (((want >> j) & 1u) ? CELL_VAL(b) : 0u));
 				}
 		}
 		if (stat_slot) {
@@ -865,13 +956,15 @@ template <int NHM> __global__ __launch_bounds__(256) void k_round_commit(ModelDe
 // Consecutive workgroups alternate between the two kinds and cycle through the lists, so every list advances at the same
 // pace, both kinds are resident on every CU from the first wave of workgroups to the last, and the launch does not end on a
 // tail of atomics.
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit_check(ModelDev md, BlockDev bd, int t, int pp)
+// gk / gc workgroups per list check / commit (powers of two; the committed lists are about twice as long as the checked
+// ones -- or, across a block boundary, 16 times shorter -- and every workgroup that is launched costs dispatch time).
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit_check(ModelDev md, BlockDev bd, int t, int pp, int gk, int gc)
 {
 	__shared__ __align__(16) unsigned char lds[CHECK_LDS_BYTES(NHM)];
-	const int nb = md.nb, per = 2 * nb, gx = (int)gridDim.x / per;
-	const int r = (int)blockIdx.x % per, bx = (int)blockIdx.x / per, l = r >> 1;
-	if (r & 1) check_emit_body<W, NHM>(md, bd, t, pp, l, bx, gx, lds, ST_PIPE_ATTEMPTS);
-	else commit_body<NHM>(md, bd, (l + t + nb - 1) % nb, pp ^ 1, l, bx, gx, lds, ST_PIPE_SUCC);
+	const int nb = md.nb, G = gk < gc ? gk : gc, rk = gk / G, rc = gc / G, per = nb * (rk + rc);
+	const int p = (int)blockIdx.x / per, r = (int)blockIdx.x % per, l = r % nb, s = r / nb;
+	if (s < rk) check_emit_body<W, NHM>(md, bd, t, pp, l, p * rk + s, gk, lds, ST_PIPE_ATTEMPTS);
+	else commit_body<NHM>(md, bd, (l + t + nb - 1) % nb, pp ^ 1, l, p * rc + (s - rk), gc, lds, ST_PIPE_SUCC);
 }
 
 // ------------------------------------------------------------------------------------------ S: ordered slow path
@@ -2422,9 +2515,9 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	const u64 eb = (*epoch)++;                                 // k_round_file's reservations
 	const int pending = (flags & KMX_ROUND_PENDING) ? 1 : 0;
 	if (pending) {
-		// the previous round's lists are about twice as long as this round's: the commit bodies stride over them
 		KPROF_BEGIN(prof, KC_COMMIT_CHECK, st);
-		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit_check<W, NHM>), dim3(2 * nb * gx, 1), blk, 0, st, md, bd, t, pp));
+		const int gc = round_gx(t > 0 ? t - 1 : nb - 1);
+		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit_check<W, NHM>), dim3(nb * (gx + gc), 1), blk, 0, st, md, bd, t, pp, gx, gc));
 		KPROF_END(prof, st);
 	} else {
 		KPROF_BEGIN(prof, KC_CHECK_CLAIM, st);
@@ -2435,7 +2528,9 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	const int keep_own = (flags & KMX_ROUND_KEEP) ? 1 : 0;
 	if (md.nh <= 8) hipLaunchKernelGGL((k_round_detect<8, 1024>), dim3(KMX_CL_BINS(8), nb), dim3(1024), 0, st, bd, nb, pp, pending, keep_own);   // (256 threads for the late rounds' few
 	else hipLaunchKernelGGL((k_round_detect<16, 1024>), dim3(KMX_CL_BINS(16), nb), dim3(1024), 0, st, bd, nb, pp, pending, keep_own);           //  hundred tuples per bin measured slower)
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_file<W, NHM>), grid, blk, 0, st, md, bd, pp, eb));
+	KPROF_END(prof, st);
+	KPROF_BEGIN(prof, KC_FILE, st);
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_file<W, NHM>), dim3(KMX_FILE_WGS, nb), dim3(1024), 0, st, md, bd, pp, eb));
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_SLOW, st);
 	const bool legacy0 = flags & KMX_ROUND_RESOLVE_GATHER;      // test hook: the gathering resolve kernel for level 0 too

@@ -748,9 +748,10 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 		const u64 cl_bins = m->nh <= 8 ? KMX_CL_BINS(8) : KMX_CL_BINS(16);
 		u64 o_surv = carve(blk), o_surv1 = carve(blk);
 		const u64 cl_bytes = (u64)nb * cl_bins * (u64)(m->nh <= 8 ? KMX_CL_CAP_OF(8) : KMX_CL_CAP_OF(16)) * 8;
-		u64 o_um[2], o_want[2], o_cidx[2], o_cnib[2], o_cl_tup[2], o_cl_cnt[2];
+		u64 o_uw[2], o_crec[2], o_cl_tup[2], o_cl_cnt[2];
+		const u64 rec_words = (u64)((m->nh + (m->nh <= 8 ? 1 : 2) + 3) & ~3);      // kernels.hip crec_words
 		for (int q = 0; q < 2; q++) {
-			o_um[q] = carve(blk * 2); o_want[q] = carve(blk * 2); o_cidx[q] = carve(blk * 4 * (u64)m->nh); o_cnib[q] = carve(blk * 8);
+			o_uw[q] = carve(blk * 4); o_crec[q] = carve(blk * 4 * rec_words);
 			o_cl_tup[q] = carve(cl_bytes); o_cl_cnt[q] = carve((u64)nb * KMX_CL_MAXBINS * 4);
 		}
 		u64 o_cl_ovf = carve((u64)nb * 4);
@@ -770,8 +771,7 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 		bd.surv = (unsigned char *)(base + o_surv);
 		m->d_surv[0] = bd.surv; m->d_surv[1] = (unsigned char *)(base + o_surv1);   // block b flags into d_surv[b & 1]
 		for (int q = 0; q < 2; q++) {
-			bd.um[q] = (unsigned short *)(base + o_um[q]); bd.want[q] = (unsigned short *)(base + o_want[q]);
-			bd.cidx[q] = (u32 *)(base + o_cidx[q]); bd.cnib[q] = (u64 *)(base + o_cnib[q]);
+			bd.uw[q] = (u32 *)(base + o_uw[q]); bd.crec[q] = (u32 *)(base + o_crec[q]);
 			bd.cl_tup[q] = (u64 *)(base + o_cl_tup[q]); bd.cl_cnt[q] = (int *)(base + o_cl_cnt[q]);
 		}
 		bd.cl_ovf = (int *)(base + o_cl_ovf);                        // zeroed with the slab; the kernels keep it zero between rounds

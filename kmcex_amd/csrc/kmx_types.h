@@ -118,10 +118,8 @@ struct BlockDev {
 	u64 *R;                  // [nb*KMX_RSIZE] epoch-tagged reservations
 	u64 *stats;              // [ST_N]
 	// claims of a round as a partitioned stream (k_round_check_emit -> k_round_detect -> k_round_commit)
-	unsigned short *um[2];   // [nb*BUCKET] per slot: positions a candidate saw untagged (bit j = hash j)
-	unsigned short *want[2]; // [nb*BUCKET] per slot: value wanted at the position of hash j (= the k-mer's occurrence bin)
-	u32 *cidx[2];            // [nh][nb*BUCKET] per candidate: cell index of the position of hash j (plane j)
-	u64 *cnib[2];            // [nb*BUCKET] per candidate: position & 15 of hash j in nibble j
+	u32 *uw[2];              // [nb*BUCKET] per candidate: positions it saw untagged (bit j = hash j) | values it wants there << 16 (= its occurrence bin)
+	u32 *crec[2];            // [nb*BUCKET][crec_words(nh)] per candidate: cell index of every position + their low 4 bits (kernels.hip CRec)
 	u64 *cl_tup[2];          // [nb][bins][KMX_CL_CAP] claim tuples, hash-partitioned by position
 	int *cl_cnt[2];          // [nb][KMX_CL_MAXBINS] tuples per bin; a round's counts are reset by the NEXT round's k_round_detect, which reads
 	                         // the tuples once more as the delta of the still-uncommitted winners
@@ -162,7 +160,7 @@ struct RingLists { RingList e[KMX_MAX_NB]; };
 enum { SLOT_UNDECIDED = 0, SLOT_FAILED = 1, SLOT_INSERTED = 2, SLOT_CONTENDED = 3 };
 
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
-enum { KC_CLASSIFY = 0, KC_CHECK_CLAIM, KC_VERIFY_COMMIT, KC_SLOW, KC_REORDER, KC_REST, KC_QUERY, KC_DETECT, KC_COMMIT_CHECK, KC_N };   // CHECK_CLAIM = check + emit, VERIFY_COMMIT = commit
+enum { KC_CLASSIFY = 0, KC_CHECK_CLAIM, KC_VERIFY_COMMIT, KC_SLOW, KC_REORDER, KC_REST, KC_QUERY, KC_DETECT, KC_COMMIT_CHECK, KC_FILE, KC_N };   // CHECK_CLAIM = check + emit, VERIFY_COMMIT = commit
 struct KernelProf {
 	bool on = false;
 	void *events = nullptr;      // std::vector<hipEvent_t>* owned by the host side

@@ -10,7 +10,7 @@ t = -1
 for r in rows:
     nm = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
     if nm == "k_block_init": t = -1
-    if nm == "k_round_check_emit": t += 1                                    # the launch a round starts with
+    if nm in ("k_round_check_emit", "k_round_commit_check"): t += 1          # the launch a round starts with
     if nm.startswith(("k_round", "k_slow", "k_reorder")) and t >= 0:
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         a = acc[(t % nb, nm)]; a[0] += 1; a[1] += d; a[2] = max(a[2], d)
@@ -23,7 +23,7 @@ if len(sys.argv) > 3:   # sequence of one kernel's durations in round 0, last bu
     for r in rows:
         nm = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         if nm == "k_block_init": t = -1
-        if nm == "k_round_check_emit": t += 1                                    # the launch a round starts with
+        if nm in ("k_round_check_emit", "k_round_commit_check"): t += 1          # the launch a round starts with
         if nm == want and t == 0: seq.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     per = len(seq) // 3 if len(seq) >= 3 else len(seq)
     print(want, "round 0, last build:", " ".join("%.0f" % v for v in seq[-per:]))
