@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void k_block_init(BlockDev bd, int nb, int pp,
 // and the verdict of a candidate can only be changed by tags it did not see yet -- exactly the claim tuples of those
 // winners, which k_round_detect enters into its tables as SETTLED positions before it looks at this round's claims.
 // For that the identity of a position inside a table must be exact: bin and fingerprint are the two halves of ONE
-// bijective mix of the position (37 bits: arrays of up to 2^37 positions; above that the host commits before it checks).
+// bijective mix of the position (36 bits: arrays of up to 2^36 positions; above that the host commits before it checks).
 #define CL_POS_BITS 44
 #define CL_TUPLE(pos, want, x) ((u64)(pos) | ((u64)(want) << CL_POS_BITS) | ((u64)(x) << (CL_POS_BITS + 1)))
 #define CL_POS(tp) ((tp) & ((1ULL << CL_POS_BITS) - 1))
@@ -442,8 +442,8 @@ __global__ __launch_bounds__(256) void k_block_init(BlockDev bd, int nb, int pp,
 #define CL_X(tp) ((u32)((tp) >> (CL_POS_BITS + 1)) & (KMX_BUCKET - 1))
 #define CL_MIX_BITS KMX_CL_MIX_BITS
 #define CL_FP_BITS (CL_MIX_BITS - 8)
-static_assert(KMX_CL_BINS_LOG2(8) == 8 && KMX_CL_BINS_LOG2(16) == 8 && CL_FP_BITS + 3 == 32, "bin (8 bits) + fingerprint (29 bits) = the mixed position; an entry = fingerprint + 3 flags");
-// multiply by an odd constant and xor-shift right are bijections on 37-bit integers: distinct positions below 2^37 get
+static_assert(KMX_CL_BINS_LOG2(8) == 8 && KMX_CL_BINS_LOG2(16) == 8 && CL_FP_BITS + 4 == 32, "bin (8 bits) + fingerprint (28 bits) = the mixed position; an entry = fingerprint + 4 flags");
+// multiply by an odd constant and xor-shift right are bijections on 36-bit integers: distinct positions below 2^36 get
 // distinct (bin, fingerprint) pairs
 __device__ __forceinline__ u64 cl_mix(u64 pos)
 {
@@ -610,93 +610,51 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_e
 }
 
 // ------------------------------------------------------------------------------------------ D: settled positions and opposite claims, bin by bin
-// One workgroup per (bin, list).  An LDS table entry = fingerprint of a position (exact within the bin, see cl_mix) + 3 flags:
+// One workgroup per (bin, list).  An LDS table entry = fingerprint of a position (exact within the bin, see cl_mix) + 4 flags:
 //   bit 0 / bit 1   value 0 / value 1 is wanted there by a candidate of this round
-//   bit 2           SETTLED: a winner of the previous visit to this array tagged the position after (or while) this round's
-//                   check looked at it; bits 0/1 then say with which value
-// Phase 0 (use_delta): the claim tuples of the previous round's list i+1 -- the list that visited this array -- whose slot
-//   ended the round as an uncontended winner (status 0: its commit rides with this round's check) become settled entries.
-// Phase 1: this round's tuples; a settled entry is left alone.
-// Phase 2: every tuple looks its position up: settled with the other value -> the candidate has failed after all (dfail);
-//   wanted with both values by candidates -> those candidates take the ordered path (SLOT_CONTENDED).  A settled position
-//   causes no contention: everybody who wants the other value there fails, the others are compatible with it.
-// A bin of more tuples than 3/4 of the table is taken in passes over a secondary hash of the fingerprint.
-#define DT_SETTLED 4u
-// table operations; BOUNDED: give up (and report) after a full sweep instead of spinning -- only the multi-pass path needs it
-template <bool BOUNDED> __device__ __forceinline__ bool dt_insert(u32 *s_t, u32 tmask, u32 fp, u32 flags)
+//   bit 2 / bit 3   SETTLED with value 0 / 1: a winner of the previous visit to this array tagged the position after (or
+//                   while) this round's check looked at it
+// Phase 1: this round's tuples enter the table (at most KMX_CL_CAP <= 3/4 of it: a free slot always exists).
+// Phase 2 (use_delta): the claim tuples of the previous round's list i+1 -- the list that visited this array -- only PROBE the
+//   table: nearly all of them (99.7 %) name a position nobody claims this round and are done after one LDS read; for a hit
+//   the slot's status is looked up, and an uncontended winner (status 0: its commit rides with this round's check) settles the entry.
+// Phase 3: every tuple of this round looks its position up: settled with the other value -> the candidate has failed after
+//   all (dfail); wanted with both values by candidates -> those candidates take the ordered path (SLOT_CONTENDED).  A settled
+//   position causes no contention: everybody who wants the other value there fails, the others are compatible with it.
+#define DT_SETTLED(v) (4u << (v))
+__device__ __forceinline__ void dt_insert(u32 *s_t, u32 tmask, u32 fp, u32 w)
 {
 	u32 slot = fp & tmask;                                           // (the low bits of cl_mix are as good as any)
-	for (u32 probes = 0; !BOUNDED || probes <= tmask; probes++) {
-		const u32 old = atomicCAS(&s_t[slot], 0u, (fp << 3) | flags);
-		if (old == 0) return true;
-		if ((old >> 3) == fp) {
-			// a settled entry is complete after phase 0 (two winners on one position want the same value); a claim adds its value bit
-			if (!(old & DT_SETTLED) && (old & flags) != flags) atomicOr(&s_t[slot], flags);
-			return true;
-		}
+	for (;;) {                                                       // a free slot always exists: 2^TBITS > 4/3 * capacity
+		const u32 old = atomicCAS(&s_t[slot], 0u, (fp << 4) | w);
+		if (old == 0) return;
+		if ((old >> 4) == fp) { if (!(old & w)) atomicOr(&s_t[slot], w); return; }
 		slot = (slot + 1) & tmask;
 	}
-	return false;
 }
-template <bool BOUNDED> __device__ __forceinline__ void dt_lookup(const u32 *s_t, u32 tmask, u32 fp, u64 e, unsigned char *status, unsigned char *dfail)
+// slot of the entry of fp, or -1
+__device__ __forceinline__ int dt_find(const u32 *s_t, u32 tmask, u32 fp)
 {
-	u32 slot = fp & tmask, cur = s_t[slot];
-	for (u32 probes = 0; (cur >> 3) != fp; probes++) {
-		if (BOUNDED && (cur == 0 || probes > tmask)) return;         // (the insert reported it)
+	u32 slot = fp & tmask, cur;
+	while ((cur = s_t[slot]) != 0) {
+		if ((cur >> 4) == fp) return (int)slot;
 		slot = (slot + 1) & tmask;
-		cur = s_t[slot];
 	}
+	return -1;
+}
+__device__ __forceinline__ void dt_settle(u32 *s_t, u32 tmask, u64 d, const unsigned char *dstatus)
+{
+	const int slot = dt_find(s_t, tmask, cl_fp(cl_mix(CL_POS(d))));
+	if (slot >= 0 && dstatus[CL_X(d)] == SLOT_UNDECIDED) atomicOr(&s_t[slot], DT_SETTLED(CL_WANT(d)));
+}
+__device__ __forceinline__ void dt_lookup(const u32 *s_t, u32 tmask, u64 e, unsigned char *status, unsigned char *dfail)
+{
+	const u32 fp = cl_fp(cl_mix(CL_POS(e)));
+	u32 slot = fp & tmask, cur;
+	while (((cur = s_t[slot]) >> 4) != fp) slot = (slot + 1) & tmask;  // (it was inserted in phase 1)
 	const u32 w = CL_WANT(e);
-	if (cur & DT_SETTLED) { if (!((cur >> w) & 1u)) dfail[CL_X(e)] = 1; }          // tagged meanwhile with the other value
-	else if ((cur >> (w ^ 1u)) & 1u) status[CL_X(e)] = SLOT_CONTENDED;             // the other value is wanted there too
-}
-// A bin (+ its delta) of more tuples than 3/4 of the table: taken in P passes over a secondary hash of the fingerprint.
-// Small arrays, where nearly every claim meets another, and the overflow libraries of tools/stress_small_tables.py get here.
-template <int BT, int TBITS> __device__ __forceinline__ void detect_multipass(u32 *s_t, const u64 *tp, int cnt, const u64 *dp, int dcnt, const unsigned char *dstatus,
-                                                                          unsigned char *status, unsigned char *dfail, u64 *table_full)
-{
-	constexpr int T = 1 << TBITS;
-	constexpr u32 tmask = T - 1;
-	int *s_sub = (int *)s_t;                                         // (the pass counters are done with before the table is cleared)
-	auto sub = [](u32 fp) { return (fp * 0x85EBCA6Bu) >> 26; };      // 6 bits
-	int P = 2;
-	for (; P < 64; P <<= 1) {                                        // uniform: the counts come from LDS after barriers
-		if (threadIdx.x < 64) s_sub[threadIdx.x] = 0;
-		__syncthreads();
-		for (int q = threadIdx.x; q < cnt + dcnt; q += BT) {
-			const u64 e = q < cnt ? tp[q] : dp[q - cnt];
-			atomicAdd(&s_sub[sub(cl_fp(cl_mix(CL_POS(e)))) & (u32)(P - 1)], 1);
-		}
-		__syncthreads();
-		int mx = 0;
-		for (int q = 0; q < P; q++) mx = max(mx, s_sub[q]);
-		__syncthreads();
-		if (mx <= T * 3 / 4) break;
-	}
-	bool full = false;
-	for (int pass = 0; pass < P; pass++) {
-		for (int q = threadIdx.x; q < T; q += BT) s_t[q] = 0;
-		__syncthreads();
-		for (int q = threadIdx.x; q < dcnt; q += BT) {
-			const u64 e = dp[q];
-			const u32 fp = cl_fp(cl_mix(CL_POS(e)));
-			if ((int)(sub(fp) & (u32)(P - 1)) == pass && dstatus[CL_X(e)] == SLOT_UNDECIDED) full |= !dt_insert<true>(s_t, tmask, fp, DT_SETTLED | (1u << CL_WANT(e)));
-		}
-		__syncthreads();
-		for (int q = threadIdx.x; q < cnt; q += BT) {
-			const u64 e = tp[q];
-			const u32 fp = cl_fp(cl_mix(CL_POS(e)));
-			if ((int)(sub(fp) & (u32)(P - 1)) == pass) full |= !dt_insert<true>(s_t, tmask, fp, 1u << CL_WANT(e));
-		}
-		__syncthreads();
-		for (int q = threadIdx.x; q < cnt; q += BT) {
-			const u64 e = tp[q];
-			const u32 fp = cl_fp(cl_mix(CL_POS(e)));
-			if ((int)(sub(fp) & (u32)(P - 1)) == pass) dt_lookup<true>(s_t, tmask, fp, e, status, dfail);
-		}
-		__syncthreads();
-	}
-	if (full) atomicAdd(table_full, 1ULL);                           // never expected: the build is then rejected (kmx_finish)
+	if (cur & 12u) { if (w != ((cur >> 3) & 1u)) dfail[CL_X(e)] = 1; }             // tagged meanwhile with the other value (two winners never settle
+	else if ((cur >> (w ^ 1u)) & 1u) status[CL_X(e)] = SLOT_CONTENDED;             // different values; one that hits it twice leaves the OR: 1)
 }
 
 // keep_own: this round's winners will be committed beside the next round's check, whose k_round_detect reads (and resets) the bins.
@@ -704,6 +662,7 @@ template <int NHM, int BT> __global__ __launch_bounds__(BT) __attribute__((amdgp
 void k_round_detect(BlockDev bd, int nb, int pp, int use_delta, int keep_own)
 {
 	constexpr int NBIN = KMX_CL_BINS(NHM), TBITS = KMX_CL_TBITS(NHM), T = 1 << TBITS, CAP = KMX_CL_CAP_OF(NHM);
+	static_assert(CAP <= T / 4 * 3, "the table of a bin must take every tuple of a full bin with room to spare");
 	__shared__ u32 s_t[T];                                           // exactly 64 KB at nh <= 8: two workgroups per CU
 	const int i = (int)blockIdx.y, b = blockIdx.x;
 	const int id = (i + 1) % nb;                                     // list that visited this array one round earlier
@@ -718,45 +677,35 @@ void k_round_detect(BlockDev bd, int nb, int pp, int use_delta, int keep_own)
 		const u64 *dp = bd.cl_tup[pp ^ 1] + ((u64)id * NBIN + b) * CAP;
 		const unsigned char *dstatus = bd.status[pp ^ 1] + (u64)id * KMX_BUCKET;
 		unsigned char *status = bd.status[pp] + (u64)i * KMX_BUCKET, *dfail = bd.dfail + (u64)i * KMX_BUCKET;
-		if (cnt + dcnt > T * 3 / 4) detect_multipass<BT, TBITS>(s_t, tp, cnt, dp, dcnt, dstatus, status, dfail, bd.stats + ST_TABLE_FULL);
-		else {
-			int tb = 10;
-			while ((1 << tb) < 4 * (cnt + dcnt) && tb < TBITS) tb++;     // load <= 1/4 in the usual case: short probe chains
-			const u32 tmask = (1u << tb) - 1;
-			for (int q = threadIdx.x; q < (1 << tb); q += BT) s_t[q] = 0;
-			constexpr int U = 8;                                         // tuples per thread in flight: the loads of a batch are issued together
-			if (cnt <= U * BT && dcnt <= U * BT / 2) {                   // the usual case: the bin's tuples stay in registers between the phases
-				u64 e[U], d[U / 2];
+		int tb = 10;
+		while ((1 << tb) < 4 * cnt && tb < TBITS) tb++;              // load <= 1/4 (<= 3/4 for a full bin): short probe chains
+		const u32 tmask = (1u << tb) - 1;
+		for (int q = threadIdx.x; q < (1 << tb); q += BT) s_t[q] = 0;
+		constexpr int U = 8;                                         // tuples per thread in flight: the loads of a batch are issued together
+		if (cnt <= U * BT && dcnt <= U * BT / 2) {                   // the usual case: the bin's tuples stay in registers between the phases
+			u64 e[U], d[U / 2];
 #pragma unroll
-				for (int u = 0; u < U; u++) { const int q = u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
+			for (int u = 0; u < U; u++) { const int q = u * BT + (int)threadIdx.x; e[u] = q < cnt ? tp[q] : ~0ULL; }
 #pragma unroll
-				for (int u = 0; u < U / 2; u++) { const int q = u * BT + (int)threadIdx.x; d[u] = q < dcnt ? dp[q] : ~0ULL; }
+			for (int u = 0; u < U / 2; u++) { const int q = u * BT + (int)threadIdx.x; d[u] = q < dcnt ? dp[q] : ~0ULL; }
+			__syncthreads();
+#pragma unroll
+			for (int u = 0; u < U; u++) if (e[u] != ~0ULL) dt_insert(s_t, tmask, cl_fp(cl_mix(CL_POS(e[u]))), 1u << CL_WANT(e[u]));
+			__syncthreads();
+			if (dcnt) {                                              // (uniform)
+#pragma unroll
+				for (int u = 0; u < U / 2; u++) if (d[u] != ~0ULL) dt_settle(s_t, tmask, d[u], dstatus);
 				__syncthreads();
-				if (dcnt) {                                              // phase 0 (uniform): the settled positions
-					unsigned char ds[U / 2];
-#pragma unroll
-					for (int u = 0; u < U / 2; u++) ds[u] = d[u] != ~0ULL ? dstatus[CL_X(d[u])] : (unsigned char)SLOT_FAILED;
-#pragma unroll
-					for (int u = 0; u < U / 2; u++)
-						if (ds[u] == SLOT_UNDECIDED) dt_insert<false>(s_t, tmask, cl_fp(cl_mix(CL_POS(d[u]))), DT_SETTLED | (1u << CL_WANT(d[u])));
-					__syncthreads();
-				}
-#pragma unroll
-				for (int u = 0; u < U; u++) if (e[u] != ~0ULL) dt_insert<false>(s_t, tmask, cl_fp(cl_mix(CL_POS(e[u]))), 1u << CL_WANT(e[u]));
-				__syncthreads();
-#pragma unroll
-				for (int u = 0; u < U; u++) if (e[u] != ~0ULL) dt_lookup<false>(s_t, tmask, cl_fp(cl_mix(CL_POS(e[u]))), e[u], status, dfail);
-			} else {
-				__syncthreads();
-				for (int q = threadIdx.x; q < dcnt; q += BT) {
-					const u64 e = dp[q];
-					if (dstatus[CL_X(e)] == SLOT_UNDECIDED) dt_insert<false>(s_t, tmask, cl_fp(cl_mix(CL_POS(e))), DT_SETTLED | (1u << CL_WANT(e)));
-				}
-				__syncthreads();
-				for (int q = threadIdx.x; q < cnt; q += BT) { const u64 e = tp[q]; dt_insert<false>(s_t, tmask, cl_fp(cl_mix(CL_POS(e))), 1u << CL_WANT(e)); }
-				__syncthreads();
-				for (int q = threadIdx.x; q < cnt; q += BT) { const u64 e = tp[q]; dt_lookup<false>(s_t, tmask, cl_fp(cl_mix(CL_POS(e))), e, status, dfail); }
 			}
+#pragma unroll
+			for (int u = 0; u < U; u++) if (e[u] != ~0ULL) dt_lookup(s_t, tmask, e[u], status, dfail);
+		} else {
+			__syncthreads();
+			for (int q = threadIdx.x; q < cnt; q += BT) { const u64 e = tp[q]; dt_insert(s_t, tmask, cl_fp(cl_mix(CL_POS(e))), 1u << CL_WANT(e)); }
+			__syncthreads();
+			for (int q = threadIdx.x; q < dcnt; q += BT) dt_settle(s_t, tmask, dp[q], dstatus);
+			__syncthreads();
+			for (int q = threadIdx.x; q < cnt; q += BT) dt_lookup(s_t, tmask, tp[q], status, dfail);
 		}
 	}
 	// (every thread has read the counters: barriers above, or nothing else happened)

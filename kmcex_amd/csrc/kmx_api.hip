@@ -788,7 +788,7 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 	HIPCHK(hipMemsetAsync(m->bd.dfail, 0, blk, m->stream));
 	HIPCHK(hipMemsetAsync(m->bd.cl_ovf, 0, (u64)nb * 4, m->stream));
 	m->pp = 0; m->pending = false; m->pending_t = 0;
-	m->defer = !m->dbg_no_defer && m->km_byte_size * 8 <= (1ULL << KMX_CL_MIX_BITS);      // position identity inside a detect table is exact up to 2^37
+	m->defer = !m->dbg_no_defer && m->km_byte_size * 8 <= (1ULL << KMX_CL_MIX_BITS);      // position identity inside a detect table is exact up to 2^36
 	// rest accumulators: grown on demand (see ensure_rest_capacity)
 	const u64 want_rest = std::max<u64>(m->n_km / 8, 2 * blk) + blk;
 	if (m->rest_cap < want_rest) {
@@ -1216,10 +1216,6 @@ static int kmx_finish_impl(kmx_model *m)
 		m->state = ST_EMPTY;
 		return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)m->h_stats[ST_BAD_COUNT], m->ci, m->cs);
 	}
-	if (m->h_stats[ST_TABLE_FULL]) {
-		m->state = ST_EMPTY;
-		return fail(KMX_E_STATE, "a claim table overflowed in %llu bins: the model is not exact and is dropped", (unsigned long long)m->h_stats[ST_TABLE_FULL]);
-	}
 	if (m->prof.on) {
 		double before = 0, after = 0;
 		for (int c = 0; c < KC_N; c++) if (c != KC_QUERY) before += m->kc_seconds[c];
@@ -1635,7 +1631,6 @@ static int kmx_shard_local_impl(kmx_model *m, kmx_stats *partial, void **d_rest_
 	HIPCHK(hipMemcpyAsync(&n_rest, m->d_rest_n, 8, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipStreamSynchronize(m->stream));
 	if (m->h_stats[ST_BAD_COUNT]) return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)m->h_stats[ST_BAD_COUNT], m->ci, m->cs);
-	if (m->h_stats[ST_TABLE_FULL]) return fail(KMX_E_STATE, "a claim table overflowed in %llu bins: the model is not exact", (unsigned long long)m->h_stats[ST_TABLE_FULL]);
 	if (m->prof.on) prof_collect(m);
 	memset(partial, 0, sizeof *partial);
 	partial->attempts = m->h_stats[ST_ATTEMPTS]; partial->successes = m->h_stats[ST_SUCCESSES];

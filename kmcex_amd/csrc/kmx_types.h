@@ -74,7 +74,6 @@ struct KmcDecode {
 enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_MAX_U0, ST_MAX_UFIN,
        ST_PIPE_ATTEMPTS, ST_PIPE_SUCC,        // attempts examined / winners committed inside fused commit|check launches (accounting only)
        ST_DELTA_FAILS,                        // candidates of a stale check that a still-uncommitted winner of the previous visit ruled out (k_round_detect)
-       ST_TABLE_FULL,                         // a detect table could not take a bin (never expected; the build fails loudly instead of guessing)
        ST_N };
 
 #define KMX_CLS_TILE 2048                      // k-mers per classification tile (front end)
@@ -130,9 +129,9 @@ struct BlockDev {
 #define KMX_CL_BINS_LOG2(NHM) 8
 #define KMX_CL_BINS(NHM) (1 << KMX_CL_BINS_LOG2(NHM))
 #define KMX_CL_MAXBINS 256
-// a position is identified inside a bin by the rest of a bijective 37-bit mix of it (kernels.hip cl_mix): exact for arrays
-// of up to 2^37 positions (1.5e11 k-mers at nh = 7 would need more) -- beyond that winners are committed before the next check
-#define KMX_CL_MIX_BITS 37
+// a position is identified inside a bin by the rest of a bijective 36-bit mix of it (kernels.hip cl_mix): exact for arrays
+// of up to 2^36 positions (2e10 coupled k-mers at nh = 7) -- beyond that winners are committed before the next check
+#define KMX_CL_MIX_BITS 36
 // tuples per bin: 2^18 * nh / bins at most on average (7168 at nh = 7, 16384 at nh = 16), + 25 % and more
 #ifndef KMX_CL_CAP                             // (tools/stress_small_tables.py builds a library with a tiny capacity: the overflow path every round)
 #define KMX_CL_CAP_OF(NHM) ((NHM) <= 8 ? 12288 : 20480)
