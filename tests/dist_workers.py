@@ -170,6 +170,10 @@ def rccl_worker(rank, world, port, spec, out_dir, q):
         b = cn.clone()
         comm.broadcast(b, 0)
         assert torch.equal(b, cn)
+        # the ring's hand-off (batch_isend_irecv): with one rank, a message sent to itself through RCCL
+        got = torch.zeros_like(km)
+        comm.exchange([(km, 0)], [(got, 0)])
+        assert torch.equal(got, km)
         m = KModel(1, 1023, 7, 5)
         eng = kd.DeviceEngine(m, dev)
         w = cn[:999].clone()                                        # odd length: exercises the padding of the range split

@@ -1,4 +1,4 @@
-"""CPU, world_size 2-3 over gloo: (i) the N>1 plumbing of bench.py (per-rank seeds, batch split, timing/count reduction,
+"""CPU, world_size 2-8 over gloo: (i) the N>1 plumbing of bench.py (per-rank seeds, batch split, timing/count reduction,
 ragged answer gather); (ii) the single-model protocol of kmcex_amd.dist -- routing all-to-all, ring of arrays, OR-merge of
 partial filters, survivor gather -- run for real over gloo with the CPU oracle as the per-rank engine and compared with the
 reference's files (the GPU engine goes through the same orchestration in tests/test_gpu_dist.py)."""
@@ -105,6 +105,8 @@ def test_routing_plan_partitions_the_stream():
     (("synth", "k55_nh9_nb6"), 2),                 # two-word k-mers, 6 arrays on 2 ranks
     (("synth", "k31_multiblock_ci1"), 2),          # 2 full blocks + partial block with unused rows: quirk Q1 across ranks
     (("kmc2", "k31_kmc2_6bins"), 3),               # unsorted listing order
+    (("synth", "tiny_k31"), 8),                    # the shape a whole 8-GPU node runs: 5 arrays on 8 ranks (3 of them route, classify, serve queries)
+    (("synth", "k55_nh9_nb6"), 8),                 # 6 arrays on 8 ranks
 ], ids=lambda v: v[1] if isinstance(v, tuple) else f"w{v}")
 def test_single_model_protocol_with_oracle_engine(spec, world, golden, tmp_path):
     from dist_workers import cpu_worker, run_ranks

@@ -1,8 +1,11 @@
-"""GPU, BASELINE.json's full single-GPU sizes.  configs[1] (10^8 synthetic 31-mers, nh=7 nb=5 ci=1) and configs[2]
-(HC14 scale, 2.5*10^9 31-mers, ci=1 cs=1023): the oracle would take minutes to a quarter of an hour there, so the hot path
-is checked through size-independent properties, and at HC14 scale against array digests pinned from ONE oracle-verified
-run (tests/golden/hc14_scale.json, written by tools/bigscale.py --oracle --golden).  A 2*10^7 build (k=31) and a 2*10^7
-build of configs[4]'s shape (k=55 nh=9 nb=6 cs=4095) are still compared with the oracle byte for byte."""
+"""GPU, BASELINE.json's full sizes.  configs[1] (10^8 synthetic 31-mers, nh=7 nb=5 ci=1), configs[2] (HC14 scale, 2.5*10^9
+31-mers, ci=1 cs=1023) and configs[3] (NA12878 scale, 10^10 31-mers, on ONE GPU: 38 GB of coupled arrays): the oracle would
+take minutes to an hour there, so the hot path is checked through size-independent properties, at HC14 scale against array
+digests pinned from ONE oracle-verified run (tests/golden/hc14_scale.json, written by tools/bigscale.py --oracle --golden),
+and at 10^10 against the deterministic statistics of the sequential algorithm (pinned from round 2's build, reproduced by
+round 3's different kernels) and digests folded ON THE DEVICE (tests/golden/na12878_scale.json).  A 2*10^7 build (k=31) and a
+2*10^7 build of configs[4]'s shape (k=55 nh=9 nb=6 cs=4095) are still compared with the oracle byte for byte; the former also
+pins the device-side digest to the bytes it stands for."""
 import hashlib
 import json
 import os
@@ -22,6 +25,56 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+# ---- digests folded on the device (a 10^10 model holds 38 GB of coupled arrays: nothing of that size is downloaded)
+_MUL = 0x9E3779B97F4A7C15 - (1 << 64)                                 # the 64-bit golden-ratio constant as an int64
+
+
+def _fold_words(t):
+    """sum over i of (word_i + 1) * ((i * M) | 1) mod 2^64 of an int32 device tensor, taken as unsigned 32-bit words"""
+    acc = 0
+    step = 1 << 27
+    for lo in range(0, t.numel(), step):
+        w = t[lo:lo + step].to(torch.int64) & 0xFFFFFFFF
+        idx = torch.arange(lo, lo + w.numel(), dtype=torch.int64, device=t.device)
+        acc = (acc + int(((w + 1) * ((idx * _MUL) | 1)).sum().item())) & 0xFFFFFFFFFFFFFFFF
+    return acc
+
+
+def _fold_words_numpy(words_u32):
+    w = words_u32.astype(np.uint64)
+    idx = np.arange(len(w), dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return int(((w + np.uint64(1)) * ((idx * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1))).sum(dtype=np.uint64))
+
+
+def _cells_numpy(tag_bytes, val_bytes):
+    """the device layout of a coupled array (device_common.h): per 16 positions value16 | tag16 << 16"""
+    def u16(b):
+        b = np.asarray(b, dtype=np.uint8)
+        if len(b) & 1:
+            b = np.concatenate([b, np.zeros(1, np.uint8)])
+        return b.view("<u2").astype(np.uint32)
+    return u16(val_bytes) | (u16(tag_bytes) << np.uint32(16))
+
+
+def _device_digests(m, dev, nb, ncells):
+    """per array: fold of its cells + the tag/value invariant (no value bit without its tag), all on the device"""
+    from kmcex_amd.dist import dev_tensor
+    out = {}
+    for a in range(nb):
+        p, nbytes = m.dev_view("cells", a)
+        cells = dev_tensor(p, nbytes // 4, torch.int32, dev)[:ncells]
+        step = 1 << 28
+        for lo in range(0, ncells, step):
+            c = cells[lo:lo + step]
+            assert not bool(((c & 0xFFFF) & ~((c >> 16) & 0xFFFF)).any()), f"array {a}: a value bit without its tag"
+        out[f"cells{a}"] = "%016x" % _fold_words(cells)
+    for name in ("km_back", "bf", "bf_back"):
+        p, nbytes = m.dev_view(name, 0)
+        out[name] = "%016x" % _fold_words(dev_tensor(p, nbytes // 4, torch.int32, dev))
+    return out
+
+
 def test_twenty_million_build_matches_oracle_bytes():
     dev = torch.device("cuda", 0)
     km, cnt = synth_torch.make_stream(20_000_000, K, CI, CS, dev)
@@ -37,6 +90,11 @@ def test_twenty_million_build_matches_oracle_bytes():
         assert not m.download("claims", a).any()
     assert _sha(m.download("km_back")) == _sha(o.array_bytes("km_back"))
     assert _sha(m.download("bf", 0)) == _sha(o.array_bytes("bf", 0))
+    # the device-side digest used at 10^10 k-mers stands for exactly these bytes
+    ncells = (int(st.km_byte_size) + 1) // 2
+    dd = _device_digests(m, dev, NB, ncells)
+    for a in range(NB):
+        assert dd[f"cells{a}"] == "%016x" % _fold_words_numpy(_cells_numpy(o.array_bytes("tag", a), o.array_bytes("value", a)))
     q = torch.cat([km[::9], synth_torch.random_kmers(200_000, K, 0xABCDEF0123, dev)])
     out = torch.empty(q.numel(), dtype=torch.int32, device=dev)
     m.kmer_to_occ_dev(q.data_ptr(), q.numel(), out.data_ptr())
@@ -154,3 +212,57 @@ def test_hc14_scale_properties():
     assert n == g["n_kmers"]
     assert (st.n_km, st.attempts, st.successes, st.rest_entries) == (g["stats"]["n_km"], g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
     assert digests == g["sha256"]
+
+
+NA12878_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "na12878_scale.json")
+
+
+def test_na12878_scale_properties():
+    """BASELINE configs[3]'s size on ONE GPU: 10^10 synthetic 31-mers, ci=1 cs=1023 nh=7 nb=5 (3.04*10^10 positions per
+    array; 7.6 GB of cells each).  The statistics of the sequential algorithm (attempts, successes, rest rows: every one of
+    them depends on every earlier insert) equal the ones pinned from round 2's build -- different kernels, same numbers --;
+    conservation, the tag/value invariant and the digests of all arrays and filters are taken on the device; encode ->
+    query round trip, strand symmetry and the false-positive bound on samples.  KMX_WRITE_GOLDEN=<file> writes the digests."""
+    dev = torch.device("cuda", 0)
+    if torch.cuda.mem_get_info()[1] < 250 * 2 ** 30:
+        pytest.skip("needs the 288 GB of an MI355X")
+    km, cnt = synth_torch.make_stream(10_000_000_000, K, CI, CS, dev)
+    n = km.numel()
+    torch.cuda.empty_cache()
+    m = KModel(CI, CS, NH, NB)
+    m.build_dev(K, km.data_ptr(), cnt.data_ptr(), n)
+    st = m.stats()
+    assert st.km_byte_size * 8 > 7 * 2 ** 32
+    assert st.successes + st.rest_entries >= st.n_km and st.successes + st.rest_entries - st.n_km < NB
+    assert st.attempts >= st.n_km and st.fast_commits + st.contended >= st.successes
+    digests = _device_digests(m, dev, NB, (int(st.km_byte_size) + 1) // 2)
+    sample = km[:: 100].contiguous()                                     # 10^8 of the inserted k-mers
+    sc = cnt[:: 100].to(torch.int64)
+    out = torch.empty(sample.numel(), dtype=torch.int32, device=dev)
+    m.kmer_to_occ_dev(sample.data_ptr(), sample.numel(), out.data_ptr())
+    torch.cuda.synchronize()
+    assert int((out != 0).sum()) >= sample.numel() - sample.numel() // 200
+    small = sc < 32                                                      # identity zone of OccuBin: exact unless aliased
+    assert int(((out.to(torch.int64) == sc) & small).sum()) > 0.97 * int(small.sum())
+    rc = synth_torch.revcomp(sample[: 5_000_000], K)
+    out2 = torch.empty(rc.numel(), dtype=torch.int32, device=dev)
+    m.kmer_to_occ_dev(rc.data_ptr(), rc.numel(), out2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out[: 5_000_000])
+    absent = synth_torch.random_kmers(5_000_000, K, 0xABCDEF0123, dev)
+    out3 = torch.empty(absent.numel(), dtype=torch.int32, device=dev)
+    m.kmer_to_occ_dev(absent.data_ptr(), absent.numel(), out3.data_ptr())
+    torch.cuda.synchronize()
+    assert int((out3 != 0).sum()) < 0.02 * absent.numel()
+    stats = {"n_km": int(st.n_km), "attempts": int(st.attempts), "successes": int(st.successes), "rest_entries": int(st.rest_entries)}
+    if os.environ.get("KMX_WRITE_GOLDEN"):
+        json.dump({"what": "synth_torch.make_stream(10^10, 31, 1, 1023), nh=7 nb=5 on one MI355X: statistics of the build (equal to round 2's, "
+                           "profiles/r02_na12878_scale_10B.log) and 64-bit folds of the cells / filter words taken on the device (tests/test_gpu_fullsize.py "
+                           "_fold_words; pinned to real bytes by test_twenty_million_build_matches_oracle_bytes).  Not oracle-verified at this size: "
+                           "the CPU oracle needs about an hour and 150 GB here.",
+                   "n_kmers": n, "k": K, "ci": CI, "cs": CS, "nh": NH, "nb": NB, "stats": stats, "fold64": digests}, open(os.environ["KMX_WRITE_GOLDEN"], "w"), indent=1)
+    assert os.path.exists(NA12878_GOLDEN), "tests/golden/na12878_scale.json is missing (KMX_WRITE_GOLDEN=<file> python -m pytest tests/test_gpu_fullsize.py -k na12878)"
+    g = json.load(open(NA12878_GOLDEN))
+    assert n == g["n_kmers"]
+    assert stats == g["stats"]
+    assert digests == g["fold64"]
