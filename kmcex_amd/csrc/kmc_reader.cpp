@@ -119,7 +119,7 @@ bool KmcListing::read_at(uint64_t off, void *dst, size_t bytes) const
 	char *p = (char *)dst;
 	while (bytes) {
 		const ssize_t got = pread(fd_, p, bytes, (off_t)off);
-		if (got <= 0) return false;
+		if (got <= 0) { io_failed_.store(true, std::memory_order_relaxed); return false; }
 		p += got; off += (uint64_t)got; bytes -= (size_t)got;
 	}
 	return true;
@@ -233,13 +233,13 @@ void KmcListing::copy_records(uint64_t rec0, uint64_t n, unsigned char *dst) con
 	for (auto &x : th) x.join();
 }
 
-void KmcListing::count_classes(uint32_t ci, uint32_t cs, int bf_num, uint64_t n_bf[3], uint64_t *out_of_range, uint64_t *not_listed) const
+void KmcListing::count_classes(uint32_t ci, uint32_t cs, int bf_num, uint64_t n_bf[3], uint64_t *out_of_range, uint64_t *not_listed, int threads) const
 {
 	n_bf[0] = n_bf[1] = n_bf[2] = 0;
 	*out_of_range = 0;
 	if (not_listed) *not_listed = 0;
 	if (fd_ < 0) return;
-	const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)threads_, avail_ / 65536 + 1));
+	const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(threads > 0 ? threads : threads_), avail_ / 65536 + 1));
 	std::vector<uint64_t> acc((size_t)T * 8, 0);
 	auto work = [&](int t) {
 		const uint64_t per = (avail_ + T - 1) / T, lo = (uint64_t)t * per, hi = std::min(avail_, lo + per);

@@ -8,6 +8,7 @@
 // a time, so that the host feed is a memcpy-speed loop rather than the reference's per-k-mer string build.
 #pragma once
 #include <cstdint>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -32,8 +33,12 @@ public:
 	// Pass 1 of KModel::init (kmodel.hpp:423-428) without materialising k-mers: number of listed k-mers per count
 	// ci+i (i < bf_num) and the number of listed counts outside [ci, cs].  Does not move the listing cursor.
 	// `not_listed` (optional): records whose count lies outside the header's [min_count, max_count] (ReadNextKmer skips them).
-	void count_classes(uint32_t ci, uint32_t cs, int bf_num, uint64_t n_bf[3], uint64_t *out_of_range, uint64_t *not_listed = nullptr) const;
+	// `threads` (0: as set_threads): the scan is bound by the copy out of the page cache, more threads than a decode wants pay off.
+	void count_classes(uint32_t ci, uint32_t cs, int bf_num, uint64_t n_bf[3], uint64_t *out_of_range, uint64_t *not_listed = nullptr, int threads = 0) const;
 	const std::string &error() const { return err_; }
+	// true once any read of the record file has failed (EIO, a file truncated after open): whatever the calls that hit it
+	// produced must not be used -- next_batch / copy_records / count_classes keep going with stale bytes, the callers check this
+	bool io_failed() const { return io_failed_.load(std::memory_order_relaxed); }
 	// Raw access for a decoder that runs elsewhere (the GPU: k_kmc_decode): fixed-size records [suffix bytes, big-endian |
 	// counter bytes, little-endian], the concatenated LUT(s) with a sentinel (record r belongs to LUT entry idx with
 	// lut[idx] <= r < lut[idx+1]; its prefix is idx & prefix_mask), and a parallel memcpy of a record range.
@@ -53,6 +58,7 @@ private:
 	int fd_ = -1;
 	size_t file_len_ = 0;
 	bool read_at(uint64_t off, void *dst, size_t bytes) const;
+	mutable std::atomic<bool> io_failed_{false};
 	std::vector<unsigned char> stage_;       // raw bytes of the batch next_batch is decoding (host decoder only)
 	std::vector<uint64_t> lut_;      // concatenated LUT(s); lut_[size] sentinel = total
 	uint64_t rec_ = 0, avail_ = 0, total_ = 0, max_count_ = 0, prefix_mask_ = 0;

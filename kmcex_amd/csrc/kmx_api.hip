@@ -1353,7 +1353,7 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 	auto &F = m->feed;
 	std::mutex mu;
 	std::condition_variable cv;
-	bool stop = false;
+	bool stop = false, alloc_done = false;
 	std::thread producer, allocator;
 	auto cleanup = [&] {
 		{ std::lock_guard<std::mutex> lk(mu); stop = true; for (auto &sl : slot) sl.full = false; }
@@ -1393,33 +1393,22 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 		}
 		if (good) good = hipMemcpy(F.d_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
 		if (!good) F.raw_cap = F.dk_cap = 0;                         // whatever is half there is replaced next time
-		ok = good;
+		{ std::lock_guard<std::mutex> lk(mu); ok = good; alloc_done = true; }
+		cv.notify_all();
 	});
-	uint64_t nbf[3] = {0, 0, 0}, bad = 0, not_listed = 0;
-	int rc = KMX_OK;
-	const auto t_p1 = std::chrono::steady_clock::now();
-	db.count_classes((u32)m->ci, (u32)m->cs, m->bf_num, nbf, &bad, &not_listed);      // pass 1 (kmodel.hpp:423-428), counts only
-	const double s_p1 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_p1).count();
-	lap("pass 1 done");
-	allocator.join();
-	lap("buffers ready");
-	if (!ok) return fail(KMX_E_NOMEM, "pinned / device buffers for the listing feed could not be allocated");
-	if (not_listed) gpu_decode = false;
-	if (!gpu_decode && F.km_cap < B * (size_t)W) {                   // host decoder: pinned k-mer / count slots
-		for (int s = 0; s < 2 && !rc; s++) {
-			if (F.km[s]) hipHostFree(F.km[s]);
-			if (F.cnt[s]) hipHostFree(F.cnt[s]);
-			F.km[s] = nullptr; F.cnt[s] = nullptr;
-			if (hipHostMalloc((void **)&F.km[s], B * W * 8) != hipSuccess || hipHostMalloc((void **)&F.cnt[s], B * 4) != hipSuccess) rc = fail(KMX_E_NOMEM, "pinned buffers for the listing feed could not be allocated");
-		}
-		F.km_cap = rc ? 0 : B * (size_t)W;
-	}
-	for (int s = 0; s < 2; s++) { slot[s].raw = F.raw[s]; slot[s].km = F.km[s]; slot[s].cnt = F.cnt[s]; }
-	// the producer fills the two slots in turn: raw records (a parallel memcpy out of the page cache) or, in host mode, decoded k-mers
-	if (!rc)
-		producer = std::thread([&] {
+	// The producer fills the two slots in turn: raw records (a parallel pread out of the page cache) or, in host mode, decoded
+	// k-mers.  In raw mode it needs nothing pass 1 finds out, so it starts as soon as the slots exist and works BESIDE pass 1:
+	// when the class counts are known the first two batches already sit in pinned memory.
+	auto start_producer = [&](bool raw) {
+		producer = std::thread([&, raw] {
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&] { return alloc_done || stop; });
+				if (stop || !ok) return;
+			}
+			for (int s = 0; s < 2; s++) { slot[s].raw = F.raw[s]; slot[s].km = F.km[s]; slot[s].cnt = F.cnt[s]; }
 			uint64_t rec = 0;
-			db.restart();                                                    // kmodel.hpp:430
+			if (!raw) db.restart();                                          // kmodel.hpp:430
 			for (int s = 0;; s ^= 1) {
 				{
 					std::unique_lock<std::mutex> lk(mu);
@@ -1428,7 +1417,7 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 				}
 				size_t got;
 				const uint64_t rec0 = rec;
-				if (gpu_decode) {
+				if (raw) {
 					got = (size_t)std::min<uint64_t>(B, db.records() > rec ? db.records() - rec : 0);
 					if (got) db.copy_records(rec, got, slot[s].raw);
 					rec += got;
@@ -1438,6 +1427,38 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 				if (!got) return;
 			}
 		});
+	};
+	if (gpu_decode) start_producer(true);
+	uint64_t nbf[3] = {0, 0, 0}, bad = 0, not_listed = 0;
+	int rc = KMX_OK;
+	const auto t_p1 = std::chrono::steady_clock::now();
+	// pass 1 (kmodel.hpp:423-428), counts only.  Everything waits for it (the sizes depend on it), and it is a copy out of the
+	// page cache + a scan: it takes as many threads as the machine has to spare beside the producer's
+	const int T1 = hw > 32 ? 32 : T;
+	db.count_classes((u32)m->ci, (u32)m->cs, m->bf_num, nbf, &bad, &not_listed, T1);
+	const double s_p1 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_p1).count();
+	lap("pass 1 done");
+	allocator.join();
+	lap("buffers ready");
+	if (!ok) return fail(KMX_E_NOMEM, "pinned / device buffers for the listing feed could not be allocated");
+	if (not_listed && gpu_decode) {                                  // records outside [min_count, max_count]: only the host decoder skips them
+		{ std::lock_guard<std::mutex> lk(mu); stop = true; }
+		cv.notify_all();
+		producer.join();
+		{ std::lock_guard<std::mutex> lk(mu); stop = false; for (auto &sl : slot) sl = FeedSlot(); }
+		gpu_decode = false;
+	}
+	if (!gpu_decode && F.km_cap < B * (size_t)W) {                   // host decoder: pinned k-mer / count slots
+		for (int s = 0; s < 2 && !rc; s++) {
+			if (F.km[s]) hipHostFree(F.km[s]);
+			if (F.cnt[s]) hipHostFree(F.cnt[s]);
+			F.km[s] = nullptr; F.cnt[s] = nullptr;
+			if (hipHostMalloc((void **)&F.km[s], B * W * 8) != hipSuccess || hipHostMalloc((void **)&F.cnt[s], B * 4) != hipSuccess) rc = fail(KMX_E_NOMEM, "pinned buffers for the listing feed could not be allocated");
+		}
+		F.km_cap = rc ? 0 : B * (size_t)W;
+	}
+	if (!rc && !gpu_decode) start_producer(false);
+	if (!rc && db.io_failed()) rc = fail(KMX_E_IO, "reading %s.kmc_suf failed during pass 1", db_prefix);
 	if (!rc && bad) rc = fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)bad, m->ci, m->cs);
 	if (!rc) rc = kmx_begin(m, k, nbf, db.kmer_count());
 	lap("begin returned");
@@ -1490,6 +1511,7 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 		}
 	}
 	lap("all batches enqueued");
+	if (!rc && db.io_failed()) { rc = fail(KMX_E_IO, "reading %s.kmc_suf failed during pass 2: the model is dropped", db_prefix); m->state = ST_EMPTY; }
 	if (!rc) rc = kmx_finish(m);
 	lap("finish returned");
 	if (!rc) {
@@ -1721,6 +1743,7 @@ static int kmx_kmc_read_impl(const char *db_prefix, uint64_t *kmers, uint32_t *c
 	uint64_t n = 0;
 	for (size_t got; n < capacity && (got = db.next_batch(kmers + n * W, counts + n, (size_t)(capacity - n))) > 0;) n += got;
 	*n_read = n;
+	if (db.io_failed()) return fail(KMX_E_IO, "reading %s.kmc_suf failed", db_prefix);
 	return KMX_OK;
 }
 
