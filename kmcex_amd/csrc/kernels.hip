@@ -1761,7 +1761,7 @@ template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev b
 // A list in flight is a *message* in device memory: u64 header[8] (header[0] = n), BUCKET*W packed k-mers, BUCKET
 // counts.  The receiver starts the next round from a fresh identity list over the message (the reference physically
 // moves its KmerBuff entries in reorder_buffer, so the order of a list is all there is to it).
-template <int W> __global__ __launch_bounds__(256) void k_ring_import(BlockDev bd, int nb, RingLists rl, u64 *stg_kmers, u32 *stg_counts)
+template <int W> __global__ __launch_bounds__(256) void k_ring_import(BlockDev bd, int nb, int pp, RingLists rl, u64 *stg_kmers, u32 *stg_counts)
 {
 	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
 	const RingList e = rl.e[i];
@@ -1778,26 +1778,26 @@ template <int W> __global__ __launch_bounds__(256) void k_ring_import(BlockDev b
 			store_kmer<W>(stg_kmers, row + x, v);
 			stg_counts[row + x] = src_c[x];
 		}
-		bd.list[0][row + x] = (u32)x;
+		bd.list[pp][row + x] = (u32)x;
 	}
 	if (x < (int)KMX_NTILES) { bd.tile_cnt[0][i * KMX_NTILES + x] = 0; bd.tile_cnt[1][i * KMX_NTILES + x] = 0; }
 	if (x == 0) {
-		bd.n[0][i] = n;                                            // lists that are elsewhere in the ring this round are empty here
+		bd.n[pp][i] = n;                                           // lists that are elsewhere in the ring this round are empty here
 		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, nb)] = 0;
 	}
 }
 
-// survivors of the round (list[1], after k_reorder) in list order -> message
-template <int W> __global__ __launch_bounds__(256) void k_ring_export(BlockDev bd, RingLists rl)
+// survivors of the round (list[pp], after k_reorder) in list order -> message
+template <int W> __global__ __launch_bounds__(256) void k_ring_export(BlockDev bd, int pp, RingLists rl)
 {
 	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
 	const RingList e = rl.e[i];
 	if (!e.active || !e.dst_msg) return;
-	const int n = bd.n[1][i];
+	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
 	if (x == 0) e.dst_msg[0] = (u64)n;
 	if (x >= n) return;
-	const u32 idx = list_entry(bd, 1, row, x);
+	const u32 idx = list_entry(bd, pp, row, x);
 	u64 v[W];
 	load_kmer<W>(bd.kmers, row + idx, v);
 	store_kmer<W>(e.dst_msg + KMX_MSG_HDR, (u64)x, v);
@@ -2551,13 +2551,13 @@ void kmc_decode(const KmcDecode &d, int W_, u64 rec0, u64 n, u64 *kmers, u32 *co
 	DISPATCH_W(W_, hipLaunchKernelGGL(k_kmc_decode<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, rec0, n, kmers, counts));
 }
 
-void ring_import(const ModelDev &md, const BlockDev &bd, const RingLists &rl, u64 *stg_kmers, u32 *stg_counts, hipStream_t st)
+void ring_import(const ModelDev &md, const BlockDev &bd, int pp, const RingLists &rl, u64 *stg_kmers, u32 *stg_counts, hipStream_t st)
 {
-	DISPATCH_W(words(md), hipLaunchKernelGGL(k_ring_import<W>, dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, bd, md.nb, rl, stg_kmers, stg_counts));
+	DISPATCH_W(words(md), hipLaunchKernelGGL(k_ring_import<W>, dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, bd, md.nb, pp, rl, stg_kmers, stg_counts));
 }
-void ring_export(const ModelDev &md, const BlockDev &bd, const RingLists &rl, hipStream_t st)
+void ring_export(const ModelDev &md, const BlockDev &bd, int pp, const RingLists &rl, hipStream_t st)
 {
-	DISPATCH_W(words(md), hipLaunchKernelGGL(k_ring_export<W>, dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, bd, rl));
+	DISPATCH_W(words(md), hipLaunchKernelGGL(k_ring_export<W>, dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, bd, pp, rl));
 }
 void or_words(u32 *dst, const u32 *src, u64 n, hipStream_t st)
 {

@@ -38,8 +38,8 @@ void commit_flush(const ModelDev &, const BlockDev &, int, int, hipStream_t, Ker
 void rest_append(const ModelDev &, const BlockDev &, int, int, int, u64 *, int *, unsigned long long *, u64 *, int *, u64 *, hipStream_t);
 void kmback_emit(const ModelDev &, const BlockDev &, const u64 *, const unsigned char *, int, int, int, int, int, const BitScatter &, hipStream_t);
 void bs_apply(const BitScatter &, hipStream_t);
-void ring_import(const ModelDev &, const BlockDev &, const RingLists &, u64 *, u32 *, hipStream_t);
-void ring_export(const ModelDev &, const BlockDev &, const RingLists &, hipStream_t);
+void ring_import(const ModelDev &, const BlockDev &, int, const RingLists &, u64 *, u32 *, hipStream_t);
+void ring_export(const ModelDev &, const BlockDev &, int, const RingLists &, hipStream_t);
 void or_words(u32 *, const u32 *, u64, hipStream_t);
 void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *);
 void query_ascii(const ModelDev &, int, const unsigned char *, int, u64, int *, hipStream_t);
@@ -1610,17 +1610,23 @@ static int kmx_ring_round_dev_impl(kmx_model *m, int t, const kmx_ring_list *lis
 		r.dst_msg = (u64 *)l.dst_msg;
 	}
 	if (t == 0) steer_passes(m);
-	kmxk::ring_import(m->md, m->bd, rl, m->d_stg_kmers, m->d_stg_counts, m->stream);
-	m->pp = 0;                                                    // (ring_import fills list[0]: a rank sees a list for one round)
-	TRY(run_round(m, t, false, nullptr));                         // committed at once: the arrays move on to other lists elsewhere
-	TRY(kmback_emit(m, t, 0, -1, (u64)n_lists * KMX_BUCKET));
+	// The winners of a list commit beside the NEXT round's check on this rank, like in the single-GPU build: arrays are owned
+	// whole, so the list that visits array a in round t+1 is examined by the rank that committed round t on a -- the claims its
+	// detect needs as settled positions are this rank's own (kernels.hip, "A: check + emit claims").
+	// (A rank that had no list in the round before -- the short final block -- was not called for it: what it still owes would
+	// be committed a round late, beside a check whose detect looks for the delta in the wrong list.  Commit it first.)
+	if (m->pending && t != (m->pending_t + 1) % nb) TRY(flush_pending_commit(m));
+	const int pp = m->pp;
+	kmxk::ring_import(m->md, m->bd, pp, rl, m->d_stg_kmers, m->d_stg_counts, m->stream);
+	TRY(run_round(m, t, m->defer, nullptr));
+	TRY(kmback_emit(m, t, pp, -1, (u64)n_lists * KMX_BUCKET));
 	bool any_out = false;
 	for (int i = 0; i < nb; i++) any_out |= rl.e[i].active && rl.e[i].dst_msg;
-	if (any_out) kmxk::ring_export(m->md, m->bd, rl, m->stream);
+	if (any_out) kmxk::ring_export(m->md, m->bd, pp ^ 1, rl, m->stream);
 	for (int i = 0; i < nb; i++)
 		if (rl.e[i].active && !rl.e[i].dst_msg) {
 			TRY(ensure_rest_capacity(m, (u64)KMX_BUCKET + (u64)nb));
-			kmxk::rest_append(m->md, m->bd, 1, i, 1, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream);
+			kmxk::rest_append(m->md, m->bd, pp ^ 1, i, 1, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream);
 		}
 	if (t == nb - 1) m->blocks++;
 	HIPCHK(hipGetLastError());
@@ -1647,6 +1653,7 @@ static int kmx_shard_local_impl(kmx_model *m, kmx_stats *partial, void **d_rest_
 	if (!m || !partial) return fail(KMX_E_ARG, "null argument");
 	if (m->state != ST_BUILDING || !m->ring) return fail(KMX_E_STATE, "shard_local before shard_begin");
 	HIPCHK(hipSetDevice(m->device));
+	TRY(flush_pending_commit(m));                                 // the arrays are about to be read by the caller's broadcasts
 	TRY(kmback_flush(m));
 	unsigned long long n_rest = 0;
 	HIPCHK(hipMemcpyAsync(m->h_stats, m->d_stats, ST_N * 8, hipMemcpyDeviceToHost, m->stream));
