@@ -23,7 +23,12 @@ def agg(tag, c):
     return a
 
 
-res = {"label": label, "unit_note": "FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3; bytes = KiB * 1024", "kernels": {}}
+import os, subprocess
+try:
+    head = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", ".head")).read().strip()   # written before the run (the GPU box has no .git)
+except OSError:
+    head = None
+res = {"label": label, "head": head, "unit_note": "FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3; bytes = KiB * 1024", "kernels": {}}
 f, w = agg("pmc_", "FETCH_SIZE"), agg("pmc_", "WRITE_SIZE")
 mf, mw = agg("pmcmicro_", "FETCH_SIZE"), agg("pmcmicro_", "WRITE_SIZE")
 cal = {}
