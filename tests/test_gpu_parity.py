@@ -298,6 +298,37 @@ def test_finisher_alone_on_filled_arrays_is_timing_independent(monkeypatch):
         monkeypatch.delenv(v)
 
 
+@pytest.mark.parametrize("cfg", [(62, 3, 146, 5, 2, 120000, 834071094, 60), (31, 1, 1023, 7, 5, 3000000, 777, 25), (27, 1, 1023, 8, 4, 700000, 4242, 40)],
+                         ids=lambda c: "k%d_nh%d_nb%d_n%d" % (c[0], c[3], c[4], c[5]))
+def test_deferred_commit_is_timing_independent(cfg, monkeypatch):
+    """The winners of a round commit INSIDE the launch that checks the next round; what that check misses reaches
+    k_round_detect as settled positions.  Whether a particular tag is seen by the racing check or supplied by
+    the delta differs from build to build -- the model must not: the same stream built dozens of times on the production
+    path (tiny arrays where nearly every position a winner tags is claimed again a round later; three blocks; a mid-size
+    case), every build compared with the oracle's arrays, and once with the commits in launches of their own (KMX_PIPE=0)."""
+    import hashlib
+    k, ci, cs, nh, nb, n, seed, reps = cfg
+    km, cnt = synth.make_stream(n, k, ci, cs, seed_k=seed, seed_c=seed + 1)
+    if n <= 700000:
+        cnt = np.maximum(cnt, ci + 3).astype(np.uint32)              # everything into the coupled arrays
+    o = O.OracleModel(ci, cs, nh, nb)
+    o.build(k, km, cnt)
+    so = o.stats()
+    dig = lambda x: hashlib.sha1(np.ascontiguousarray(x).tobytes()).hexdigest()
+    want = [dig(o.array_bytes(w, a)) for a in range(nb) for w in ("tag", "value")] + [dig(o.array_bytes("km_back"))]
+    for it in range(reps + 1):
+        if it == reps:
+            monkeypatch.setenv("KMX_PIPE", "0")
+        m = KModel(ci, cs, nh, nb)
+        m.build_packed(k, km, cnt)
+        st = m.stats()
+        got = [dig(m.download(w, a)) for a in range(nb) for w in ("tag", "value")] + [dig(m.download("km_back"))]
+        assert got == want, f"build {it} differs from the oracle"
+        assert (st.attempts, st.successes, st.rest_entries) == (so.attempts, so.successes, so.rest_entries), f"build {it}"
+        del m
+    monkeypatch.delenv("KMX_PIPE")
+
+
 def test_error_behaviour():
     m = KModel(1, 1023, 7, 5)
     with pytest.raises(api.KmxError):
