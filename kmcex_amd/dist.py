@@ -207,28 +207,36 @@ class Comm:
         out = out.to(local.device) if out.device != local.device else out
         return torch.cat([out[q * width: q * width + int(counts[q])] for q in range(self.world)])
 
-    def or_allreduce(self, words: torch.Tensor, or_into):
+    def or_allreduce(self, words: torch.Tensor, or_into, window: int = 1 << 26):
         """Bitwise OR of `words` (int32, same length on every rank) over the ranks, in place, by position range: an
         all-to-all brings range r of every rank's partial filter to rank r, `or_into(dst, src)` merges them there, an
-        all-gather hands every rank the merged filter (RCCL has no OR reduction)."""
+        all-gather hands every rank the merged filter (RCCL has no OR reduction).  Big slabs go window by window (2^26
+        words = 256 MB at a time), so the temporaries stay a fixed size whatever the model's."""
         if (self.world == 1 and self.shortcut) or words.numel() == 0:
             return
-        P, n = self.world, words.numel()
-        chunk = -(-n // P)
-        pad = torch.zeros(chunk * P, dtype=words.dtype, device=words.device)
-        pad[:n] = words
-        w = self._wire(pad)
-        got = torch.empty_like(w)
-        dist.all_to_all_single(got, w, group=self.group)
-        got = got.to(words.device) if got.device != words.device else got
-        acc = got[:chunk]
-        for q in range(1, P):
-            or_into(acc, got[q * chunk: (q + 1) * chunk])
-        aw = self._wire(acc.contiguous())
-        full = torch.empty(chunk * P, dtype=words.dtype, device=aw.device)
-        dist.all_gather_into_tensor(full, aw, group=self.group)
-        words.copy_(full[:n])
-        self.bytes_sent += 2 * chunk * (P - 1) * words.element_size()
+        P = self.world
+        for lo in range(0, words.numel(), window):
+            part = words[lo:lo + window]
+            n = part.numel()
+            chunk = -(-n // P)
+            if chunk * P == n:
+                pad = part                                           # the all-to-all only reads it
+            else:
+                pad = torch.zeros(chunk * P, dtype=words.dtype, device=words.device)
+                pad[:n] = part
+            w = self._wire(pad)
+            got = torch.empty_like(w)
+            dist.all_to_all_single(got, w, group=self.group)
+            got = got.to(words.device) if got.device != words.device else got
+            acc = got[:chunk]
+            for q in range(1, P):
+                or_into(acc, got[q * chunk: (q + 1) * chunk])
+            aw = self._wire(acc.contiguous())
+            full = pad if (pad is not part and not self.staged) else torch.empty(chunk * P, dtype=words.dtype, device=aw.device)
+            dist.all_gather_into_tensor(full, aw, group=self.group)
+            part.copy_(full[:n])
+            self.bytes_sent += 2 * chunk * (P - 1) * words.element_size()
+            del pad, got, acc, full
 
     def barrier(self):
         if self.world > 1:

@@ -36,6 +36,12 @@ def _worker(rank, world, port, q):
         lo, hi = kd.split_batch(n, world, rank)
         local = torch.arange(lo, hi, dtype=torch.int32) * 10
         full = kd.gather_slices(local, n, world, rank)
+        # OR-merge of partial filters, window by window (ragged last window, a length the ranks do not divide)
+        comm = kd.Comm()
+        words = torch.tensor([(1 << (i % 31)) if (i + rank) % 3 == 0 else 0 for i in range(53)], dtype=torch.int32)
+        want = torch.tensor([(1 << (i % 31)) if (i % 3 == 0 or (i + 1) % 3 == 0) else 0 for i in range(53)], dtype=torch.int32)
+        comm.or_allreduce(words, lambda dst, src: dst.bitwise_or_(src), window=16)
+        assert torch.equal(words, want)
         q.put((rank, t, u, full.tolist(), int(km[0]), len(cnt)))
     finally:
         dist.destroy_process_group()
