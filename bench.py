@@ -183,6 +183,7 @@ def promote_single_model(line, single, world):
         return line
     line["replica_value"], line["replica_ms_per_step"], line["replica_query_value"] = line["value"], line["ms_per_step"], line["query_value"]
     line["value"], line["ms_per_step"], line["query_value"] = single["value"], single["ms_per_build"], single["query_value"]
+    line["replica_query_ms_per_step"], line["query_ms_per_step"] = line["query_ms_per_step"], single["query_ms_per_step"]
     line["steps"] = single["steps"]
     line["value_is"] = "k-mers/s encoded into ONE model by all ranks together (single_model); replica_value = N independent models"
     line["config"]["parallelism"] = (f"one model over {world} ranks: routing all-to-all + ring of whole arrays (min({world}, nb) array owners) + "
@@ -216,7 +217,7 @@ def single_model_leg(a, m, km, cnt, q, out, rank, world, dev, rehearsal, distrib
     return {"what": "ONE model over all ranks' streams: routing all-to-all + ring of arrays (send/recv) + OR-merged filters + array broadcast; queries over replicas",
             "transport": "gloo, ranks sharing one GPU (rehearsal: rates are not xGMI rates)" if rehearsal else ("nccl (RCCL)" if world > 1 else "none (one rank)"),
             "value": n_all * a.single_model_steps / t_b, "unit": "k-mers/s", "ms_per_build": t_b / a.single_model_steps * 1e3, "kmers": n_all,
-            "query_value": nq_all * a.single_model_steps / t_qq, "steps": a.single_model_steps, "scaling": "weak",
+            "query_value": nq_all * a.single_model_steps / t_qq, "query_ms_per_step": t_qq / a.single_model_steps * 1e3, "steps": a.single_model_steps, "scaling": "weak",
             "bytes_exchanged_per_build": sent, "blocks": info["blocks"],
             "stats": {"n_km": st.n_km, "attempts": st.attempts, "successes": st.successes, "rest_entries": st.rest_entries}}
 
