@@ -122,6 +122,16 @@ def list_length(n_km: int, nb: int, b: int, i: int) -> int:
     return int(min(max(n_km - (b * nb + i) * BUCKET, 0), BUCKET))
 
 
+MSG_HDR = 8                                                 # 64-bit words before the k-mers of a ring message (kmx_types.h KMX_MSG_HDR)
+
+
+def ring_msg_pieces(msg: torch.Tensor, n: int, W: int):
+    """the words of a ring message that n survivors occupy: header + n k-mers, and the n 32-bit counts behind the k-mer area"""
+    n = max(0, min(int(n), BUCKET))
+    c0 = MSG_HDR + BUCKET * W
+    return [msg[:MSG_HDR + n * W], msg[c0:c0 + (n + 1) // 2]]
+
+
 # ------------------------------------------------------------------------------------------------ the exchange
 class Comm:
     """The collectives of the sharded build on top of torch.distributed.  Backend "nccl" (RCCL over xGMI) moves device
@@ -179,6 +189,19 @@ class Comm:
             if st is not dst:
                 dst.copy_(st)
         self.bytes_sent += sum(t.numel() * t.element_size() for t, _ in sends)
+
+    def exchange_counted(self, sends, recvs, pieces):
+        """`exchange` for messages whose word 0 says how much of them is in use: the fill counts travel first (one word
+        per message), then only `pieces(msg, n)` -> [contiguous views] of every message.  Reading word 0 waits for the
+        kernels that wrote it, so this form is for the staged transport, which waits for them anyway; over RCCL the ring
+        step stays free of host synchronisation and ships whole buffers."""
+        if not sends and not recvs:
+            return
+        n_out = [int(t[0]) for t, _ in sends]
+        heads = [torch.empty(1, dtype=torch.int64) for _ in recvs]
+        self.exchange([(torch.tensor([n], dtype=torch.int64), d) for n, (_, d) in zip(n_out, sends)], [(h, s) for h, (_, s) in zip(heads, recvs)])
+        self.exchange([(v, d) for n, (t, d) in zip(n_out, sends) for v in pieces(t, n)],
+                      [(v, s) for h, (t, s) in zip(heads, recvs) for v in pieces(t, int(h[0]))])
 
     def broadcast(self, t: torch.Tensor, src: int):
         if self.world == 1 and self.shortcut:
@@ -378,7 +401,10 @@ def build_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: torch.Te
                     recvs.append((msg(i, (t + 1) & 1), own[a]))
             if lists:
                 eng.ring_round(t, lists)
-            comm.exchange(sends, recvs)
+            if comm.staged:
+                comm.exchange_counted(sends, recvs, lambda m, n: ring_msg_pieces(m, n, (k + 31) // 32))
+            else:
+                comm.exchange(sends, recvs)
     # merge: survivors -> every rank; filters OR-merged by range; every array from its owner
     st, rest_km, rest_cnt = eng.local()
     rest_counts = comm.all_gather_ints(int(st.rest_entries), dev)

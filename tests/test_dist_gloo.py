@@ -122,3 +122,16 @@ def test_single_model_protocol_with_oracle_engine(spec, world, golden, tmp_path)
         assert r["sha"] == {f: g["sha256"][f] for f in ("header", "km.bin", "rest.bin")}, f"rank {r['rank']} holds a different model"
         assert r["stats"][2:5] == (g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
     assert res[0]["occ_sha"] == g["occ_sha256"]
+
+
+def test_ring_message_pieces_cover_exactly_the_survivors():
+    """the staged transport ships header + n k-mers + n counts of a ring message, not the 2^18-entry buffer"""
+    for W in (1, 2):
+        msg = torch.arange(kd.MSG_HDR + kd.BUCKET * W + kd.BUCKET // 2, dtype=torch.int64)
+        for n in (0, 1, 2, 7, kd.BUCKET):
+            head, cnt = kd.ring_msg_pieces(msg, n, W)
+            assert head.numel() == kd.MSG_HDR + n * W and int(head[0]) == 0
+            assert cnt.numel() == (n + 1) // 2 and (cnt.numel() == 0 or int(cnt[0]) == kd.MSG_HDR + kd.BUCKET * W)
+            assert head.is_contiguous() and cnt.is_contiguous()
+        assert [p.numel() for p in kd.ring_msg_pieces(msg, -5, W)] == [kd.MSG_HDR, 0]
+        assert sum(p.numel() for p in kd.ring_msg_pieces(msg, kd.BUCKET + 9, W)) == msg.numel()
