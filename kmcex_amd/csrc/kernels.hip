@@ -118,6 +118,60 @@ __device__ __forceinline__ void gather_touches(const ModelDev &md, const Premixe
 		}
 }
 
+// The fused launches are bound by the number of random DRAM operations, and a failing attempt usually fails
+// on one of its first positions: gather md.nh_first positions, and the others only for the lanes none of them refused.
+// Same verdict as gather_touches + touches_conflict (the conflicts are OR-ed, kmodel.hpp:604-610); pos / cell beyond the
+// first group are only defined for lanes that return false.
+// (Hashing the next group while the loads of the current one are in flight -- pinned there with an asm -- changed nothing.)
+template <int W, int NHM> struct StagedGather {
+	const ModelDev &md;
+	const Premixed<W> &pm;
+	const cell_t *cells;
+	int sbase;
+	u32 bin;
+	Touches<NHM> &t;
+	__device__ __forceinline__ void hash(int lo, int hi)
+	{
+#pragma unroll
+		for (int j = 0; j < NHM; j++)
+			if (j >= lo && j < hi) {
+				t.pos[j] = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(sbase + j) & 127]), md.km_mod);
+			}
+	}
+	__device__ __forceinline__ void load(int lo, int hi)
+	{
+#pragma unroll
+		for (int j = 0; j < NHM; j++)
+			if (j >= lo && j < hi) t.cell[j] = cells[t.pos[j] >> 4];
+	}
+	__device__ __forceinline__ bool conflict(int lo, int hi)
+	{
+		bool fail = false;
+#pragma unroll
+		for (int j = 0; j < NHM; j++)
+			if (j >= lo && j < hi) {
+				const u32 b = bit_in_cell(t.pos[j]);
+				fail |= ((u32)(t.cell[j] >> (16 + b)) & 1u) && (((u32)(t.cell[j] >> b) & 1u) != ((bin >> j) & 1u));
+			}
+		return fail;
+	}
+};
+template <int W, int NHM>
+__device__ __forceinline__ bool gather_touches_staged(const ModelDev &md, const Premixed<W> &pm, int a, u32 bin, Touches<NHM> &t)
+{
+	StagedGather<W, NHM> g = {md, pm, md.cells[a], a * md.nh, bin, t};
+	const int j1 = md.nh_first, j2 = md.nh_second, nh = md.nh;
+	g.hash(0, j1);
+	g.load(0, j1);
+	if (g.conflict(0, j1)) return true;
+	g.hash(j1, j2);
+	g.load(j1, j2);
+	if (g.conflict(j1, j2)) return true;
+	g.hash(j2, nh);
+	g.load(j2, nh);
+	return g.conflict(j2, nh);
+}
+
 // insert_to_array's check (kmodel.hpp:604-610): fail iff a set tag carries the other value
 template <int NHM> __device__ __forceinline__ bool touches_conflict(const ModelDev &md, const Touches<NHM> &t, u32 bin)
 {
@@ -553,8 +607,7 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 			load_kmer<W>(bd.kmers, row + idx, v);
 			bin = md.bin_of_occ[bd.counts[row + idx]];
 			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
-			gather_touches<W, NHM, false>(md, pm, a, tc);
-			failed = touches_conflict<NHM>(md, tc, bin);
+			failed = gather_touches_staged<W, NHM>(md, pm, a, bin, tc);
 			status[x] = failed ? SLOT_FAILED : SLOT_UNDECIDED;
 			if (!failed) {
 #pragma unroll

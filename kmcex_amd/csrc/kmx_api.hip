@@ -495,6 +495,14 @@ static void fill_model_dev(kmx_model *m)
 	ModelDev &md = m->md;
 	memset(&md, 0, sizeof md);
 	md.k = m->k; md.nh = m->nh; md.nb = m->nb; md.ci = m->ci; md.cs = m->cs; md.bf_num = m->bf_num;
+	{
+		// a failing attempt usually fails on its first few positions: fetch those first (KMX_NH_FIRST >= nh: all at once)
+		// (measured at nh = 7: 2 + 2 + 3 positions, profiles/r03_experiments_measured_and_rejected.txt)
+		const char *e = hook_env("KMX_NH_FIRST"), *e2 = hook_env("KMX_NH_SECOND");
+		const int f = e ? atoi(e) : (2 * m->nh + 3) / 7, f2 = e2 ? atoi(e2) : (4 * m->nh + 3) / 7;
+		md.nh_first = f < 1 ? 1 : (f > m->nh ? m->nh : f);
+		md.nh_second = f2 < md.nh_first ? md.nh_first : (f2 > m->nh ? m->nh : f2);
+	}
 	md.gfull = make_geom(m->k);
 	md.gback = make_geom(m->k - 2);
 	for (int i = 0; i < 3; i++) {

@@ -5,6 +5,7 @@
 // Everything a kernel needs to address the model in HBM (A.1-A.3 of SURVEY.md).
 struct ModelDev {
 	int k, nh, nb, ci, cs, bf_num;
+	int nh_first, nh_second;                   // the check gathers positions [0, nh_first) first, then [nh_first, nh_second), then the rest -- each group only if no earlier one conflicts
 	StrGeom gfull, gback;                      // geometry of the k-mer and (k-2)-mer strings
 	u32 *bf[3];      ModU64 bf_mod[3];         // Bloom filters, on-disk byte layout (kmodel.hpp:250,253)
 	u32 *bf_back[3]; ModU64 bf_back_mod[3];    // their (k-2)-mer back filters       (kmodel.hpp:251,255)

@@ -233,8 +233,17 @@ def test_both_finisher_paths_bit_exact(cfg, monkeypatch):
     o = O.OracleModel(ci, cs, nh, nb)
     o.build(k, km, cnt)
     so = o.stats()
-    for force_global, nsub0, gather, pipe in ((0, -1, 0, 1), (1, -1, 0, 0), (0, 0, 0, 1), (0, 2, 0, 1), (0, 2, 1, 0), (1, 1, 1, 1), (0, -1, 0, 0)):
+    # KMX_NH_FIRST / KMX_NH_SECOND: the check fetches its nh positions in up to three groups and stops at the first group
+    # with a conflict (default: about 2/7 and 4/7 of nh); nh / nh = all at once, 1 / 2 = one, one, the rest.
+    for force_global, nsub0, gather, pipe, groups in ((0, -1, 0, 1, None), (1, -1, 0, 0, (nh, nh)), (0, 0, 0, 1, (1, 2)), (0, 2, 0, 1, None), (0, 2, 1, 0, (nh - 1, nh)),
+                                                      (1, 1, 1, 1, (1, 1)), (0, -1, 0, 0, None), (0, -1, 0, 1, (nh, nh))):
         monkeypatch.setenv("KMX_PIPE", str(pipe))
+        if groups:
+            monkeypatch.setenv("KMX_NH_FIRST", str(groups[0]))
+            monkeypatch.setenv("KMX_NH_SECOND", str(groups[1]))
+        else:
+            monkeypatch.delenv("KMX_NH_FIRST", raising=False)
+            monkeypatch.delenv("KMX_NH_SECOND", raising=False)
         monkeypatch.setenv("KMX_FIN_GLOBAL", str(force_global))
         monkeypatch.setenv("KMX_NSUB0", str(nsub0))
         monkeypatch.setenv("KMX_NSUB1", str(nsub0))
@@ -245,8 +254,8 @@ def test_both_finisher_paths_bit_exact(cfg, monkeypatch):
         _check_arrays(m, o, nb, st.bf_num)
         assert (st.attempts, st.successes, st.rest_entries) == (so.attempts, so.successes, so.rest_entries)
         assert st.contended > 0
-    for v in ("KMX_FIN_GLOBAL", "KMX_NSUB0", "KMX_NSUB1", "KMX_RESOLVE_GATHER", "KMX_PIPE"):
-        monkeypatch.delenv(v)
+    for v in ("KMX_FIN_GLOBAL", "KMX_NSUB0", "KMX_NSUB1", "KMX_RESOLVE_GATHER", "KMX_PIPE", "KMX_NH_FIRST", "KMX_NH_SECOND"):
+        monkeypatch.delenv(v, raising=False)
 
 
 @pytest.mark.parametrize("cfg", [(31, 1, 1023, 7, 5, 3000000), (40, 3, 4095, 9, 4, 600000), (27, 1, 1023, 6, 3, 2500000)], ids=lambda c: "k%d_ci%d_nh%d_n%d" % (c[0], c[1], c[3], c[5]))

@@ -29,8 +29,9 @@ while time.time() - t0 < budget:
     km, cnt = synth.make_stream(n, k, ci, cs, seed_k=seed, seed_c=seed + 1)
     if rng.random() < 0.6: cnt = np.maximum(cnt, ci + 3).astype(np.uint32)     # everything into the coupled arrays
     o.build(k, km, cnt); so = o.stats()
-    for env in [HOOKS[int(rng.integers(0, len(HOOKS)))], HOOKS[0]]:
-        for v in ("KMX_NSUB0", "KMX_NSUB1", "KMX_FIN_GLOBAL", "KMX_RESOLVE_GATHER", "KMX_KMB_DIRECT", "KMX_PIPE", "KMX_KMB_HOST"): os.environ.pop(v, None)
+    g1 = int(rng.integers(1, nh + 1)); g2 = int(rng.integers(g1, nh + 1))       # groups the check fetches its positions in (forced path only)
+    for env in [dict(HOOKS[int(rng.integers(0, len(HOOKS)))], KMX_NH_FIRST=str(g1), KMX_NH_SECOND=str(g2)), HOOKS[0]]:
+        for v in ("KMX_NSUB0", "KMX_NSUB1", "KMX_FIN_GLOBAL", "KMX_RESOLVE_GATHER", "KMX_KMB_DIRECT", "KMX_PIPE", "KMX_KMB_HOST", "KMX_NH_FIRST", "KMX_NH_SECOND"): os.environ.pop(v, None)
         os.environ.update(env)
         m = KModel(ci, cs, nh, nb); m.build_packed(k, km, cnt); st = m.stats()
         tag = (k, ci, cs, nh, nb, n, seed, env)
