@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): tools/pmc_run.sh <tag>
+# usage (on the GPU box, from the repo root): KMX_GIT_HEAD=<commit> tools/pmc_run.sh <tag>
 # HBM traffic per kernel from rocprofv3 PMC counters, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
 # WRITE_SIZE in SEPARATE passes, nothing else traced; the absolute scale is calibrated on kmx_microbench kernels with a
 # known touch count under the same counters (tools/pmc_summary.py).  -> gpurun_out/<tag>_pmc_traffic.json

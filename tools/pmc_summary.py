@@ -23,11 +23,8 @@ def agg(tag, c):
     return a
 
 
-import os, subprocess
-try:
-    head = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", ".head")).read().strip()   # written before the run (the GPU box has no .git)
-except OSError:
-    head = None
+import os
+head = os.environ.get("KMX_GIT_HEAD") or None      # the GPU box has no .git: gpurun -- "KMX_GIT_HEAD=$(git rev-parse --short HEAD) tools/pmc_run.sh <tag>"
 res = {"label": label, "head": head, "unit_note": "FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3; bytes = KiB * 1024", "kernels": {}}
 f, w = agg("pmc_", "FETCH_SIZE"), agg("pmc_", "WRITE_SIZE")
 mf, mw = agg("pmcmicro_", "FETCH_SIZE"), agg("pmcmicro_", "WRITE_SIZE")
