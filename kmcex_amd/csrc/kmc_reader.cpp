@@ -245,7 +245,7 @@ void KmcListing::count_classes(uint32_t ci, uint32_t cs, int bf_num, uint64_t n_
 		const uint64_t per = (avail_ + T - 1) / T, lo = (uint64_t)t * per, hi = std::min(avail_, lo + per);
 		uint64_t a[5] = {0, 0, 0, 0, 0};
 		const uint32_t cnt_mask = counter_size_ == 4 ? 0xFFFFFFFFu : ((1u << (8 * counter_size_)) - 1);
-		const uint64_t chunk = (4u << 20) / rec_bytes_;                      // records per read: ~4 MB
+		const uint64_t chunk = std::max<uint64_t>(1, (256u << 10) / rec_bytes_);   // records per read: ~256 KB, so that the scan finds in this core's L2 what pread just copied there
 		std::vector<unsigned char> buf(chunk * rec_bytes_ + 8);
 		for (uint64_t r0 = lo; r0 < hi; r0 += chunk) {
 			const uint64_t nr = std::min(chunk, hi - r0);
