@@ -489,9 +489,11 @@ __global__ __launch_bounds__(256) void k_block_init(BlockDev bd, int nb, int pp,
 // winners, which k_round_detect enters into its tables as SETTLED positions before it looks at this round's claims.
 // For that the identity of a position inside a table must be exact: bin and fingerprint are the two halves of ONE
 // bijective mix of the position (36 bits: arrays of up to 2^36 positions; above that the host commits before it checks).
+// A tuple carries the position in its MIXED form (cl_mix below: bin = top 8 bits, fingerprint = the rest), computed once by
+// the producer: k_round_detect spent half its time re-deriving it (two 64-bit multiplies per tuple and phase, 10^7 per launch).
 #define CL_POS_BITS 44
-#define CL_TUPLE(pos, want, x) ((u64)(pos) | ((u64)(want) << CL_POS_BITS) | ((u64)(x) << (CL_POS_BITS + 1)))
-#define CL_POS(tp) ((tp) & ((1ULL << CL_POS_BITS) - 1))
+#define CL_TUPLE(mixed, want, x) ((u64)(mixed) | ((u64)(want) << CL_POS_BITS) | ((u64)(x) << (CL_POS_BITS + 1)))
+#define CL_MIXED(tp) ((tp) & ((1ULL << CL_POS_BITS) - 1))
 #define CL_WANT(tp) ((u32)((tp) >> CL_POS_BITS) & 1u)
 #define CL_X(tp) ((u32)((tp) >> (CL_POS_BITS + 1)) & (KMX_BUCKET - 1))
 #define CL_MIX_BITS KMX_CL_MIX_BITS
@@ -642,13 +644,15 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 		if (um) {
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
-				if (j < md.nh && ((um >> j) & 1u))
-					s_tup[s_off[cl_bin(cl_mix(tc.pos[j]))] + rank[j]] = CL_TUPLE(tc.pos[j], (bin >> j) & 1u, x);
+				if (j < md.nh && ((um >> j) & 1u)) {
+					const u64 mx = cl_mix(tc.pos[j]);
+					s_tup[s_off[cl_bin(mx)] + rank[j]] = CL_TUPLE(mx, (bin >> j) & 1u, x);
+				}
 		}
 		__syncthreads();
 		for (int q = threadIdx.x; q < total; q += 256) {               // consecutive lanes, consecutive tuples of a run
 			const u64 tp = s_tup[q];
-			const u32 b = cl_bin(cl_mix(CL_POS(tp)));
+			const u32 b = cl_bin(CL_MIXED(tp));
 			const int g = s_base[b] + (q - s_off[b]);
 			if (g < CAP) tup[(u64)b * CAP + g] = tp;
 			else bd.cl_ovf[i] = 1;                                     // the whole list takes the ordered path this round
@@ -697,12 +701,12 @@ __device__ __forceinline__ int dt_find(const u32 *s_t, u32 tmask, u32 fp)
 }
 __device__ __forceinline__ void dt_settle(u32 *s_t, u32 tmask, u64 d, const unsigned char *dstatus)
 {
-	const int slot = dt_find(s_t, tmask, cl_fp(cl_mix(CL_POS(d))));
+	const int slot = dt_find(s_t, tmask, cl_fp(CL_MIXED(d)));
 	if (slot >= 0 && dstatus[CL_X(d)] == SLOT_UNDECIDED) atomicOr(&s_t[slot], DT_SETTLED(CL_WANT(d)));
 }
 __device__ __forceinline__ void dt_lookup(const u32 *s_t, u32 tmask, u64 e, unsigned char *status, unsigned char *dfail)
 {
-	const u32 fp = cl_fp(cl_mix(CL_POS(e)));
+	const u32 fp = cl_fp(CL_MIXED(e));
 	u32 slot = fp & tmask, cur;
 	while (((cur = s_t[slot]) >> 4) != fp) slot = (slot + 1) & tmask;  // (it was inserted in phase 1)
 	const u32 w = CL_WANT(e);
@@ -743,7 +747,7 @@ void k_round_detect(BlockDev bd, int nb, int pp, int use_delta, int keep_own)
 			for (int u = 0; u < U / 2; u++) { const int q = u * BT + (int)threadIdx.x; d[u] = q < dcnt ? dp[q] : ~0ULL; }
 			__syncthreads();
 #pragma unroll
-			for (int u = 0; u < U; u++) if (e[u] != ~0ULL) dt_insert(s_t, tmask, cl_fp(cl_mix(CL_POS(e[u]))), 1u << CL_WANT(e[u]));
+			for (int u = 0; u < U; u++) if (e[u] != ~0ULL) dt_insert(s_t, tmask, cl_fp(CL_MIXED(e[u])), 1u << CL_WANT(e[u]));
 			__syncthreads();
 			if (dcnt) {                                              // (uniform)
 #pragma unroll
@@ -754,7 +758,7 @@ void k_round_detect(BlockDev bd, int nb, int pp, int use_delta, int keep_own)
 			for (int u = 0; u < U; u++) if (e[u] != ~0ULL) dt_lookup(s_t, tmask, e[u], status, dfail);
 		} else {
 			__syncthreads();
-			for (int q = threadIdx.x; q < cnt; q += BT) { const u64 e = tp[q]; dt_insert(s_t, tmask, cl_fp(cl_mix(CL_POS(e))), 1u << CL_WANT(e)); }
+			for (int q = threadIdx.x; q < cnt; q += BT) { const u64 e = tp[q]; dt_insert(s_t, tmask, cl_fp(CL_MIXED(e)), 1u << CL_WANT(e)); }
 			__syncthreads();
 			for (int q = threadIdx.x; q < dcnt; q += BT) dt_settle(s_t, tmask, dp[q], dstatus);
 			__syncthreads();
