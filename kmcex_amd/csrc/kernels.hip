@@ -1156,7 +1156,6 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 	// the n records are Urec[lv][s_list[0..n)], or Urec[lv][0..n) when s_list is null; the tables are empty on entry and on exit
 	const u64 row = (u64)i * KMX_BUCKET;
 	cell_t *cells = md.cells[a];
-	const int sbase = a * md.nh;
 	u32 x[RPT], bin[RPT], rec[RPT], um[RPT], ghost[RPT], cidx[RPT][NHM];   // ghost: won, but these positions are not published yet
 	u64 bits[RPT];                                                   // bit_in_cell of position j in nibble j
 	bool live[RPT], won[RPT];
@@ -1172,16 +1171,15 @@ __device__ __forceinline__ u64 finish_lds(const ModelDev &md, const BlockDev &bd
 			rec[r] = s_list ? s_list[slot] : (u32)slot;
 			u64 v[W];
 			um[r] = rec_load<W>(bd.Urec[lv], row + rec[r], x[r], bin[r], v);    // every record of the finisher's level is undecided
-			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
+			// the positions: what check_emit left for the slot (every record is a candidate of this round's check) -- no hashing
+			const CRec<NHM> cr = crec_load<NHM>(bd.crec[pp] + (row + x[r]) * (u64)crec_words(md.nh), md.nh);
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
 				if (j < md.nh) {
-					const u64 pos = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(sbase + j) & 127]), md.km_mod);
-					cidx[r][j] = (u32)(pos >> 4);
-					bits[r] |= (u64)bit_in_cell(pos) << (4 * j);
+					cidx[r][j] = crec_cell<NHM>(cr, j);
+					bits[r] |= (u64)bit_of_nibble(crec_nib<NHM>(cr, md.nh, j)) << (4 * j);
 				}
 		}
-		__builtin_amdgcn_sched_barrier(0);                           // one record's hashes at a time
 	}
 #define FIN_BIT(r, j) ((u32)(bits[r] >> (4 * (j))) & 15u)
 #define FIN_Q(r, j) (((u64)cidx[r][j] << 4) | FIN_BIT(r, j))
