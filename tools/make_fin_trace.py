@@ -13,9 +13,9 @@ rep("template <int W, int NHM, int RPT>\n__device__ __forceinline__ u64 finish_l
     "template <int W, int NHM, int RPT>\n__device__ __forceinline__ u64 finish_lds(")
 rep("#define FIN_BIT(r, j) ((u32)(bits[r] >> (4 * (j))) & 15u)", "TR(3);\n#define FIN_BIT(r, j) ((u32)(bits[r] >> (4 * (j))) & 15u)")
 rep("	int succ = 0;\n	u64 iters = 0;\n	for (;; iters++) {\n		const int par = (int)(iters % 3), par_next", "	TR(7);\n	int succ = 0;\n	u64 iters = 0;\n	for (;; iters++) {\n		const int par = (int)(iters % 3), par_next")
-rep("		if (threadIdx.x == 0) s_pending[par_next] = 0;               // last read two iterations ago\n		__syncthreads();",
-    "		if (threadIdx.x == 0) s_pending[par_next] = 0;               // last read two iterations ago\n		__syncthreads();\nTR(4);")
-rep("		__syncthreads();\n		if (!s_pending[par]) break;", "		__syncthreads();\nTR(5);\n		if (!s_pending[par]) break;")
+rep("		if (threadIdx.x == 0) s_pending[par_next] = 0;               // last read two iterations ago\n		lds_barrier();",
+    "		if (threadIdx.x == 0) s_pending[par_next] = 0;               // last read two iterations ago\n		lds_barrier();\nTR(4);")
+rep("		lds_barrier();\n		if (!s_pending[par]) break;", "		lds_barrier();\nTR(5);\n		if (!s_pending[par]) break;")
 rep("	constexpr int CAP = RPT * 1024;\n	const u64 row = (u64)i * KMX_BUCKET;\n",
     "	constexpr int CAP = RPT * 1024;\n	const u64 row = (u64)i * KMX_BUCKET;\n	if (threadIdx.x == 0 && blockIdx.x == 0) g_trn = 0;\n	TR(1);\n")
 rep("				if (cnt <= CAP) break;\n", "				TR(6);\n				if (cnt <= CAP) break;\n")
