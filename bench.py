@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="k-mers of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-init-db", action="store_true", help="skip the KModel::init(database) leg")
+    ap.add_argument("--no-query-strings", action="store_true", help="skip the kmer_to_occ(vector<string>) leg")
     ap.add_argument("--no-single-model", action="store_true", help="skip the one-model-over-all-ranks leg")
     ap.add_argument("--single-model-steps", type=int, default=0, help="0: --steps when N > 1 (it is the headline there), 2 at N = 1")
     return ap.parse_args()
@@ -110,6 +111,47 @@ def init_db_leg(a, km, cnt, reps=3):
                 "init_db_attempts": st.attempts, "init_db_bytes": os.path.getsize(db + ".kmc_suf")}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def source_digest():
+    """sha256 over the library's sources: the PMC file carries the digest of the code its counters were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "kmcex_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "kmx.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def query_strings_leg(a, m, q, out, reps=3):
+    """The reference's only batch query API, kmer_to_occ(vector<string>) (kmodel.hpp:90-98), end to end: n separate host
+    strings in, answers in a host array out (kmx_query_strings: worker threads pack chunks into pinned slots, hipMemcpyAsync
+    both ways under the kernel of the chunk before).  Wall clock; the strings are built once, outside the timed region."""
+    import ctypes as C
+    k, nq = a.k, q.numel()
+    rows = torch.zeros((nq, 32), dtype=torch.uint8, device=q.device)     # 31 characters + NUL: what a std::string's buffer holds
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=q.device)
+    for pos in range(k):
+        rows[:, pos] = lut[((q >> (2 * (k - 1 - pos))) & 3)]
+    host = rows.cpu().numpy()
+    del rows
+    ptrs = (host.ctypes.data + np.arange(nq, dtype=np.uint64) * np.uint64(32)).astype(np.uint64)
+    ans = np.zeros(nq, dtype=np.int32)
+    ts = []
+    for _ in range(reps + 1):                                            # first call allocates the pinned slots: warm-up
+        t0 = time.perf_counter()
+        rc = m.L.kmx_query_strings(m.h, C.cast(ptrs.ctypes.data, C.POINTER(C.c_char_p)), k, nq, ans.ctypes.data)
+        ts.append(time.perf_counter() - t0)
+        if rc != 0:
+            raise RuntimeError(f"kmx_query_strings: {rc}")
+    same = bool(np.array_equal(ans, out.cpu().numpy()))                 # against the packed device-resident query of the same k-mers
+    mean = sum(ts[1:]) / reps
+    return {"query_strings_value": nq / mean, "query_strings_ms": mean * 1e3, "query_strings_best_ms": min(ts[1:]) * 1e3,
+            "query_strings_reps": reps, "query_strings_equal_packed_answers": same, "query_strings_host_cpus": len(os.sched_getaffinity(0)),
+            "query_strings_what": f"kmx_query_strings = kmer_to_occ(vector<string>): {nq} separate host strings in, host int32 out, wall clock"}
 
 
 def sync_all(distributed):
@@ -179,7 +221,14 @@ def headline(a, world, n, q, n_all, nq_all, t_ins, t_q, st, roof, cpu, extra, in
 def promote_single_model(line, single, world):
     """N > 1: the headline is the ONE model the N ranks build together; the N independent models become `replica_value`."""
     line["single_model"] = single
-    if world == 1 or not single or "value" not in single:
+    if world == 1 or single is None:                             # N = 1, or the leg was switched off (--no-single-model)
+        return line
+    if "value" not in single:
+        # the leg failed: the headline (ONE model) was NOT measured -- the replicas' rate must not stand in for it
+        line["replica_value"], line["replica_ms_per_step"], line["replica_query_value"] = line["value"], line["ms_per_step"], line["query_value"]
+        line["value"], line["ms_per_step"], line["query_value"] = None, None, None
+        line["value_is"] = "NOT MEASURED: the single-model leg failed (single_model.error); replica_value = N independent models"
+        line["failed"] = True
         return line
     line["replica_value"], line["replica_ms_per_step"], line["replica_query_value"] = line["value"], line["ms_per_step"], line["query_value"]
     line["value"], line["ms_per_step"], line["query_value"] = single["value"], single["ms_per_build"], single["query_value"]
@@ -338,7 +387,10 @@ def main():
         kname = {"check": "k_round_check_emit<", "commit": "k_round_commit<", "commit_check": "k_round_commit_check<", "classify": "k_classify_count"}.get(dom)
         if a.n == 100_000_000 and (a.k, a.nh, a.nb, a.ci, a.cs) == (31, 7, 5, 1, 1023) and os.path.exists(pmc_file) and kname:
             pm = json.load(open(pmc_file))
-            traffic_head = pm.get("head")                          # the commit the counters were taken at (staleness is visible in the line)
+            traffic_head = pm.get("head")                          # the commit the counters were taken at
+            if pm.get("src_sha") != source_digest():               # counters of other code say nothing about this run: traffic stays null
+                traffic_src = f"stale: {os.path.basename(pmc_file)} was taken on sources {pm.get('src_sha')}, this run is {source_digest()}"
+                pm = {"kernels": {}}
             for kn, kv in pm["kernels"].items():
                 if kn.startswith(kname):
                     traffic, traffic_src = kv["hbm_bytes_per_launch"], "profiles/pmc_traffic_default_workload.json"
@@ -349,6 +401,14 @@ def main():
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                 "traffic": traffic, "traffic_source": traffic_src, "traffic_head": traffic_head, "alg_bytes_per_launch": per_launch,
                 "avg_launch_us": classes[dom]["avg_launch_us"], "launches": dv["launches"]}
+        if dom == "commit_check":
+            # what the fused launches actually ISSUED (device counters): the staged fetch stops at the first conflicting group and a
+            # winner sets only the positions it saw untagged -- priced like the formula at G bytes per random operation
+            issued = (st.piped_gathers + st.piped_atomics) * G + Ap * W8
+            roof["issued_frac"] = issued / (dv["seconds"] / a.steps) / 8e12
+            roof["issued"] = {"gathers_per_step": st.piped_gathers, "atomics_per_step": st.piped_atomics,
+                              "random_ops_per_s": (st.piped_gathers + 2 * st.piped_atomics) / (dv["seconds"] / a.steps),
+                              "note": "random_ops_per_s counts an atomic as a read and a write at the DRAM (DESIGN.md 4: one budget of ~56 G/s)"}
         # the random-access ceiling of this chip for 8-byte touches over a footprint like the coupled arrays'
         foot = max(int(st.km_byte_size) * 2 * a.nb, 1 << 26)              # the cells of all arrays (4 bytes per 16 positions)
         tg = api.microbench(8, foot, 1 << 27, 3)                           # 4-byte random loads: what check_emit issues
@@ -373,6 +433,13 @@ def main():
             init_db = init_db_leg(a, km, cnt)
         except Exception as e:  # noqa: BLE001
             init_db = {"init_db_error": repr(e)}
+    if rank == 0 and world == 1 and not a.no_query_strings and a.k <= 31:
+        try:
+            query_step()
+            torch.cuda.synchronize()
+            init_db.update(query_strings_leg(a, m, q, out))
+        except Exception as e:  # noqa: BLE001
+            init_db["query_strings_error"] = repr(e)
     # ---- ONE model over all ranks' streams; a watchdog ends the job with what is measured if the exchange hangs
     single = None
     if not a.no_single_model:
@@ -406,12 +473,15 @@ def main():
             cpu = cpu_baseline(a)
         except Exception as e:  # noqa: BLE001
             cpu = {"error": repr(e)}
+    failed = world > 1 and single is not None and "value" not in single
     if rank == 0:
         line = headline(a, world, n, q, n_all, nq_all, t_ins, t_q, st, roof, cpu, extra, init_db)
         print(json.dumps(promote_single_model(line, single, world)), flush=True)
     if distributed:
         dist.barrier()                      # rank 0 may still have been in its roofline leg: leave together
         dist.destroy_process_group()
+    if failed:
+        sys.exit(3)                         # like the watchdog: a failed exchange is a failed run, on every rank
 
 
 if __name__ == "__main__":

@@ -78,14 +78,26 @@ public:
 		std::vector<int> occ_v(n);
 		if (!n) return occ_v;
 		static_assert(sizeof(int) == sizeof(int32_t), "int is 32 bits on every supported target");
-		// the reference answers every string on its own, whatever its length: batch the strings of equal length
+		// the reference answers every string on its own, whatever its length.  One length (the usual batch): the strings
+		// go to the library as they lie, and it cuts them into chunks that worker threads pack while the GPU answers the
+		// chunk before (kmx_query_strings).  Mixed lengths: one such call per length.
+		const size_t len0 = kmer_v[0].size();
+		bool uniform = true;
+		for (size_t i = 1; i < n && uniform; i++) uniform = kmer_v[i].size() == len0;
+		std::vector<const char *> ptrs;
+		if (uniform) {
+			ptrs.resize(n);
+			for (size_t i = 0; i < n; i++) ptrs[i] = kmer_v[i].data();
+			check(kmx_query_strings(h_, ptrs.data(), (int)len0, n, (int32_t *)occ_v.data()));
+			return occ_v;
+		}
 		std::vector<size_t> order(n);
 		for (size_t i = 0; i < n; i++) order[i] = i;
 		std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return kmer_v[a].size() < kmer_v[b].size(); });
 		for (size_t lo = 0; lo < n;) {
 			const size_t len = kmer_v[order[lo]].size();
 			size_t hi = lo;
-			std::vector<const char *> ptrs;
+			ptrs.clear();
 			while (hi < n && kmer_v[order[hi]].size() == len) ptrs.push_back(kmer_v[order[hi++]].data());
 			std::vector<int32_t> part(hi - lo);
 			check(kmx_query_strings(h_, ptrs.data(), (int)len, hi - lo, part.data()));

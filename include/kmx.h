@@ -53,6 +53,8 @@ typedef struct kmx_stats {
 	uint64_t rest_bytes;      /* KRestData::get_all_byte_size (rest.hpp:257-259)                */
 	uint64_t piped_attempts;  /* attempts examined / successes committed inside the fused commit|check launches   */
 	uint64_t piped_commits;   /* of the big rounds (accounting for the per-kernel roofline only)                   */
+	uint64_t piped_gathers;   /* random 4-byte loads / 32-bit atomic ORs those launches actually ISSUED: the check     */
+	uint64_t piped_atomics;   /* stops at the first conflicting group, a winner sets only its untagged positions      */
 } kmx_stats;
 
 const char *kmx_last_error(void);
@@ -152,6 +154,11 @@ int kmx_debug_hash(int k, const uint64_t *kmers, uint64_t n, const uint32_t *see
 int kmx_debug_min_kmer(int k, const uint64_t *kmers, uint64_t n, uint64_t *out);
 /* out[i] = h[i] % d with the device's exact reciprocal modulo (`% length`, kmodel.hpp:378,503,600,633), d up to 2^63 */
 int kmx_debug_mod(const uint64_t *h, uint64_t n, uint64_t d, uint64_t *out);
+/* Host half of kmx_query_strings / kmx_query_ascii, on its own (no device needed): strings -> packed k-mers
+ * (2 bits per base, first base most significant, ceil(len/32) words each, tools.hpp:63-76).  strs != NULL: n separate
+ * strings; else n records of `stride` bytes in `flat`.  *clean = 0 when a string holds anything but ACGT (such a
+ * batch travels as bytes and is answered by the byte-string kernel).                                */
+int kmx_debug_pack_strings(const char *const *strs, const char *flat, int len, int stride, uint64_t n, uint64_t *packed, int *clean);
 /* OccuBin tables (occu_bin.hpp:27-83): bin_of_occ[cs+1], mean_of_bin[2^nh]                         */
 int kmx_occubin(int cs, int nh, uint32_t *bin_of_occ, uint32_t *mean_of_bin);
 
@@ -166,9 +173,11 @@ int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double
 
 /* Per-kernel-class timing with HIP events recorded on the model's stream around each launch (off by default).
  * classes: 0 classify(+Bloom insert) 1 check (+ claim emission) 2 commit 3 ordered slow path 4 reorder 5 rest append 6 query
- * 7 detect (opposite claims) 8 commit of one group of lists beside the check of the next (the pipelined big rounds).
- * seconds[9], launches[9] accumulate until reset.                                                            */
+ * 7 detect (opposite claims) 8 commit of the previous round beside the check of the next (k_round_commit_check)
+ * 9 file (k_round_file).  seconds[KMX_KERNEL_CLASSES], launches[KMX_KERNEL_CLASSES] accumulate until reset: a caller
+ * must size both arrays with the macro of the header it was compiled against and check kmx_kernel_classes() == it.  */
 #define KMX_KERNEL_CLASSES 10
+int kmx_kernel_classes(void);           /* what this library writes: KMX_KERNEL_CLASSES of ITS header */
 int kmx_set_profile(kmx_model *m, int on);
 int kmx_get_kernel_times(kmx_model *m, double *seconds, uint64_t *launches, int reset);
 

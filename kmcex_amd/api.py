@@ -31,7 +31,8 @@ class Stats(C.Structure):
                 ("blocks", C.c_uint64), ("rounds", C.c_uint64),
                 ("k", C.c_int32), ("ci", C.c_int32), ("cs", C.c_int32), ("nh", C.c_int32), ("nb", C.c_int32),
                 ("bf_num", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32), ("rest_bytes", C.c_uint64),
-                ("piped_attempts", C.c_uint64), ("piped_commits", C.c_uint64)]
+                ("piped_attempts", C.c_uint64), ("piped_commits", C.c_uint64),
+                ("piped_gathers", C.c_uint64), ("piped_atomics", C.c_uint64)]
 
 
 # every symbol include/kmx.h declares (tests check that the library exports all of them)
@@ -43,6 +44,7 @@ ABI_SYMBOLS = [
     "kmx_set_profile", "kmx_get_kernel_times", "kmx_kmc_info", "kmx_kmc_read", "kmx_debug_mod",
     "kmx_count_classes_dev", "kmx_shard_begin", "kmx_shard_classify_dev", "kmx_ring_msg_bytes", "kmx_ring_round_dev",
     "kmx_ring_stale_dup_dev", "kmx_shard_local", "kmx_shard_complete", "kmx_dev_view", "kmx_or_words_dev",
+    "kmx_debug_pack_strings", "kmx_kernel_classes",
 ]
 
 
@@ -65,6 +67,9 @@ def load_library():
         return _lib
     # a specially built variant (tools/stress_small_tables.py): a test hook like the library's own, honoured only with KMX_TEST_HOOKS=1
     path = os.environ.get("KMX_LIBRARY") if os.environ.get("KMX_TEST_HOOKS") == "1" else None
+    if os.environ.get("KMX_LIBRARY") and path is None:
+        # results must not be taken for the variant's: refuse instead of silently running the stock library
+        raise KmxError(-2, "KMX_LIBRARY is set but KMX_TEST_HOOKS=1 is not: the variant library would be ignored")
     if path:
         if not os.path.exists(path):
             raise KmxError(-2, f"KMX_LIBRARY={path} does not exist")
@@ -124,6 +129,8 @@ def load_library():
     L.kmx_shard_complete.argtypes = [vp, vp, vp, u64, C.POINTER(Stats)]
     L.kmx_dev_view.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(u64)]
     L.kmx_or_words_dev.argtypes = [vp, vp, vp, u64]
+    L.kmx_debug_pack_strings.argtypes = [vp, vp, i32, i32, u64, vp, C.POINTER(i32)]
+    L.kmx_kernel_classes.argtypes = []
     L.kmx_set_profile.argtypes = [vp, i32]
     L.kmx_get_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), i32]
     _lib = L
@@ -168,6 +175,33 @@ def debug_mod(h: np.ndarray, d: int) -> np.ndarray:
     out = np.zeros_like(h)
     _chk(load_library().kmx_debug_mod(h.ctypes.data, len(h), d, out.ctypes.data))
     return out
+
+
+def pack_strings(flat: np.ndarray, separate: bool = False):
+    """Host half of the vector<string> front door on its own (strpack.cpp): uint8[n, stride >= len] rows -> (packed u64[n * W], clean).
+    `separate`: hand the rows over as n pointers (what a vector<string> holds) instead of one buffer."""
+    L = load_library()
+    flat = np.ascontiguousarray(flat, dtype=np.uint8)
+    n, stride = flat.shape
+    return _pack(L, flat, n, stride, stride, separate)
+
+
+def _pack(L, flat, n, ln, stride, separate):
+    out = np.zeros(n * ((ln + 31) // 32), dtype=np.uint64)
+    clean = C.c_int32(-1)
+    if separate:
+        ptrs = (flat.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(stride)).astype(np.uint64)
+        _chk(L.kmx_debug_pack_strings(ptrs.ctypes.data, None, ln, ln, n, out.ctypes.data, C.byref(clean)))
+    else:
+        _chk(L.kmx_debug_pack_strings(None, flat.ctypes.data, ln, stride, n, out.ctypes.data, C.byref(clean)))
+    return out, bool(clean.value)
+
+
+def pack_strings_len(flat: np.ndarray, ln: int, separate: bool = False):
+    """as pack_strings, for rows that hold `ln` characters followed by padding"""
+    L = load_library()
+    flat = np.ascontiguousarray(flat, dtype=np.uint8)
+    return _pack(L, flat, flat.shape[0], ln, flat.shape[1], separate)
 
 
 def kmc_list(db_prefix: str):
@@ -296,6 +330,19 @@ class KModel:
             _chk(self.L.kmx_query_ascii(self.h, "".join(strs[i] for i in idx).encode("latin-1"), ln, ln, len(idx), part.ctypes.data))
             out[idx] = part
         return int(out[0]) if single else out.tolist()
+
+    def kmer_to_occ_rows(self, rows: np.ndarray, ln: int, separate: bool = True) -> np.ndarray:
+        """kmer_to_occ over uint8[n, stride >= ln] rows holding one string each -- as n separate strings (kmx_query_strings:
+        what the reference's vector<string> is, kmodel.hpp:90-98) or as one buffer (kmx_query_ascii)."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        n, stride = rows.shape
+        out = np.zeros(n, dtype=np.int32)
+        if separate:
+            ptrs = (rows.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(stride)).astype(np.uint64)
+            _chk(self.L.kmx_query_strings(self.h, C.cast(ptrs.ctypes.data, C.POINTER(C.c_char_p)), ln, n, out.ctypes.data))
+        else:
+            _chk(self.L.kmx_query_ascii(self.h, C.cast(rows.ctypes.data, C.c_char_p), ln, stride, n, out.ctypes.data))
+        return out
 
     def kmer_to_occ_packed(self, kmers: np.ndarray) -> np.ndarray:
         kmers = np.ascontiguousarray(kmers, dtype=np.uint64)

@@ -9,8 +9,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libkmx.so")
-SOURCES = ["kernels.hip", "rest_device.hip", "kmx_api.hip", "kmc_reader.cpp"]
-HEADERS = ["device_common.h", "kmx_types.h", "kmc_reader.h", os.path.join("..", "..", "include", "kmx.h")]
+SOURCES = ["kernels.hip", "rest_device.hip", "kmx_api.hip", "kmc_reader.cpp", "strpack.cpp"]
+HEADERS = ["device_common.h", "kmx_types.h", "kmc_reader.h", "strpack.h", os.path.join("..", "..", "include", "kmx.h")]
 
 
 def hipcc() -> str:

@@ -156,17 +156,21 @@ template <int W, int NHM> struct StagedGather {
 		return fail;
 	}
 };
+// `stages`: how many of the three groups this lane fetched (accounting: random loads actually issued).
 template <int W, int NHM>
-__device__ __forceinline__ bool gather_touches_staged(const ModelDev &md, const Premixed<W> &pm, int a, u32 bin, Touches<NHM> &t)
+__device__ __forceinline__ bool gather_touches_staged(const ModelDev &md, const Premixed<W> &pm, int a, u32 bin, Touches<NHM> &t, int &stages)
 {
 	StagedGather<W, NHM> g = {md, pm, md.cells[a], a * md.nh, bin, t};
 	const int j1 = md.nh_first, j2 = md.nh_second, nh = md.nh;
+	stages = 1;
 	g.hash(0, j1);
 	g.load(0, j1);
 	if (g.conflict(0, j1)) return true;
+	stages = 2;
 	g.hash(j1, j2);
 	g.load(j1, j2);
 	if (g.conflict(j1, j2)) return true;
+	stages = 3;
 	g.hash(j2, nh);
 	g.load(j2, nh);
 	return g.conflict(j2, nh);
@@ -578,7 +582,7 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 	constexpr int NBIN = KMX_CL_BINS(NHM);
 	u64 *s_tup = (u64 *)lds;                                         // [256 * NHM]
 	int *s_cnt = (int *)(lds + 256 * NHM * 8), *s_off = s_cnt + NBIN, *s_base = s_off + NBIN, *s_tmp = s_base + NBIN;
-	int &s_fail = s_tmp[4];
+	int &s_fail = s_tmp[4], &s_gath = s_tmp[5];
 	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;                                  // kmodel.hpp:563
@@ -587,6 +591,7 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 		if (stat_slot && n) atomicAdd(bd.stats + stat_slot, (u64)n);   // accounting: attempts examined inside fused launches
 		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, md.nb)] = 0;   // k_round_file files this round's records
 	}
+	if (threadIdx.x == 0) s_gath = 0;                                // (the loop's first barrier orders this)
 	constexpr int CAP = KMX_CL_CAP_OF(NHM);
 	u64 *tup = bd.cl_tup[pp] + (u64)i * NBIN * CAP;
 	int *gcnt = bd.cl_cnt[pp] + i * KMX_CL_MAXBINS;
@@ -599,7 +604,7 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 		const int x = base + threadIdx.x;
 		bool failed = false;
 		u32 um = 0, bin = 0;
-		int rank[NHM];
+		int rank[NHM], stages = 0;
 		Touches<NHM> tc;
 		if (x < n) {
 			const u32 raw = bd.list[pp][row + x];
@@ -609,7 +614,7 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 			load_kmer<W>(bd.kmers, row + idx, v);
 			bin = md.bin_of_occ[bd.counts[row + idx]];
 			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
-			failed = gather_touches_staged<W, NHM>(md, pm, a, bin, tc);
+			failed = gather_touches_staged<W, NHM>(md, pm, a, bin, tc, stages);
 			status[x] = failed ? SLOT_FAILED : SLOT_UNDECIDED;
 			if (!failed) {
 #pragma unroll
@@ -628,6 +633,10 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 		// survivors are counted per 1024-slot tile as they fail, so the reorder needs no counting pass
 		const u64 mask = __ballot(failed);
 		if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&s_fail, (int)__popcll(mask));
+		if (stat_slot) {                                                 // random 4-byte loads this wave issued (the staged fetch stops early)
+			const int g1 = (int)__popcll(__ballot(stages >= 1)), g2 = (int)__popcll(__ballot(stages >= 2)), g3 = (int)__popcll(__ballot(stages >= 3));
+			if ((threadIdx.x & 63) == 0 && g1) atomicAdd(&s_gath, g1 * md.nh_first + g2 * (md.nh_second - md.nh_first) + g3 * (md.nh - md.nh_second));
+		}
 		__syncthreads();
 		if (threadIdx.x == 0 && s_fail) atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (base >> 10), s_fail);
 		// one run per bin: its offset in the LDS staging area (scan) and its place in the bin (ONE global atomic per run)
@@ -659,6 +668,7 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 		}
 		__syncthreads();
 	}
+	if (stat_slot && threadIdx.x == 0 && s_gath) atomicAdd(bd.stats + ST_PIPE_GATHERS, (u64)s_gath);
 }
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_emit(ModelDev md, BlockDev bd, int t, int pp)
 {
@@ -915,18 +925,20 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_round_file(M
 // (a = the array list i visited in the round being committed; pp = that round's parity)
 template <int NHM> __device__ __forceinline__ void commit_body(const ModelDev &md, const BlockDev &bd, int a, int pp, int i, int bx, int gx, unsigned char *lds, int stat_slot)
 {
-	int &s_cnt = ((int *)lds)[0];
+	int &s_cnt = ((int *)lds)[0], &s_atom = ((int *)lds)[1];
 	const int n = bd.n[pp][i];
 	const u64 row = (u64)i * KMX_BUCKET;
 	cell_t *cells = md.cells[a];
 	const unsigned char *status = bd.status[pp] + row;
-	if (stat_slot && threadIdx.x == 0) s_cnt = 0;
+	if (stat_slot && threadIdx.x == 0) { s_cnt = 0; s_atom = 0; }
 	if (stat_slot) __syncthreads();
 	for (int base = bx * 256; base < n; base += gx * 256) {
 		const int x = base + threadIdx.x;
 		const bool win = x < n && status[x] == SLOT_UNDECIDED;
+		u32 um = 0;
 		if (win) {
-			const u32 uw = bd.uw[pp][row + x], um = uw & 0xFFFFu, want = uw >> 16;
+			const u32 uw = bd.uw[pp][row + x], want = uw >> 16;
+			um = uw & 0xFFFFu;
 			const CRec<NHM> rec = crec_load<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh);
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
@@ -937,12 +949,17 @@ template <int NHM> __device__ __forceinline__ void commit_body(const ModelDev &m
 		}
 		if (stat_slot) {
 			const u64 wm = __ballot(win);
-			if ((threadIdx.x & 63) == 0 && wm) atomicAdd(&s_cnt, (int)__popcll(wm));
+			if (wm) {                                                    // (uniform per wave) atomics this wave issued: one per untagged position of a winner
+				int at = 0;
+#pragma unroll
+				for (int j = 0; j < NHM; j++) at += (int)__popcll(__ballot((um >> j) & 1u));
+				if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt, (int)__popcll(wm)); atomicAdd(&s_atom, at); }
+			}
 		}
 	}
 	if (stat_slot) {
 		__syncthreads();
-		if (threadIdx.x == 0 && s_cnt) atomicAdd(bd.stats + stat_slot, (u64)s_cnt);
+		if (threadIdx.x == 0 && s_cnt) { atomicAdd(bd.stats + stat_slot, (u64)s_cnt); atomicAdd(bd.stats + ST_PIPE_ATOMICS, (u64)s_atom); }
 	}
 }
 // commit of the round with parity pp, whose list i visited array (i + t) % nb

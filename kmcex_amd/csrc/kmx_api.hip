@@ -6,6 +6,7 @@
 #include "../../include/kmx.h"
 #include "kmc_reader.h"
 #include "kmx_types.h"
+#include "strpack.h"
 
 #include <algorithm>
 #include <atomic>
@@ -245,6 +246,16 @@ struct kmx_model {
 		hipStream_t copy = nullptr;
 		hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
 	} feed;
+	// feed of kmer_to_occ(vector<string>): three slots of pinned + device buffers (strings in, answers out), a copy stream
+	// each way -- kept on the handle like the KMC feed
+	struct QueryFeed {
+		static const int S = 3;
+		unsigned char *h_in[S] = {nullptr, nullptr, nullptr}, *d_in[S] = {nullptr, nullptr, nullptr};
+		int32_t *h_out[S] = {nullptr, nullptr, nullptr}, *d_out[S] = {nullptr, nullptr, nullptr};
+		size_t in_cap = 0, out_cap = 0;                            // bytes per slot / answers per slot
+		hipStream_t to_dev = nullptr, to_host = nullptr;
+		hipEvent_t ev_in[S] = {nullptr, nullptr, nullptr}, ev_k[S] = {nullptr, nullptr, nullptr}, ev_out[S] = {nullptr, nullptr, nullptr};
+	} qfeed;
 	bool ring = false;                                         // built by several GPUs (kmx_shard_begin): this handle holds ONE rank's share
 	int ring_rank = 0, ring_world = 1;
 	int nsub = 1;                                              // grid-wide ordered passes in round 0 (see process_block)
@@ -253,7 +264,7 @@ struct kmx_model {
 	int pp = 0;                                                // list / per-slot-state parity of the next round (alternates from round to round, never reset inside a build)
 	bool pending = false;
 	int pending_t = 0;
-	bool defer = true;                                         // false: every round commits in a launch of its own before the next check (arrays above 2^37 positions; KMX_PIPE=0)
+	bool defer = true;                                         // false: every round commits in a launch of its own before the next check (arrays above 2^KMX_CL_MIX_BITS = 2^36 positions; KMX_PIPE=0)
 	bool dbg_no_defer = false;
 	// test hooks, read from the environment by kmx_begin: forced pass counts, forced older code
 	// paths (KMX_ROUND_* flags of kmx_types.h), a trace of the pass-count controller
@@ -448,6 +459,21 @@ static void free_feed(kmx_model *m)
 	f.raw_cap = f.km_cap = f.dk_cap = f.lut_cap = 0;
 }
 
+static void free_query_feed(kmx_model *m)
+{
+	auto &f = m->qfeed;
+	if (f.to_dev) { hipStreamSynchronize(f.to_dev); hipStreamDestroy(f.to_dev); f.to_dev = nullptr; }
+	if (f.to_host) { hipStreamSynchronize(f.to_host); hipStreamDestroy(f.to_host); f.to_host = nullptr; }
+	for (int s = 0; s < f.S; s++) {
+		if (f.h_in[s]) hipHostFree(f.h_in[s]);
+		if (f.h_out[s]) hipHostFree(f.h_out[s]);
+		hipFree(f.d_in[s]); hipFree(f.d_out[s]);
+		f.h_in[s] = f.d_in[s] = nullptr; f.h_out[s] = f.d_out[s] = nullptr;
+		for (hipEvent_t *e : {&f.ev_in[s], &f.ev_k[s], &f.ev_out[s]}) { if (*e) hipEventDestroy(*e); *e = nullptr; }
+	}
+	f.in_cap = f.out_cap = 0;
+}
+
 static int kmx_destroy_impl(kmx_model *m)
 {
 	if (!m) return KMX_OK;
@@ -463,6 +489,7 @@ static int kmx_destroy_impl(kmx_model *m)
 	hipFree(m->d_totals);
 	if (m->h_totals) hipHostFree(m->h_totals);
 	free_feed(m);
+	free_query_feed(m);
 	for (hipEvent_t e : m->prof_events) hipEventDestroy(e);
 	delete m;
 	return KMX_OK;
@@ -900,7 +927,11 @@ static int flush_pending_commit(kmx_model *m)
 }
 
 // one round of the block in m->bd (list parity m->pp): the previous round's commit rides with its check; its own winners
-// stay pending -- or are committed right away when the build does not defer (m->defer, or a rank of the multi-GPU ring)
+// stay pending -- or are committed right away when the build does not defer (m->defer false: arrays beyond 2^36 positions,
+// KMX_PIPE=0).  A rank of the multi-GPU ring defers too (kmx_ring_round_dev passes m->defer): it owns its arrays whole, so
+// the claims its detect needs as settled positions are its own.  Deferring is sound only while cl_mix is a bijection on the
+// positions of an array -- the gate in kmx_begin and the static_assert below tie the two together.
+static_assert(KMX_CL_MIX_BITS == 36, "kmx_begin's defer gate, cl_mix's mask and the 8 + 28-bit table entry of k_round_detect all assume 36 bits");
 static int run_round(kmx_model *m, int t, bool defer, const KmbackJob *job)
 {
 	const int flags = m->dbg_flags | (m->pending ? KMX_ROUND_PENDING : 0) | (defer ? KMX_ROUND_KEEP : 0);
@@ -1789,87 +1820,163 @@ static int kmx_query_packed_impl(kmx_model *m, const uint64_t *kmers, uint64_t n
 	return rc;
 }
 
-// vector<string> front door (kmodel.hpp:90-116).  Strings of the model's k that hold only ACGT are packed on the host
-// (2 bits/base) and take the packed kernel; anything else -- other characters, another length -- is answered by the
-// byte-string kernel, which hashes the bytes as they are, exactly like the reference does.
-template <typename PTR>
-static int query_text(kmx_model *m, PTR ptr_of, const char *flat, int len, int stride, uint64_t n, int32_t *out)
+// vector<string> front door (kmodel.hpp:90-116).  The reference splits the vector over t_num threads (:93-96); here the
+// batch is cut into chunks that flow through a three-slot pipeline: worker threads turn chunk c into packed k-mers inside a
+// pinned slot (strpack.cpp: 8 bytes per string over the link instead of k), a copy stream moves it (hipMemcpyAsync), the
+// model's stream answers it (k_query), a second copy stream brings the answers back, and the workers hand them to the
+// caller's array -- chunk c is packed while c-1 is on the GPU and c-2 is copied out.  A chunk that holds a string the packed
+// form cannot express (other characters, or a length that is not the model's k) travels as bytes and is answered by the
+// byte-string kernel, which hashes the bytes as they are, exactly like the reference does -- chunk by chunk, so one dirty
+// string does not slow the whole batch down.
+static const u64 kQueryChunk = u64(1) << 20;
+
+static int ensure_query_feed(kmx_model *m, size_t in_bytes, size_t answers)
+{
+	auto &F = m->qfeed;
+	if (!F.to_dev) HIPCHK(hipStreamCreateWithFlags(&F.to_dev, hipStreamNonBlocking));
+	if (!F.to_host) HIPCHK(hipStreamCreateWithFlags(&F.to_host, hipStreamNonBlocking));
+	for (int s = 0; s < F.S; s++)
+		for (hipEvent_t *e : {&F.ev_in[s], &F.ev_k[s], &F.ev_out[s]})
+			if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+	if (in_bytes > F.in_cap) {
+		HIPCHK(hipStreamSynchronize(m->stream));
+		for (int s = 0; s < F.S; s++) {
+			if (F.h_in[s]) hipHostFree(F.h_in[s]);
+			hipFree(F.d_in[s]);
+			F.h_in[s] = F.d_in[s] = nullptr;
+		}
+		F.in_cap = 0;
+		for (int s = 0; s < F.S; s++) {
+			HIPCHK(hipHostMalloc((void **)&F.h_in[s], in_bytes));
+			HIPCHK(timed_malloc((void **)&F.d_in[s], in_bytes));
+		}
+		F.in_cap = in_bytes;
+	}
+	if (answers > F.out_cap) {
+		HIPCHK(hipStreamSynchronize(m->stream));
+		for (int s = 0; s < F.S; s++) {
+			if (F.h_out[s]) hipHostFree(F.h_out[s]);
+			hipFree(F.d_out[s]);
+			F.h_out[s] = F.d_out[s] = nullptr;
+		}
+		F.out_cap = 0;
+		for (int s = 0; s < F.S; s++) {
+			HIPCHK(hipHostMalloc((void **)&F.h_out[s], answers * 4));
+			HIPCHK(timed_malloc((void **)&F.d_out[s], answers * 4));
+		}
+		F.out_cap = answers;
+	}
+	return KMX_OK;
+}
+
+static int query_text(kmx_model *m, const KmxStrBatch &sb, uint64_t n, int32_t *out)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (m->state != ST_READY) return fail(KMX_E_STATE, "query before the model is built or loaded");
-	if (len < 2 || len > 64 || stride < len) return fail(KMX_E_ARG, "k-mer strings must hold 2..64 characters (got %d, stride %d)", len, stride);
+	const int len = sb.len, W = m->W;
+	if (len < 2 || len > 64 || sb.stride < len) return fail(KMX_E_ARG, "k-mer strings must hold 2..64 characters (got %d, stride %d)", len, sb.stride);
 	if (!n) return KMX_OK;
-	bool clean = len == m->k;
-	std::unique_ptr<u64[]> pk_mem(clean ? new u64[n * m->W] : nullptr);   // not zero-filled: every word is written below
-	u64 *pk = pk_mem.get();
-	if (clean) {                                              // pack on up to 16 host threads
-		const unsigned hw = std::thread::hardware_concurrency();
-		const int T = (int)std::max<u64>(1, std::min<u64>(std::min<unsigned>(hw ? hw : 1, 16), n / 65536 + 1));
-		std::vector<char> ok(T, 1);
-		static const struct Lut { unsigned char c[256]; Lut() { memset(c, 0x80, sizeof c); c['A'] = 0; c['C'] = 1; c['G'] = 2; c['T'] = 3; } } lut;
-		auto work = [&](int t) {
-			const u64 per = (n + T - 1) / T, lo = (u64)t * per, hi = std::min<u64>(n, lo + per);
-			unsigned bad = 0;
-			for (u64 i = lo; i < hi; i++) {
-				const unsigned char *s = (const unsigned char *)ptr_of(i);
-				if (m->W == 1) {
-					u64 v = 0;
-					for (int j = 0; j < len; j++) { const unsigned c = lut.c[s[j]]; bad |= c; v = (v << 2) | (c & 3); }
-					pk[i] = v;
-				} else {
-					u64 hi64 = 0, lo64 = 0;                                  // len > 32: the first len-32 characters fill the high word
-					int j = 0;
-					for (; j < len - 32; j++) { const unsigned c = lut.c[s[j]]; bad |= c; hi64 = (hi64 << 2) | (c & 3); }
-					for (; j < len; j++) { const unsigned c = lut.c[s[j]]; bad |= c; lo64 = (lo64 << 2) | (c & 3); }
-					pk[2 * i] = hi64; pk[2 * i + 1] = lo64;
-				}
-			}
-			if (bad & 0x80) ok[t] = 0;
-		};
-		if (T == 1) work(0);
-		else {
-			std::vector<std::thread> th;
-			for (int t = 0; t < T; t++) th.emplace_back(work, t);
-			for (auto &x : th) x.join();
-		}
-		for (int t = 0; t < T; t++) clean = clean && ok[t];
-	}
-	if (clean) return kmx_query_packed(m, (const uint64_t *)pk, n, out);
-	pk_mem.reset();
-	std::vector<char> gathered;                                  // separate strings: lay them out back to back first
-	if (!flat) {
-		gathered.resize(n * (u64)len);
-		for (u64 i = 0; i < n; i++) memcpy(gathered.data() + i * (u64)len, ptr_of(i), (size_t)len);
-		flat = gathered.data();
-		stride = len;
-	}
 	HIPCHK(hipSetDevice(m->device));
-	DevMem ds, dout;
-	const u64 bytes = (n - 1) * (u64)stride + (u64)len;
-	HIPCHK(ds.alloc(bytes));
-	HIPCHK(dout.alloc(n * 4));
+	const bool packable = len == m->k;                           // (another length hashes differently from any k-mer of the model)
+	const u64 C = std::min<u64>(kQueryChunk, (n + 4095) & ~u64(4095)), nc = (n + C - 1) / C;
+	const int T = (int)std::max<u64>(1, std::min<u64>(std::min(kmx_host_cpus(), 32), n / 16384 + 1));
+	// a slot takes a chunk in either form; a batch that can only travel as bytes gets slots for that from the start
+	TRY(ensure_query_feed(m, (size_t)(C * std::max<u64>(8 * W, (u64)len)), (size_t)C));
+	auto &F = m->qfeed;
+	enum { UNDECIDED = 0, PACKED = 1, RAW = 2 };
+	std::mutex mu;
+	std::condition_variable cv;
+	std::vector<int> arrived(nc, 0), mode(nc, packable ? UNDECIDED : RAW), staged(nc, 0), copied(nc, 0);
+	std::vector<char> dirty(nc, 0), ready(nc, 0);
+	bool abort = false;
+	auto piece = [&](u64 c, int t, u64 &lo, u64 &hi) {            // worker t's share of chunk c, in strings of the batch
+		const u64 c0 = c * C, cn = std::min<u64>(C, n - c0), per = (cn + T - 1) / T;
+		lo = c0 + std::min<u64>(cn, (u64)t * per);
+		hi = c0 + std::min<u64>(cn, (u64)(t + 1) * per);
+	};
+	auto copy_out = [&](u64 c, int t) {
+		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready[c] || abort; }); if (abort) return; }
+		u64 lo, hi;
+		piece(c, t, lo, hi);
+		if (hi > lo) memcpy(out + lo, F.h_out[c % F.S] + (lo - c * C), (hi - lo) * 4);
+		std::lock_guard<std::mutex> lk(mu);
+		if (++copied[c] == T) cv.notify_all();
+	};
+	auto worker = [&](int t) {
+		const u64 lag = F.S - 1;
+		for (u64 c = 0; c < nc; c++) {
+			if (c >= (u64)F.S) {                                     // the slot is free once chunk c - S has left it
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&] { return copied[c - F.S] == T || abort; });
+				if (abort) return;
+			}
+			u64 lo, hi;
+			piece(c, t, lo, hi);
+			unsigned char *slot = F.h_in[c % F.S];
+			if (packable) {
+				const bool ok = hi > lo ? kmx_pack_strings(sb, W, lo, hi, (uint64_t *)slot + (lo - c * C) * W) : true;
+				std::unique_lock<std::mutex> lk(mu);
+				if (!ok) dirty[c] = 1;
+				if (++arrived[c] == T) { mode[c] = dirty[c] ? RAW : PACKED; cv.notify_all(); }
+				else cv.wait(lk, [&] { return mode[c] != UNDECIDED || abort; });
+				if (abort) return;
+			}
+			if (mode[c] == RAW) {
+				if (hi > lo) kmx_gather_strings(sb, lo, hi, slot + (lo - c * C) * (u64)len);
+				std::lock_guard<std::mutex> lk(mu);
+				if (++staged[c] == T) cv.notify_all();
+			}
+			if (c >= lag) copy_out(c - lag, t);
+		}
+		for (u64 c = nc > lag ? nc - lag : 0; c < nc; c++) copy_out(c, t);
+	};
+	std::vector<std::thread> th;
+	for (int t = 0; t < T; t++) th.emplace_back(worker, t);
 	int rc = KMX_OK;
-	if (hipMemcpyAsync(ds.p, flat, bytes, hipMemcpyHostToDevice, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
-	if (!rc) {
-		kmxk::query_ascii(m->md, len, ds.as<unsigned char>(), stride, n, dout.as<int>(), m->stream);
-		if (hipMemcpyAsync(out, dout.p, n * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess) rc = fail(KMX_E_NODEVICE, "D2H copy failed");
+	auto publish = [&](u64 c) {                                   // chunk c's answers are in its pinned slot
+		if (hipEventSynchronize(F.ev_out[c % F.S]) != hipSuccess && !rc) rc = fail(KMX_E_NODEVICE, "query failed");
+		std::lock_guard<std::mutex> lk(mu);
+		ready[c] = 1;
+		if (rc) abort = true;
+		cv.notify_all();
+	};
+	for (u64 c = 0; c < nc && !rc; c++) {
+		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return mode[c] == PACKED || (mode[c] == RAW && staged[c] == T); }); }
+		const int s = (int)(c % F.S);
+		const u64 cn = std::min<u64>(C, n - c * C);
+		const size_t bytes = (size_t)(mode[c] == PACKED ? cn * W * 8 : cn * (u64)len);
+		if (hipMemcpyAsync(F.d_in[s], F.h_in[s], bytes, hipMemcpyHostToDevice, F.to_dev) != hipSuccess || hipEventRecord(F.ev_in[s], F.to_dev) != hipSuccess ||
+		    hipStreamWaitEvent(m->stream, F.ev_in[s], 0) != hipSuccess) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
+		if (!rc) {
+			if (mode[c] == PACKED) kmxk::query(m->md, (const u64 *)F.d_in[s], cn, F.d_out[s], m->stream, &m->prof);
+			else kmxk::query_ascii(m->md, len, F.d_in[s], len, cn, F.d_out[s], m->stream);
+			if (hipEventRecord(F.ev_k[s], m->stream) != hipSuccess || hipStreamWaitEvent(F.to_host, F.ev_k[s], 0) != hipSuccess ||
+			    hipMemcpyAsync(F.h_out[s], F.d_out[s], cn * 4, hipMemcpyDeviceToHost, F.to_host) != hipSuccess ||
+			    hipEventRecord(F.ev_out[s], F.to_host) != hipSuccess) rc = fail(KMX_E_NODEVICE, "D2H copy failed");
+		}
+		if (rc) break;
+		if (c >= 1) publish(c - 1);
 	}
-	hipStreamSynchronize(m->stream);
+	if (!rc) publish(nc - 1);
+	else { std::lock_guard<std::mutex> lk(mu); abort = true; cv.notify_all(); }
+	for (auto &x : th) x.join();
+	hipStreamSynchronize(F.to_dev); hipStreamSynchronize(F.to_host);
+	if (hipStreamSynchronize(m->stream) != hipSuccess && !rc) rc = fail(KMX_E_NODEVICE, "query failed");
 	if (!rc && hipGetLastError() != hipSuccess) rc = fail(KMX_E_NODEVICE, "query kernel failed");
 	return rc;
 }
 
 static int kmx_query_ascii_impl(kmx_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out)
 {
-	if (n && !strs) return fail(KMX_E_ARG, "null argument");
-	return query_text(m, [&](u64 i) { return strs + i * (u64)stride; }, strs, len, stride, n, out);
+	if (n && (!strs || !out)) return fail(KMX_E_ARG, "null argument");
+	return query_text(m, KmxStrBatch{nullptr, strs, stride, len}, n, out);
 }
 
 // the same for n separate strings of `len` characters each (what a vector<string> holds), without concatenating them
 static int kmx_query_strings_impl(kmx_model *m, const char *const *strs, int len, uint64_t n, int32_t *out)
 {
-	if (n && !strs) return fail(KMX_E_ARG, "null argument");
-	return query_text(m, [&](u64 i) { return strs[i]; }, nullptr, len, len, n, out);
+	if (n && (!strs || !out)) return fail(KMX_E_ARG, "null argument");
+	return query_text(m, KmxStrBatch{strs, nullptr, len, len}, n, out);
 }
 
 // ------------------------------------------------------------------------------------------ persistence
@@ -2150,6 +2257,7 @@ static int kmx_get_stats_impl(kmx_model *m, kmx_stats *st)
 	st->rest_entries = m->rest.entries; st->km_byte_size = m->km_byte_size; st->byte_km_back = m->byte_km_back;
 	st->blocks = m->blocks; st->rounds = m->rounds;
 	st->piped_attempts = m->h_stats[ST_PIPE_ATTEMPTS]; st->piped_commits = m->h_stats[ST_PIPE_SUCC];
+	st->piped_gathers = m->h_stats[ST_PIPE_GATHERS]; st->piped_atomics = m->h_stats[ST_PIPE_ATOMICS];
 	st->rest_bytes = m->rest.suff_bin_size + 4 * m->rest.entries + 4 * (u64)m->rest.pre_buffer_size + 4 * (u64)m->rest.map_size;
 	st->k = m->k; st->ci = m->ci; st->cs = m->cs; st->nh = m->nh; st->nb = m->nb; st->bf_num = m->bf_num; st->device = m->device;
 	return KMX_OK;
@@ -2339,6 +2447,16 @@ extern "C" int kmx_last_build_seconds(kmx_model *m, double *insert_kernels_s, do
 extern "C" int kmx_debug_hash(int k, const uint64_t *kmers, uint64_t n, const uint32_t *seeds, int n_seeds, int whole, uint64_t *hashes) { return guarded([&] { return kmx_debug_hash_impl(k, kmers, n, seeds, n_seeds, whole, hashes); }); }
 extern "C" int kmx_debug_min_kmer(int k, const uint64_t *kmers, uint64_t n, uint64_t *out) { return guarded([&] { return kmx_debug_min_kmer_impl(k, kmers, n, out); }); }
 extern "C" int kmx_debug_mod(const uint64_t *h, uint64_t n, uint64_t d, uint64_t *out) { return guarded([&] { return kmx_debug_mod_impl(h, n, d, out); }); }
+extern "C" int kmx_debug_pack_strings(const char *const *strs, const char *flat, int len, int stride, uint64_t n, uint64_t *packed, int *clean)
+{
+	return guarded([&] {
+		if (len < 2 || len > 64 || (!strs && (!flat || stride < len)) || !packed || !clean) return fail(KMX_E_ARG, "bad argument");
+		*clean = kmx_pack_strings(KmxStrBatch{strs, flat, strs ? len : stride, len}, (len + 31) / 32, 0, n, packed) ? 1 : 0;
+		return (int)KMX_OK;
+	});
+}
+extern "C" int kmx_kernel_classes(void) { return KMX_KERNEL_CLASSES; }
 extern "C" int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds) { return guarded([&] { return kmx_microbench_impl(mode, bytes, touches, iters, seconds); }); }
 extern "C" int kmx_set_profile(kmx_model *m, int on) { return guarded([&] { return kmx_set_profile_impl(m, on); }); }
+static_assert(KC_N == KMX_KERNEL_CLASSES, "include/kmx.h promises KMX_KERNEL_CLASSES entries");
 extern "C" int kmx_get_kernel_times(kmx_model *m, double *seconds, uint64_t *launches, int reset) { return guarded([&] { return kmx_get_kernel_times_impl(m, seconds, launches, reset); }); }

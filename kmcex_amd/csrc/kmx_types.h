@@ -74,6 +74,7 @@ struct KmcDecode {
 // device-side statistics (one u64 each)
 enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_MAX_U0, ST_MAX_UFIN,
        ST_PIPE_ATTEMPTS, ST_PIPE_SUCC,        // attempts examined / winners committed inside fused commit|check launches (accounting only)
+       ST_PIPE_GATHERS, ST_PIPE_ATOMICS,      // random 4-byte loads / 32-bit atomic ORs issued inside those launches (the staged fetch stops early; one atomic per NEW tag bit)
        ST_DELTA_FAILS,                        // candidates of a stale check that a still-uncommitted winner of the previous visit ruled out (k_round_detect)
        ST_N };
 

@@ -122,3 +122,27 @@ def test_no_gpu_means_loud_failure_not_a_fallback():
     assert e.value.code == -2
     with pytest.raises(api.KmxError):
         api.KModel.load(os.path.join(ROOT, "tests", "golden", "tiny"))
+
+
+def test_string_packer_matches_numpy_at_every_length():
+    """strpack.cpp (the host half of kmer_to_occ(vector<string>), kmodel.hpp:90-98): 16 characters per SSSE3 step, overlapping
+    loads, two-word k-mers -- against synth.to_ascii's inverse, as one buffer and as separate strings; no GPU involved."""
+    rng = np.random.default_rng(5)
+    for ln in list(range(2, 65)):
+        n = 300
+        km = synth.random_kmers(n, ln, seed_k=1000 + ln)
+        rows = np.zeros((n, 72), dtype=np.uint8)
+        rows[:, :ln] = synth.to_ascii(km, ln)
+        rows[:, ln:] = rng.integers(0, 256, size=(n, 72 - ln), dtype=np.uint8)       # what follows a string is not looked at
+        for separate in (False, True):
+            got, clean = api.pack_strings_len(rows, ln, separate)
+            assert clean and np.array_equal(got, np.ascontiguousarray(km).reshape(-1)), (ln, separate)
+        for bad in (b"N", b"a", b"\0", b"U"):
+            r2 = rows.copy()
+            r2[int(rng.integers(n)), int(rng.integers(ln))] = bad[0]
+            assert not api.pack_strings_len(r2, ln, bool(ln & 1))[1], (ln, bad)
+
+
+def test_kernel_class_count_is_exported():
+    L = api.load_library()
+    assert L.kmx_kernel_classes() == len(api.KModel.KERNEL_CLASSES)

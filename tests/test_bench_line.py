@@ -26,6 +26,14 @@ def test_one_rank_keeps_the_plain_build_as_headline():
     assert out["value"] == 8.0e9 and "replica_value" not in out and out["single_model"]["value"] == 3.0e9
 
 
-def test_a_failed_single_model_leg_does_not_take_the_headline():
+def test_a_failed_single_model_leg_leaves_no_headline():
+    """N > 1 and the exchange failed: `value` (ONE model) was not measured -- the replicas' rate must not stand in for it
+    (bench.py then exits 3, like its watchdog)."""
     out = bench.promote_single_model(copy.deepcopy(LINE), {"error": "exchange timed out"}, 8)
-    assert out["value"] == 8.0e9 and out["single_model"]["error"] and "replica_value" not in out
+    assert out["value"] is None and out["replica_value"] == 8.0e9 and out["single_model"]["error"] and out["failed"]
+    assert "NOT MEASURED" in out["value_is"]
+
+
+def test_a_switched_off_single_model_leg_keeps_the_replica_headline():
+    out = bench.promote_single_model(copy.deepcopy(LINE), None, 8)
+    assert out["value"] == 8.0e9 and "replica_value" not in out

@@ -432,6 +432,43 @@ def test_strings_the_packed_form_cannot_hold(name):
         assert np.array_equal(np.array(m.kmer_to_occ(strs), dtype=np.int32), o.query_strings(strs)), L
 
 
+@pytest.mark.parametrize("name,k", [("tiny_k31", 31), ("k55_nh9_nb6", 55)])
+def test_vector_of_strings_pipeline_over_many_chunks(name, k):
+    """kmer_to_occ(vector<string>) (kmodel.hpp:90-98) on a batch of several chunks of the three-slot pipeline (kmx_query_strings:
+    2^20 strings per chunk, packed by worker threads, answered under the next chunk's packing): as separate strings and as one
+    buffer, with chunks that must travel as bytes (a string the packed form cannot hold) between chunks that travel packed --
+    every answer equal to the packed query's, the dirty strings' answers equal to the oracle's."""
+    _, kk, ci, cs, nh, nb, n = CASE[name]
+    assert kk == k
+    km, cnt = synth.make_stream(n, k, ci, cs)
+    m = KModel(ci, cs, nh, nb)
+    m.build_packed(k, km, cnt)
+    o = O.OracleModel(ci, cs, nh, nb)
+    o.build(k, km, cnt)
+    W = (k + 31) // 32
+    nq = (1 << 20) * 3 + 12345                                  # four chunks, the last one short
+    rng = np.random.default_rng(11)
+    pool = np.concatenate([km.reshape(-1, W), synth.revcomp(km, k).reshape(-1, W), synth.random_kmers(len(cnt), k, seed_k=0xABCDEF0123).reshape(-1, W)])
+    q = pool[rng.integers(0, len(pool), size=nq)]
+    want = m.kmer_to_occ_packed(q.reshape(-1))
+    rows = np.zeros((nq, 64), dtype=np.uint8)
+    rows[:, :k] = synth.to_ascii(q.reshape(-1), k)
+    for separate in (True, False):
+        assert np.array_equal(m.kmer_to_occ_rows(rows, k, separate), want), separate
+    # chunks 1 and 3 hold strings of other bytes: they travel as bytes, 0 and 2 stay packed
+    dirty_at = [(1 << 20) + 5, (1 << 20) * 2 - 1, (1 << 20) * 3 + 7, nq - 1]
+    r2 = rows.copy()
+    for j, i in enumerate(dirty_at):
+        r2[i, (3 * j + 1) % k] = b"NnX-"[j]
+    exp = want.copy()
+    exp[dirty_at] = o.query_strings([bytes(r2[i, :k]).decode("latin-1") for i in dirty_at])
+    for separate in (True, False):
+        assert np.array_equal(m.kmer_to_occ_rows(r2, k, separate), exp), separate
+    # a second model on the same thread reuses nothing of the first one's feed; a short batch after a long one reuses the slots
+    assert np.array_equal(m.kmer_to_occ_rows(rows[:1000], k, True), want[:1000])
+    assert np.array_equal(m.kmer_to_occ_rows(rows[:1], k, False), want[:1])
+
+
 @pytest.mark.parametrize("case", KMC2_CASES, ids=lambda c: c[0])
 def test_init_from_kmc2_database_unsorted_listing(case, golden, tmp_path):
     """A KMC2-layout database (what KMC 3 emits) lists bin-major, i.e. NOT in sorted order; the ordered insert must follow

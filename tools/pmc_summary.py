@@ -25,7 +25,9 @@ def agg(tag, c):
 
 import os
 head = os.environ.get("KMX_GIT_HEAD") or None      # the GPU box has no .git: gpurun -- "KMX_GIT_HEAD=$(git rev-parse --short HEAD) tools/pmc_run.sh <tag>"
-res = {"label": label, "head": head, "unit_note": "FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3; bytes = KiB * 1024", "kernels": {}}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                                       # source_digest(): bench.py reports `traffic` only for the sources the counters were taken on
+res = {"label": label, "head": head, "src_sha": bench.source_digest(), "unit_note": "FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3; bytes = KiB * 1024", "kernels": {}}
 f, w = agg("pmc_", "FETCH_SIZE"), agg("pmc_", "WRITE_SIZE")
 mf, mw = agg("pmcmicro_", "FETCH_SIZE"), agg("pmcmicro_", "WRITE_SIZE")
 cal = {}
