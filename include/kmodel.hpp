@@ -60,9 +60,17 @@ public:
 
 class KModel {
 public:
-	KModel() : h_(nullptr) {}                                          // kmodel.hpp:43; fill it with load(dir)
-	explicit KModel(kmx_model *h) : h_(h) {}
+	KModel() : h_(nullptr) { abi(); }                                  // kmodel.hpp:43; fill it with load(dir)
+	explicit KModel(kmx_model *h) : h_(h) { abi(); }
 	~KModel() { kmx_destroy(h_); }
+	// a binary built against an older kmx.h must not hand its structs to a newer libkmx.so
+	static void abi()
+	{
+		if (kmx_abi_version() != KMX_ABI_VERSION) {
+			std::cout << "libkmx.so has ABI version " << kmx_abi_version() << ", this program was built for " << KMX_ABI_VERSION << "; rebuild it" << std::endl;
+			exit(1);
+		}
+	}
 	KModel(const KModel &) = delete;
 	KModel &operator=(const KModel &) = delete;
 

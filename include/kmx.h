@@ -59,6 +59,11 @@ typedef struct kmx_stats {
 
 const char *kmx_last_error(void);
 int kmx_device_count(void);
+/* Layout version of the structs and array sizes this header declares (kmx_stats, KMX_KERNEL_CLASSES ...): a caller built
+ * against an older header must not hand its smaller structs to a newer library -- compare before the first call that
+ * takes one (include/kmodel.hpp does, and exits like the reference does on a bad model directory).                    */
+#define KMX_ABI_VERSION 4
+int kmx_abi_version(void);
 
 /* get_model(ci, cs, num_hash, num_bit)                                     kmodel.hpp:674-677 */
 int kmx_create(int ci, int cs, int nh, int nb, kmx_model **out);

@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "kmx_set_profile", "kmx_get_kernel_times", "kmx_kmc_info", "kmx_kmc_read", "kmx_debug_mod",
     "kmx_count_classes_dev", "kmx_shard_begin", "kmx_shard_classify_dev", "kmx_ring_msg_bytes", "kmx_ring_round_dev",
     "kmx_ring_stale_dup_dev", "kmx_shard_local", "kmx_shard_complete", "kmx_dev_view", "kmx_or_words_dev",
-    "kmx_debug_pack_strings", "kmx_kernel_classes",
+    "kmx_debug_pack_strings", "kmx_kernel_classes", "kmx_abi_version",
 ]
 
 
@@ -131,6 +131,7 @@ def load_library():
     L.kmx_or_words_dev.argtypes = [vp, vp, vp, u64]
     L.kmx_debug_pack_strings.argtypes = [vp, vp, i32, i32, u64, vp, C.POINTER(i32)]
     L.kmx_kernel_classes.argtypes = []
+    L.kmx_abi_version.argtypes = []
     L.kmx_set_profile.argtypes = [vp, i32]
     L.kmx_get_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), i32]
     _lib = L

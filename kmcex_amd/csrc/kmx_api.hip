@@ -1821,14 +1821,16 @@ static int kmx_query_packed_impl(kmx_model *m, const uint64_t *kmers, uint64_t n
 }
 
 // vector<string> front door (kmodel.hpp:90-116).  The reference splits the vector over t_num threads (:93-96); here the
-// batch is cut into chunks that flow through a three-slot pipeline: worker threads turn chunk c into packed k-mers inside a
-// pinned slot (strpack.cpp: 8 bytes per string over the link instead of k), a copy stream moves it (hipMemcpyAsync), the
-// model's stream answers it (k_query), a second copy stream brings the answers back, and the workers hand them to the
-// caller's array -- chunk c is packed while c-1 is on the GPU and c-2 is copied out.  A chunk that holds a string the packed
-// form cannot express (other characters, or a length that is not the model's k) travels as bytes and is answered by the
-// byte-string kernel, which hashes the bytes as they are, exactly like the reference does -- chunk by chunk, so one dirty
-// string does not slow the whole batch down.
-static const u64 kQueryChunk = u64(1) << 20;
+// batch flows through a three-slot pipeline in chunks: worker threads turn chunk c into packed k-mers inside a pinned slot
+// (strpack.cpp: 8 bytes per string over the link instead of k), a copy stream moves it (hipMemcpyAsync), the model's stream
+// answers it (k_query), a second copy stream brings the answers back, and the workers hand them to the caller's array --
+// chunk c is packed while c-1 is on the GPU and c-2 is copied out.  The work is dealt in tasks of 2^14 strings from one
+// atomic counter (pack tasks of chunk c, then copy-out tasks of chunk c-2, and so on): no barrier between the threads.
+// A string the packed form cannot express (other characters) is remembered by its index and answered afterwards by the
+// byte-string kernel, which hashes the bytes as they are, exactly like the reference does -- the cost of dirty strings is
+// proportional to their number; a batch of another length than the model's k travels as bytes altogether.
+static const u64 kQuerySub = u64(1) << 14;                     // strings per task
+static const size_t kQuerySlotBytes = size_t(32) << 20;        // input bytes per slot
 
 static int ensure_query_feed(kmx_model *m, size_t in_bytes, size_t answers)
 {
@@ -1869,6 +1871,96 @@ static int ensure_query_feed(kmx_model *m, size_t in_bytes, size_t answers)
 	return KMX_OK;
 }
 
+// n items of item_bytes each through the pipeline.  stage(worker, lo, hi, dst): items [lo, hi) -> dst (their place in the
+// slot); launch(slot, count): the kernel from d_in[slot] to d_out[slot] on the model's stream; answers -> out[0 .. n).
+template <typename STAGE, typename LAUNCH>
+static int query_pipeline(kmx_model *m, u64 n, size_t item_bytes, int T, STAGE stage, LAUNCH launch, int32_t *out)
+{
+	auto &F = m->qfeed;
+	u64 C = std::max<u64>(kQuerySub, (kQuerySlotBytes / item_bytes) & ~(kQuerySub - 1));
+	C = std::min<u64>(C, (n + kQuerySub - 1) & ~(kQuerySub - 1));
+	const u64 nc = (n + C - 1) / C;
+	TRY(ensure_query_feed(m, (size_t)C * item_bytes, (size_t)C));
+	auto count_of = [&](u64 c) { return std::min<u64>(C, n - c * C); };
+	auto subs_of = [&](u64 c) { return (count_of(c) + kQuerySub - 1) / kQuerySub; };
+	auto enqueue = [&](u64 c) -> bool {
+		const int s = (int)(c % F.S);
+		const u64 cn = count_of(c);
+		if (hipMemcpyAsync(F.d_in[s], F.h_in[s], cn * item_bytes, hipMemcpyHostToDevice, F.to_dev) != hipSuccess || hipEventRecord(F.ev_in[s], F.to_dev) != hipSuccess ||
+		    hipStreamWaitEvent(m->stream, F.ev_in[s], 0) != hipSuccess) return false;
+		launch(s, cn);
+		return hipEventRecord(F.ev_k[s], m->stream) == hipSuccess && hipStreamWaitEvent(F.to_host, F.ev_k[s], 0) == hipSuccess &&
+		       hipMemcpyAsync(F.h_out[s], F.d_out[s], cn * 4, hipMemcpyDeviceToHost, F.to_host) == hipSuccess && hipEventRecord(F.ev_out[s], F.to_host) == hipSuccess;
+	};
+	if (nc == 1 && T == 1) {                                      // a handful of strings: no threads
+		stage(0, 0, n, F.h_in[0]);
+		if (!enqueue(0) || hipEventSynchronize(F.ev_out[0]) != hipSuccess) return fail(KMX_E_NODEVICE, "query failed");
+		memcpy(out, F.h_out[0], n * 4);
+		return KMX_OK;
+	}
+	// phase p = the pack tasks of chunk p, then the copy-out tasks of chunk p - 2
+	const u64 lag = F.S - 1, n_phase = nc + lag;
+	std::vector<u64> first(n_phase + 1, 0);
+	for (u64 p = 0; p < n_phase; p++) first[p + 1] = first[p] + (p < nc ? subs_of(p) : 0) + (p >= lag ? subs_of(p - lag) : 0);
+	std::unique_ptr<std::atomic<u32>[]> packed(new std::atomic<u32>[nc]), copied(new std::atomic<u32>[nc]), ready(new std::atomic<u32>[nc]);
+	for (u64 c = 0; c < nc; c++) { packed[c] = 0; copied[c] = 0; ready[c] = 0; }
+	std::atomic<u64> next{0};
+	std::atomic<bool> abort{false};
+	auto wait_for = [&](auto cond) {                              // short waits: spin, then give the core away
+		for (unsigned spins = 0; !cond(); spins++) {
+			if (abort.load(std::memory_order_relaxed)) return false;
+			if (spins < 256) __builtin_ia32_pause(); else std::this_thread::yield();
+		}
+		return true;
+	};
+	auto worker = [&](int t) {
+		u64 p = 0;
+		for (;;) {
+			const u64 id = next.fetch_add(1, std::memory_order_relaxed);
+			if (id >= first[n_phase]) return;
+			while (id >= first[p + 1]) p++;
+			u64 s = id - first[p];
+			const u64 n_pack = p < nc ? subs_of(p) : 0;
+			if (s < n_pack) {                                        // pack sub-piece s of chunk p
+				const u64 c = p;
+				if (c >= (u64)F.S && !wait_for([&] { return copied[c - F.S].load(std::memory_order_acquire) == subs_of(c - F.S); })) return;
+				const u64 lo = c * C + s * kQuerySub, hi = std::min<u64>(lo + kQuerySub, c * C + count_of(c));
+				stage(t, lo, hi, F.h_in[c % F.S] + (lo - c * C) * item_bytes);
+				packed[c].fetch_add(1, std::memory_order_release);
+			} else {                                                 // hand sub-piece s of chunk p - lag's answers to the caller
+				s -= n_pack;
+				const u64 c = p - lag;
+				if (!wait_for([&] { return ready[c].load(std::memory_order_acquire) != 0; })) return;
+				const u64 lo = c * C + s * kQuerySub, hi = std::min<u64>(lo + kQuerySub, c * C + count_of(c));
+				memcpy(out + lo, F.h_out[c % F.S] + (lo - c * C), (hi - lo) * 4);
+				copied[c].fetch_add(1, std::memory_order_release);
+			}
+		}
+	};
+	std::vector<std::thread> th;
+	for (int t = 0; t < T; t++) th.emplace_back(worker, t);
+	int rc = KMX_OK;
+	auto publish = [&](u64 c) {                                   // chunk c's answers are in its pinned slot
+		hipError_t e;
+		while ((e = hipEventQuery(F.ev_out[c % F.S])) == hipErrorNotReady) std::this_thread::yield();
+		if (e != hipSuccess && !rc) rc = fail(KMX_E_NODEVICE, "query failed");
+		if (rc) abort = true;
+		ready[c].store(1, std::memory_order_release);
+	};
+	for (u64 c = 0; c < nc && !rc; c++) {
+		wait_for([&] { return packed[c].load(std::memory_order_acquire) == subs_of(c); });
+		if (!enqueue(c)) { rc = fail(KMX_E_NODEVICE, "query pipeline: enqueue failed"); break; }
+		if (c >= 1) publish(c - 1);
+	}
+	if (!rc) publish(nc - 1);
+	else abort = true;
+	for (auto &x : th) x.join();
+	hipStreamSynchronize(F.to_dev); hipStreamSynchronize(F.to_host);
+	if (hipStreamSynchronize(m->stream) != hipSuccess && !rc) rc = fail(KMX_E_NODEVICE, "query failed");
+	if (!rc && hipGetLastError() != hipSuccess) rc = fail(KMX_E_NODEVICE, "query kernel failed");
+	return rc;
+}
+
 static int query_text(kmx_model *m, const KmxStrBatch &sb, uint64_t n, int32_t *out)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
@@ -1877,93 +1969,25 @@ static int query_text(kmx_model *m, const KmxStrBatch &sb, uint64_t n, int32_t *
 	if (len < 2 || len > 64 || sb.stride < len) return fail(KMX_E_ARG, "k-mer strings must hold 2..64 characters (got %d, stride %d)", len, sb.stride);
 	if (!n) return KMX_OK;
 	HIPCHK(hipSetDevice(m->device));
-	const bool packable = len == m->k;                           // (another length hashes differently from any k-mer of the model)
-	const u64 C = std::min<u64>(kQueryChunk, (n + 4095) & ~u64(4095)), nc = (n + C - 1) / C;
-	const int T = (int)std::max<u64>(1, std::min<u64>(std::min(kmx_host_cpus(), 32), n / 16384 + 1));
-	// a slot takes a chunk in either form; a batch that can only travel as bytes gets slots for that from the start
-	TRY(ensure_query_feed(m, (size_t)(C * std::max<u64>(8 * W, (u64)len)), (size_t)C));
-	auto &F = m->qfeed;
-	enum { UNDECIDED = 0, PACKED = 1, RAW = 2 };
-	std::mutex mu;
-	std::condition_variable cv;
-	std::vector<int> arrived(nc, 0), mode(nc, packable ? UNDECIDED : RAW), staged(nc, 0), copied(nc, 0);
-	std::vector<char> dirty(nc, 0), ready(nc, 0);
-	bool abort = false;
-	auto piece = [&](u64 c, int t, u64 &lo, u64 &hi) {            // worker t's share of chunk c, in strings of the batch
-		const u64 c0 = c * C, cn = std::min<u64>(C, n - c0), per = (cn + T - 1) / T;
-		lo = c0 + std::min<u64>(cn, (u64)t * per);
-		hi = c0 + std::min<u64>(cn, (u64)(t + 1) * per);
+	const int T = (int)std::max<u64>(1, std::min<u64>(std::min(kmx_host_cpus(), 32), n / 8192 + 1));
+	auto bytes_pass = [&](const KmxStrBatch &b, u64 cnt, int32_t *dst) {   // the strings as they are -> k_query_ascii
+		return query_pipeline(m, cnt, (size_t)len, (int)std::max<u64>(1, std::min<u64>(T, cnt / 8192 + 1)),
+		                      [&](int, u64 lo, u64 hi, unsigned char *d) { kmx_gather_strings(b, lo, hi, d); },
+		                      [&](int s, u64 cn) { kmxk::query_ascii(m->md, len, m->qfeed.d_in[s], len, cn, m->qfeed.d_out[s], m->stream); }, dst);
 	};
-	auto copy_out = [&](u64 c, int t) {
-		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready[c] || abort; }); if (abort) return; }
-		u64 lo, hi;
-		piece(c, t, lo, hi);
-		if (hi > lo) memcpy(out + lo, F.h_out[c % F.S] + (lo - c * C), (hi - lo) * 4);
-		std::lock_guard<std::mutex> lk(mu);
-		if (++copied[c] == T) cv.notify_all();
-	};
-	auto worker = [&](int t) {
-		const u64 lag = F.S - 1;
-		for (u64 c = 0; c < nc; c++) {
-			if (c >= (u64)F.S) {                                     // the slot is free once chunk c - S has left it
-				std::unique_lock<std::mutex> lk(mu);
-				cv.wait(lk, [&] { return copied[c - F.S] == T || abort; });
-				if (abort) return;
-			}
-			u64 lo, hi;
-			piece(c, t, lo, hi);
-			unsigned char *slot = F.h_in[c % F.S];
-			if (packable) {
-				const bool ok = hi > lo ? kmx_pack_strings(sb, W, lo, hi, (uint64_t *)slot + (lo - c * C) * W) : true;
-				std::unique_lock<std::mutex> lk(mu);
-				if (!ok) dirty[c] = 1;
-				if (++arrived[c] == T) { mode[c] = dirty[c] ? RAW : PACKED; cv.notify_all(); }
-				else cv.wait(lk, [&] { return mode[c] != UNDECIDED || abort; });
-				if (abort) return;
-			}
-			if (mode[c] == RAW) {
-				if (hi > lo) kmx_gather_strings(sb, lo, hi, slot + (lo - c * C) * (u64)len);
-				std::lock_guard<std::mutex> lk(mu);
-				if (++staged[c] == T) cv.notify_all();
-			}
-			if (c >= lag) copy_out(c - lag, t);
-		}
-		for (u64 c = nc > lag ? nc - lag : 0; c < nc; c++) copy_out(c, t);
-	};
-	std::vector<std::thread> th;
-	for (int t = 0; t < T; t++) th.emplace_back(worker, t);
-	int rc = KMX_OK;
-	auto publish = [&](u64 c) {                                   // chunk c's answers are in its pinned slot
-		if (hipEventSynchronize(F.ev_out[c % F.S]) != hipSuccess && !rc) rc = fail(KMX_E_NODEVICE, "query failed");
-		std::lock_guard<std::mutex> lk(mu);
-		ready[c] = 1;
-		if (rc) abort = true;
-		cv.notify_all();
-	};
-	for (u64 c = 0; c < nc && !rc; c++) {
-		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return mode[c] == PACKED || (mode[c] == RAW && staged[c] == T); }); }
-		const int s = (int)(c % F.S);
-		const u64 cn = std::min<u64>(C, n - c * C);
-		const size_t bytes = (size_t)(mode[c] == PACKED ? cn * W * 8 : cn * (u64)len);
-		if (hipMemcpyAsync(F.d_in[s], F.h_in[s], bytes, hipMemcpyHostToDevice, F.to_dev) != hipSuccess || hipEventRecord(F.ev_in[s], F.to_dev) != hipSuccess ||
-		    hipStreamWaitEvent(m->stream, F.ev_in[s], 0) != hipSuccess) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
-		if (!rc) {
-			if (mode[c] == PACKED) kmxk::query(m->md, (const u64 *)F.d_in[s], cn, F.d_out[s], m->stream, &m->prof);
-			else kmxk::query_ascii(m->md, len, F.d_in[s], len, cn, F.d_out[s], m->stream);
-			if (hipEventRecord(F.ev_k[s], m->stream) != hipSuccess || hipStreamWaitEvent(F.to_host, F.ev_k[s], 0) != hipSuccess ||
-			    hipMemcpyAsync(F.h_out[s], F.d_out[s], cn * 4, hipMemcpyDeviceToHost, F.to_host) != hipSuccess ||
-			    hipEventRecord(F.ev_out[s], F.to_host) != hipSuccess) rc = fail(KMX_E_NODEVICE, "D2H copy failed");
-		}
-		if (rc) break;
-		if (c >= 1) publish(c - 1);
-	}
-	if (!rc) publish(nc - 1);
-	else { std::lock_guard<std::mutex> lk(mu); abort = true; cv.notify_all(); }
-	for (auto &x : th) x.join();
-	hipStreamSynchronize(F.to_dev); hipStreamSynchronize(F.to_host);
-	if (hipStreamSynchronize(m->stream) != hipSuccess && !rc) rc = fail(KMX_E_NODEVICE, "query failed");
-	if (!rc && hipGetLastError() != hipSuccess) rc = fail(KMX_E_NODEVICE, "query kernel failed");
-	return rc;
+	if (len != m->k) return bytes_pass(sb, n, out);              // (another length hashes differently from any k-mer of the model)
+	std::vector<std::vector<uint64_t>> dirty((size_t)T);
+	TRY(query_pipeline(m, n, (size_t)W * 8, T,
+	                   [&](int t, u64 lo, u64 hi, unsigned char *d) { kmx_pack_strings(sb, W, lo, hi, (uint64_t *)d, &dirty[(size_t)t]); },
+	                   [&](int s, u64 cn) { kmxk::query(m->md, (const u64 *)m->qfeed.d_in[s], cn, m->qfeed.d_out[s], m->stream, &m->prof); }, out));
+	std::vector<const char *> dptr;
+	std::vector<uint64_t> didx;
+	for (auto &v : dirty) for (uint64_t i : v) { didx.push_back(i); dptr.push_back(sb.ptrs ? sb.ptrs[i] : sb.flat + i * (uint64_t)sb.stride); }
+	if (didx.empty()) return KMX_OK;
+	std::vector<int32_t> ans(didx.size());
+	TRY(bytes_pass(KmxStrBatch{dptr.data(), nullptr, len, len}, (u64)didx.size(), ans.data()));
+	for (size_t j = 0; j < didx.size(); j++) out[didx[j]] = ans[j];
+	return KMX_OK;
 }
 
 static int kmx_query_ascii_impl(kmx_model *m, const char *strs, int len, int stride, uint64_t n, int32_t *out)
@@ -2456,6 +2480,7 @@ extern "C" int kmx_debug_pack_strings(const char *const *strs, const char *flat,
 	});
 }
 extern "C" int kmx_kernel_classes(void) { return KMX_KERNEL_CLASSES; }
+extern "C" int kmx_abi_version(void) { return KMX_ABI_VERSION; }
 extern "C" int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds) { return guarded([&] { return kmx_microbench_impl(mode, bytes, touches, iters, seconds); }); }
 extern "C" int kmx_set_profile(kmx_model *m, int on) { return guarded([&] { return kmx_set_profile_impl(m, on); }); }
 static_assert(KC_N == KMX_KERNEL_CLASSES, "include/kmx.h promises KMX_KERNEL_CLASSES entries");

@@ -3,6 +3,8 @@
 // over the link) 16 characters per SSSE3 step, and the kernels do the rest.  Plain C++ (no HIP): compiled for the host only.
 #include "strpack.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <immintrin.h>
 #include <sched.h>
@@ -45,53 +47,47 @@ __attribute__((target("ssse3"))) inline uint64_t run_simd(const unsigned char *s
 	return (hi << (2 * r)) | (lo & ((1ULL << (2 * r)) - 1));
 }
 
-template <bool SIMD> inline uint64_t run(const unsigned char *s, int cnt, unsigned &bad)
+__attribute__((target("ssse3"))) bool pack_range_simd(const KmxStrBatch &b, int W, uint64_t lo, uint64_t hi, uint64_t *dst, std::vector<uint64_t> *dirty)
 {
-	if (SIMD) return run_simd(s, cnt, bad);
-	return run_scalar(s, cnt, bad);
-}
-
-template <bool SIMD>
-#if defined(__GNUC__)
-__attribute__((target("ssse3")))
-#endif
-bool pack_range_simd(const KmxStrBatch &b, int W, uint64_t lo, uint64_t hi, uint64_t *dst)
-{
-	unsigned bad = 0;
+	unsigned any = 0;
 	const int len = b.len;
 	for (uint64_t i = lo; i < hi; i++) {
 		const unsigned char *s = (const unsigned char *)(b.ptrs ? b.ptrs[i] : b.flat + i * (uint64_t)b.stride);
 		if (b.ptrs && i + 8 < hi) __builtin_prefetch(b.ptrs[i + 8]);
+		unsigned bad = 0;
 		if (W == 1) dst[i - lo] = run_simd(s, len, bad);
 		else {
 			dst[2 * (i - lo)] = run_simd(s, len - 32, bad);
 			dst[2 * (i - lo) + 1] = run_simd(s + (len - 32), 32, bad);
 		}
+		if (bad & 0x80) { any = 1; if (dirty) dirty->push_back(i); }
 	}
-	return !(bad & 0x80);
+	return !any;
 }
 
-bool pack_range_scalar(const KmxStrBatch &b, int W, uint64_t lo, uint64_t hi, uint64_t *dst)
+bool pack_range_scalar(const KmxStrBatch &b, int W, uint64_t lo, uint64_t hi, uint64_t *dst, std::vector<uint64_t> *dirty)
 {
-	unsigned bad = 0;
+	unsigned any = 0;
 	const int len = b.len;
 	for (uint64_t i = lo; i < hi; i++) {
 		const unsigned char *s = (const unsigned char *)(b.ptrs ? b.ptrs[i] : b.flat + i * (uint64_t)b.stride);
+		unsigned bad = 0;
 		if (W == 1) dst[i - lo] = run_scalar(s, len, bad);
 		else {
 			dst[2 * (i - lo)] = run_scalar(s, len - 32, bad);
 			dst[2 * (i - lo) + 1] = run_scalar(s + (len - 32), 32, bad);
 		}
+		if (bad & 0x80) { any = 1; if (dirty) dirty->push_back(i); }
 	}
-	return !(bad & 0x80);
+	return !any;
 }
 
 }   // namespace
 
-bool kmx_pack_strings(const KmxStrBatch &b, int W, uint64_t lo, uint64_t hi, uint64_t *dst)
+bool kmx_pack_strings(const KmxStrBatch &b, int W, uint64_t lo, uint64_t hi, uint64_t *dst, std::vector<uint64_t> *dirty)
 {
 	static const bool simd = __builtin_cpu_supports("ssse3");
-	return simd ? pack_range_simd<true>(b, W, lo, hi, dst) : pack_range_scalar(b, W, lo, hi, dst);
+	return simd ? pack_range_simd(b, W, lo, hi, dst, dirty) : pack_range_scalar(b, W, lo, hi, dst, dirty);
 }
 
 void kmx_gather_strings(const KmxStrBatch &b, uint64_t lo, uint64_t hi, unsigned char *dst)
@@ -103,8 +99,20 @@ void kmx_gather_strings(const KmxStrBatch &b, uint64_t lo, uint64_t hi, unsigned
 
 int kmx_host_cpus(void)
 {
+	int n = 1;
 	cpu_set_t set;
 	CPU_ZERO(&set);
-	if (sched_getaffinity(0, sizeof set, &set) == 0) { const int n = CPU_COUNT(&set); if (n > 0) return n; }
-	return 1;
+	if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = CPU_COUNT(&set);
+	long long quota = -1, period = 100000;
+	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {              // cgroup v2: "<quota|max> <period>"
+		char q[32] = "";
+		if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+		fclose(f);
+	} else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+		if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+		fclose(g);
+		if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+	}
+	if (quota > 0 && period > 0) { const int c = (int)((quota + period - 1) / period); if (c >= 1 && c < n) n = c; }
+	return n;
 }

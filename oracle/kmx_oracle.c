@@ -380,7 +380,19 @@ static void rest_build(kmo_model *m, rest_vec *r)
 }
 
 /* kmodel.hpp:57-86 + :423-434 + :458-527 */
+static int build_impl(kmo_model *m, int k, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint64_t total_kmers, const uint64_t *declared_n_bf);
 int kmo_build(kmo_model *m, int k, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint64_t total_kmers)
+{
+	return build_impl(m, k, kmers, counts, n, total_kmers, NULL);
+}
+/* The same build with the class counts of pass 1 DECLARED instead of counted (kmodel.hpp:423-434 counts them over the whole
+ * database): the model is sized for `total_kmers` / `n_bf` although only the first n k-mers of the listing are inserted --
+ * a prefix of a build too large for the CPU, on arrays of its full size (tests/test_gpu_fullsize.py). */
+int kmo_build_declared(kmo_model *m, int k, const uint64_t *kmers, const uint32_t *counts, uint64_t n, const uint64_t n_bf[3], uint64_t total_kmers)
+{
+	return build_impl(m, k, kmers, counts, n, total_kmers, n_bf);
+}
+static int build_impl(kmo_model *m, int k, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint64_t total_kmers, const uint64_t *declared_n_bf)
 {
 	if (!m || k < 3 || k > 64) return -1;
 	int W = (k + 31) / 32, nb = m->nb;
@@ -391,6 +403,7 @@ int kmo_build(kmo_model *m, int k, const uint64_t *kmers, const uint32_t *counts
 		if (counts[i] < (uint32_t)m->ci || counts[i] > (uint32_t)m->cs) return -4;      /* D4 */
 		if (counts[i] < (uint32_t)(m->ci + m->bf_num)) m->n_bf[counts[i] - (uint32_t)m->ci]++;
 	}
+	if (declared_n_bf) for (int i = 0; i < 3; i++) m->n_bf[i] = i < m->bf_num ? declared_n_bf[i] : 0;
 	m->total = total_kmers;
 	init_bf_parameter(m);
 	uint64_t nbf = 0;

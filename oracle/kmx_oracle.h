@@ -45,6 +45,7 @@ kmo_model *kmo_create(int ci, int cs, int nh, int nb);
 void       kmo_destroy(kmo_model *m);
 /* kmers: n*W words in LISTING ORDER, counts already within [min,max]; total_kmers = KmerCount() */
 int        kmo_build(kmo_model *m, int k, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint64_t total_kmers);
+int        kmo_build_declared(kmo_model *m, int k, const uint64_t *kmers, const uint32_t *counts, uint64_t n, const uint64_t n_bf[3], uint64_t total_kmers);   /* a prefix of a build on arrays of its full size */
 int        kmo_save(const kmo_model *m, const char *dir);
 kmo_model *kmo_load(const char *dir);
 void       kmo_get_stats(const kmo_model *m, kmo_stats *st);

@@ -38,6 +38,7 @@ def lib():
         L.kmo_create.argtypes = [C.c_int] * 4
         L.kmo_destroy.argtypes = [C.c_void_p]
         L.kmo_build.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+        L.kmo_build_declared.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64]
         L.kmo_save.argtypes = [C.c_void_p, C.c_char_p]
         L.kmo_load.restype = C.c_void_p
         L.kmo_load.argtypes = [C.c_char_p]
@@ -97,6 +98,23 @@ class OracleModel:
         rc = self.L.kmo_build(self.h, k, kmers.ctypes.data, counts.ctypes.data, n, n if total is None else total)
         if rc:
             raise RuntimeError(f"kmo_build rc={rc}")
+
+    def build_declared(self, k: int, kmers: np.ndarray, counts: np.ndarray, n_bf, total: int):
+        """The first len(counts) k-mers of a listing whose pass 1 would have found `n_bf` / `total` (kmo_build_declared)."""
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        nbf = (C.c_uint64 * 3)(*[int(x) for x in (list(n_bf) + [0, 0, 0])[:3]])
+        rc = self.L.kmo_build_declared(self.h, k, kmers.ctypes.data, counts.ctypes.data, len(counts), nbf, total)
+        if rc:
+            raise RuntimeError(f"kmo_build_declared rc={rc}")
+
+    def array_view(self, which: str, i: int = 0) -> np.ndarray:
+        """array_bytes without the copy (arrays of a 10^10-k-mer model are 3.8 GB each)"""
+        st = self.stats()
+        p, n = {"km_back": lambda: (self.L.kmo_km_back(self.h), st.byte_km_back), "bf": lambda: (self.L.kmo_bf(self.h, i), st.byte_bf[i]),
+                "bf_back": lambda: (self.L.kmo_bf_back(self.h, i), st.byte_bf_back[i]), "value": lambda: (self.L.kmo_value_array(self.h, i), st.km_byte_size),
+                "tag": lambda: (self.L.kmo_tag_array(self.h, i), st.km_byte_size)}[which]()
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(int(n),)) if n else np.zeros(0, np.uint8)
 
     def save(self, d: str):
         os.makedirs(d, exist_ok=True)

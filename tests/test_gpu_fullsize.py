@@ -214,6 +214,50 @@ def test_hc14_scale_properties():
     assert digests == g["sha256"]
 
 
+def test_na12878_sized_arrays_prefix_matches_oracle_bytes():
+    """An independent witness for configs[3]'s size: the model is DECLARED at 10^10 k-mers (the pinned class counts: 8 683 276 598
+    coupled, the rest in the Bloom class -- kmx_begin / kmo_build_declared size every array from the declared totals,
+    kmodel.hpp:402-456), but only 3*10^8 k-mers are inserted, which the CPU oracle does in minutes.  That exercises what the
+    size changes -- 3.04*10^10 positions per array (35-bit addressing, cl_mix near its 2^36 limit), 3.8 GB tag / value arrays,
+    the two-level partitioned bit-sets of a 2.7 GB km_back -- against the oracle byte for byte: all ten arrays, km_back, the Bloom
+    filter and its back filter, the statistics, and a query sample."""
+    import psutil
+    dev = torch.device("cuda", 0)
+    if torch.cuda.mem_get_info()[1] < 100 * 2 ** 30:
+        pytest.skip("needs 100 GB of HBM")
+    if psutil.virtual_memory().available < 70 * 2 ** 30:
+        pytest.skip("the oracle's arrays of a 10^10-k-mer model need 45 GB of host memory")
+    g = json.load(open(NA12878_GOLDEN))
+    total, n_km = g["n_kmers"], g["stats"]["n_km"]
+    n_bf = [total - n_km, 0, 0]
+    km, cnt = synth_torch.make_stream(300_000_000, K, CI, CS, dev)
+    n = km.numel()
+    m = KModel(CI, CS, NH, NB)
+    m.begin(K, n_bf, total)
+    m.insert_batch_dev(km.data_ptr(), cnt.data_ptr(), n)
+    m.finish()
+    st = m.stats()
+    assert st.km_byte_size * 8 > 7 * 2 ** 32 and st.n_km == n_km
+    hk, hc = km.cpu().numpy().view(np.uint64), cnt.cpu().numpy().view(np.uint32)
+    o = O.OracleModel(CI, CS, NH, NB)
+    o.build_declared(K, hk, hc, n_bf, total)
+    so = o.stats()
+    assert (st.km_byte_size, st.byte_km_back, st.byte_bf[0], st.byte_bf_back[0]) == (so.km_byte_size, so.byte_km_back, so.byte_bf[0], so.byte_bf_back[0])
+    assert (st.attempts, st.successes, st.rest_entries) == (so.attempts, so.successes, so.rest_entries)
+    for a in range(NB):
+        for which in ("tag", "value"):
+            got = m.download(which, a)
+            assert np.array_equal(got, o.array_view(which, a)), (which, a)
+            del got
+    for which in ("km_back", "bf", "bf_back"):
+        assert np.array_equal(m.download(which, 0), o.array_view(which, 0)), which
+    q = torch.cat([km[::300], synth_torch.revcomp(km[7::1000], K), synth_torch.random_kmers(300_000, K, 0xABCDEF0123, dev)])
+    out = torch.empty(q.numel(), dtype=torch.int32, device=dev)
+    m.kmer_to_occ_dev(q.data_ptr(), q.numel(), out.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), o.query_packed(K, q.cpu().numpy().view(np.uint64), threads=32))
+
+
 NA12878_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "na12878_scale.json")
 
 
