@@ -2697,3 +2697,5 @@ void micro(int mode, u64 *buf, u64 ncell, u64 n_lanes, u64 salt, u64 *sink, hipS
 }
 
 }   // namespace kmxk
+
+#include "range_kernels.h"

@@ -158,6 +158,27 @@ struct RingList {
 };
 struct RingLists { RingList e[KMX_MAX_NB]; };
 
+// ---- the position-range partition of the coupled arrays over several GPUs (range_kernels.h)
+#define KMX_MAX_RANKS 16
+struct RangePlan {
+	int rank, world;
+	u64 cell_lo[KMX_MAX_RANKS + 1];   // rank q owns the cells [cell_lo[q], cell_lo[q+1]) -- 16 positions each -- of every array
+};
+struct RangeDev {
+	u64 *send;               // [world][cap] words leaving this rank, by destination (triples of a round, then its winners' commits)
+	int *send_cnt;           // [KMX_MAX_RANKS * KMX_CTR_STRIDE] words per destination
+	u64 cap;
+	u32 *tidx;               // [nb*BUCKET][nh] where the triple of hash j of a slot went: destination << 28 | index in its region
+	u32 *contended;          // [nb*BUCKET] slots of the contended candidates of a list (any order)
+	int *n_contended;        // [KMX_MAX_NB * KMX_CTR_STRIDE]
+	// k_range_resolve: exact position table per held list (2^rt_bits entries), per-record scratch
+	u64 *rt_key;
+	u32 *rt_resv, *rt_mark;
+	u32 *rt_eidx;            // [nb*BUCKET][nh]
+	u32 *rt_um;              // [nb*BUCKET]
+	u32 rt_bits;
+};
+
 enum { SLOT_UNDECIDED = 0, SLOT_FAILED = 1, SLOT_INSERTED = 2, SLOT_CONTENDED = 3 };
 
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).

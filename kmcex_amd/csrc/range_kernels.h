@@ -1,0 +1,379 @@
+// range_kernels.h -- the north star's multi-GPU partition on the device: every coupled array cut by POSITION RANGE across
+// the ranks.  Included at the end of kernels.hip (one translation unit: c_seeds, the claim tuples, k_round_detect
+// and k_reorder are shared with the single-GPU path).
+//
+// Rank q owns the cells [cell_lo[q], cell_lo[q+1]) -- 16 positions each -- of EVERY array.  List i of a block lives on rank
+// i % P for the whole block: it hashes its k-mers, keeps the list order and reorders locally (kmodel.hpp:529-540); k-mers
+// never move.  A round (all lists at once, list i against array (i + t) % nb, kmodel.hpp:560-565) is three exchanges:
+//   1. k_range_emit        list rank: one TRIPLE (position, wanted value, list, slot, hash index) per position of every attempt,
+//                          binned by owner rank                                      -> all-to-all
+//   2. k_range_verdict     owner: reads the cell -- conflict with a set tag (kmodel.hpp:604-610) | untagged --, files every
+//      k_round_detect      untagged claim in the position-hashed bins of the single-GPU path and lets ITS detect kernel find
+//      k_range_verdict2    the positions wanted with both values by claims of this round: the owner sees every claim on its
+//                          positions, so contention is found where the bits live.  One verdict byte per triple -> all-to-all back
+//   3. k_range_apply       list rank: a slot with a conflict anywhere has failed (final: bits are never cleared); a candidate
+//      k_range_resolve     none of whose untagged positions is contended wins outright; the contended ones are decided in list
+//      k_range_commit_emit order from the verdicts alone (the only writers that can matter to them are earlier contended
+//                          winners): priority reservations on an exact position table, the smallest undecided slot always
+//                          wins its turn.  The winners' (position, value) pairs -> all-to-all -> k_range_commit_apply on the owners.
+// Then k_reorder, the km_back emission of the round and, after the last round, k_rest_append -- the single-GPU kernels.
+#pragma once
+
+// triple: position (36 bits) | want << 36 | list << 37 | slot << 41 | hash index << 59
+#define RT_POS(tr) ((tr) & ((1ULL << 36) - 1))
+#define RT_WANT(tr) ((u32)((tr) >> 36) & 1u)
+#define RT_LIST(tr) ((u32)((tr) >> 37) & 15u)
+#define RT_X(tr) ((u32)((tr) >> 41) & (KMX_BUCKET - 1))
+#define RT_J(tr) ((u32)((tr) >> 59) & 15u)
+#define RT_MAKE(pos, want, i, x, j) ((u64)(pos) | ((u64)(want) << 36) | ((u64)(i) << 37) | ((u64)(x) << 41) | ((u64)(j) << 59))
+enum { RV_CONFLICT = 1, RV_UNTAGGED = 2, RV_BOTH = 4 };
+
+__device__ __forceinline__ int range_owner(const RangePlan &pl, u64 cell)
+{
+	int q = 0;
+#pragma unroll 1
+	while (q + 1 < pl.world && cell >= pl.cell_lo[q + 1]) q++;
+	return q;
+}
+
+// Appends this thread's `cnt` (<= NHM) words, each to the region of its destination rank: the workgroup counts per
+// destination in LDS, reserves each run with ONE global atomic, and remembers where every word went (where[j]).
+template <int NHM> __device__ __forceinline__ void range_block_append(const RangeDev &rd, int world, const u64 *word, const int *dest, u32 valid, u32 *where, int *s_cnt, int *s_base)
+{
+	if ((int)threadIdx.x < world) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	int rank[NHM];
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if ((valid >> j) & 1u) rank[j] = atomicAdd(&s_cnt[dest[j]], 1);
+	__syncthreads();
+	if ((int)threadIdx.x < world) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(rd.send_cnt + (int)threadIdx.x * KMX_CTR_STRIDE, s_cnt[threadIdx.x]) : 0;
+	__syncthreads();
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if ((valid >> j) & 1u) {
+			const u64 off = (u64)(s_base[dest[j]] + rank[j]);
+			rd.send[(u64)dest[j] * rd.cap + off] = word[j];
+			if (where) where[j] = ((u32)dest[j] << 28) | (u32)off;
+		}
+	__syncthreads();
+}
+
+// 1. every attempt of the lists this rank holds -> triples by owner rank; positions kept per slot (crec) for steps 3
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_range_emit(ModelDev md, BlockDev bd, RangeDev rd, RangePlan pl, int t, int pp)
+{
+	__shared__ int s_cnt[KMX_MAX_RANKS], s_base[KMX_MAX_RANKS];
+	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	const int n = bd.n[pp][i];
+	if ((int)blockIdx.x * 256 >= n) return;                             // uniform
+	const u64 row = (u64)i * KMX_BUCKET;
+	const int a = (i + t) % md.nb;
+	if (x == 0) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
+	u64 word[NHM];
+	int dest[NHM];
+	u32 where[NHM], valid = 0;
+	if (x < n) {
+		const u32 raw = bd.list[pp][row + x];
+		const u32 idx = (raw & LIST_HOLE) ? bd.mover[pp][row + (raw & ~LIST_HOLE)] : raw;
+		if (raw & LIST_HOLE) bd.list[pp][row + x] = idx;                // later kernels of the round read plain entries
+		u64 v[W];
+		load_kmer<W>(bd.kmers, row + idx, v);
+		const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+		Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
+		u64 pos[NHM];
+#pragma unroll
+		for (int j = 0; j < NHM; j++)
+			if (j < md.nh) {
+				pos[j] = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(a * md.nh + j) & 127]), md.km_mod);
+				word[j] = RT_MAKE(pos[j], (bin >> j) & 1u, i, x, j);
+				dest[j] = range_owner(pl, pos[j] >> 4);
+				valid |= 1u << j;
+			}
+		crec_store<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh, pos);
+		bd.uw[pp][row + x] = bin << 16;                                  // the untagged mask arrives with the verdicts
+		bd.status[pp][row + x] = SLOT_UNDECIDED;
+	}
+	range_block_append<NHM>(rd, pl.world, word, dest, valid, where, s_cnt, s_base);
+	if (x < n)
+#pragma unroll
+		for (int j = 0; j < NHM; j++)
+			if (j < md.nh) rd.tidx[(row + x) * (u64)md.nh + j] = where[j];
+}
+
+// 2a. owner: the state of every claimed position; untagged claims go to the detect bins of their list
+template <int NHM> __global__ __launch_bounds__(256) void k_range_verdict(ModelDev md, BlockDev obd, int t, const u64 *triples, u64 n, unsigned char *verdict)
+{
+	constexpr int NBIN = KMX_CL_BINS(NHM), CAP = KMX_CL_CAP_OF(NHM);
+	for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < n; q += (u64)gridDim.x * 256) {
+		const u64 tr = triples[q];
+		const u64 pos = RT_POS(tr);
+		const u32 i = RT_LIST(tr), want = RT_WANT(tr);
+		const int a = (int)((i + (u32)t) % (u32)md.nb);
+		const cell_t c = md.cells[a][pos >> 4];
+		const u32 b = bit_in_cell(pos);
+		const u32 tag = (c >> (16 + b)) & 1u, val = (c >> b) & 1u;
+		unsigned char v = 0;
+		if (tag) v = val != want ? RV_CONFLICT : 0;
+		else {
+			v = RV_UNTAGGED;
+			const u64 mx = cl_mix(pos);
+			const u32 bin = cl_bin(mx);
+			const int g = atomicAdd(obd.cl_cnt[0] + i * KMX_CL_MAXBINS + bin, 1);
+			if (g < CAP) obd.cl_tup[0][((u64)i * NBIN + bin) * CAP + g] = CL_TUPLE(mx, want, RT_X(tr));
+			else obd.cl_ovf[i] = 1;                                     // tuples lost: every untagged claim of the list counts as contended
+		}
+		verdict[q] = v;
+	}
+}
+// 2b. after k_round_detect on the owner's bins: a slot it marked holds a position that is wanted with both values
+__global__ __launch_bounds__(256) void k_range_verdict2(BlockDev obd, const u64 *triples, u64 n, unsigned char *verdict)
+{
+	for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < n; q += (u64)gridDim.x * 256) {
+		const unsigned char v = verdict[q];
+		if (!(v & RV_UNTAGGED)) continue;
+		const u64 tr = triples[q];
+		const u32 i = RT_LIST(tr);
+		if (obd.status[0][(u64)i * KMX_BUCKET + RT_X(tr)] == SLOT_CONTENDED || obd.cl_ovf[i]) verdict[q] = v | RV_BOTH;
+	}
+}
+
+// 3a. list rank: the verdicts of a slot's positions, gathered from where its triples went
+template <int NHM> __global__ __launch_bounds__(256) void k_range_apply(ModelDev md, BlockDev bd, RangeDev rd, int world, int pp, const unsigned char *verdict)
+{
+	__shared__ int s_fail, s_cnt, s_base;
+	__shared__ u64 s_off[KMX_MAX_RANKS];
+	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	const int n = bd.n[pp][i];
+	if ((int)blockIdx.x * 256 >= n) return;                             // uniform
+	if (threadIdx.x == 0) {
+		s_fail = 0; s_cnt = 0;
+		u64 o = 0;
+		for (int q = 0; q < world; q++) { s_off[q] = o; o += (u64)rd.send_cnt[q * KMX_CTR_STRIDE]; }   // the triples travelled grouped by destination, in rank order
+	}
+	__syncthreads();
+	const u64 row = (u64)i * KMX_BUCKET;
+	bool failed = false, contended = false;
+	if (x < n) {
+		u32 um = 0, both = 0;
+#pragma unroll
+		for (int j = 0; j < NHM; j++)
+			if (j < md.nh) {
+				const u32 w = rd.tidx[(row + x) * (u64)md.nh + j];
+				const unsigned char v = verdict[s_off[w >> 28] + (w & 0x0FFFFFFFu)];
+				failed |= (v & RV_CONFLICT) != 0;
+				um |= (v & RV_UNTAGGED) ? 1u << j : 0u;
+				both |= (v & RV_BOTH) ? 1u << j : 0u;
+			}
+		contended = !failed && both != 0;
+		bd.uw[pp][row + x] |= um;
+		if (failed) bd.status[pp][row + x] = SLOT_FAILED;
+	}
+	const u64 fm = __ballot(failed);
+	if ((threadIdx.x & 63) == 0 && fm) atomicAdd(&s_fail, (int)__popcll(fm));
+	const int slot = block_append_slot(rd.n_contended + i * KMX_CTR_STRIDE, contended, &s_cnt, &s_base);
+	if (contended) rd.contended[row + slot] = (u32)x;
+	if (threadIdx.x == 0 && s_fail) atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (int)(blockIdx.x >> 2), s_fail);   // survivors per 1024-slot tile (k_reorder)
+}
+
+// 3b. the contended candidates of a list, in list order, from the verdicts alone.  ONE workgroup per list; an exact
+// position table in global memory (open addressing on the position itself): a record reserves every position it still
+// believes untagged with its priority (smaller slot first); whoever holds all of its positions has no earlier undecided
+// record on any of them -- it wins and MARKS them with the value it commits (a k-mer that hits a position twice leaves the
+// OR, kmodel.hpp:611-618); a record that meets a mark with the other value has failed, with its own value the position
+// leaves its mask.  The smallest undecided slot wins every iteration, and a later record can never win a position an
+// earlier undecided one still wants, so the outcome is the sequential one (the scheme of finish_lds, without its size limit).
+__device__ __forceinline__ u32 rt_hash(u64 pos) { return (u32)((pos * 0x9E3779B97F4A7C15ULL) >> 32); }
+template <int NHM> __global__ __launch_bounds__(1024) void k_range_resolve(ModelDev md, BlockDev bd, RangeDev rd, int world, int pp)
+{
+	__shared__ int s_pending, s_succ;
+	const int i = blockIdx.x, tab = i / world;                          // the lists a rank holds are i = rank, rank + world, ...: one table each
+	const int nc = rd.n_contended[i * KMX_CTR_STRIDE];
+	if (nc == 0) return;
+	const u64 row = (u64)i * KMX_BUCKET;
+	int tb = 10;
+	while ((1u << tb) < 4u * (u32)nc * (u32)md.nh && tb < (int)rd.rt_bits) tb++;
+	const u32 tmask = (1u << tb) - 1;
+	u64 *key = rd.rt_key + ((u64)tab << rd.rt_bits);
+	u32 *resv = rd.rt_resv + ((u64)tab << rd.rt_bits), *mark = rd.rt_mark + ((u64)tab << rd.rt_bits);
+	u32 *eidx = rd.rt_eidx + row * (u64)md.nh, *cur = rd.rt_um + row;     // per record: table entry of each position / mask still believed untagged | live
+	const u32 *cont = rd.contended + row;
+	constexpr u32 LIVE = 1u << 31;
+	for (u32 q = threadIdx.x; q <= tmask; q += 1024) { key[q] = 0; resv[q] = 0; mark[q] = 0; }
+	if (threadIdx.x == 0) { s_succ = 0; atomicAdd(bd.stats + ST_CONTENDED, (u64)nc); atomicMax(bd.stats + ST_MAX_U0, (u64)nc); }
+	drain_vmem();
+	__syncthreads();
+	for (int r = threadIdx.x; r < nc; r += 1024) {
+		const u32 x = cont[r];
+		const u32 um = bd.uw[pp][row + x] & 0xFFFFu;
+		const CRec<NHM> cr = crec_load<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh);
+#pragma unroll
+		for (int j = 0; j < NHM; j++)
+			if (j < md.nh && ((um >> j) & 1u)) {
+				const u64 pos = ((u64)crec_cell<NHM>(cr, j) << 4) | crec_nib<NHM>(cr, md.nh, j);
+				u32 e = rt_hash(pos) & tmask;
+				for (;;) {
+					const u64 old = atomicCAS(&key[e], 0ULL, pos + 1);
+					if (old == 0 || old == pos + 1) break;
+					e = (e + 1) & tmask;
+				}
+				eidx[(u64)r * md.nh + j] = e;
+			}
+		cur[r] = um | LIVE;
+	}
+	drain_vmem();
+	__syncthreads();
+	u64 iters = 0;
+	for (;; iters++) {
+		if (threadIdx.x == 0) s_pending = 0;
+		for (int r = threadIdx.x; r < nc; r += 1024) {                 // 1: reserve
+			const u32 c = cur[r];
+			if (!(c & LIVE)) continue;
+			const u32 prio = 0x40000u - cont[r];
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((c >> j) & 1u)) atomicMax(&resv[eidx[(u64)r * md.nh + j]], prio);
+		}
+		drain_vmem();
+		__syncthreads();
+		int succ = 0;
+		for (int r = threadIdx.x; r < nc; r += 1024) {                 // 2: whoever holds everything wins and marks
+			const u32 c = cur[r];
+			if (!(c & LIVE)) continue;
+			const u32 x = cont[r], prio = 0x40000u - x, want = bd.uw[pp][row + x] >> 16;
+			bool mine = true;
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((c >> j) & 1u)) mine &= cell_load_coherent(&resv[eidx[(u64)r * md.nh + j]]) == prio;
+			if (!mine) continue;
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((c >> j) & 1u)) {
+					const u32 e = eidx[(u64)r * md.nh + j];
+					u32 v = (want >> j) & 1u;
+#pragma unroll
+					for (int j2 = 0; j2 < NHM; j2++)
+						if (j2 < md.nh && j2 != j && ((c >> j2) & 1u) && eidx[(u64)r * md.nh + j2] == e) v |= (want >> j2) & 1u;
+					atomicOr(&mark[e], 1u << v);
+				}
+			bd.status[pp][row + x] = SLOT_INSERTED;
+			cur[r] = 0;
+			succ++;
+		}
+		if (succ) atomicAdd(&s_succ, succ);
+		drain_vmem();
+		__syncthreads();
+		for (int r = threadIdx.x; r < nc; r += 1024) {                 // 3: what the winners marked
+			u32 c = cur[r];
+			if (!(c & LIVE)) continue;
+			const u32 x = cont[r], want = bd.uw[pp][row + x] >> 16;
+			bool conflict = false;
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((c >> j) & 1u)) {
+					const u32 e = eidx[(u64)r * md.nh + j];
+					const u32 mk = cell_load_coherent(&mark[e]);
+					if (mk) { conflict |= ((mk >> 1) & 1u) != ((want >> j) & 1u); c &= ~(1u << j); }
+					else resv[e] = 0;                                    // everybody who still wants it reserves it again
+				}
+			if (conflict) { mark_failed(bd, pp, i, row, x); cur[r] = 0; }
+			else { cur[r] = c; s_pending = 1; }
+		}
+		drain_vmem();
+		__syncthreads();
+		const int pending = s_pending;
+		__syncthreads();
+		if (!pending) break;
+	}
+	if (threadIdx.x == 0) {
+		atomicAdd(bd.stats + ST_FIN_ITERS, iters + 1);
+		if (s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)s_succ);
+	}
+}
+
+// 3c. the winners' tag / value bits, by owner rank: one word per position they saw untagged (kmodel.hpp:611-618)
+template <int NHM> __global__ __launch_bounds__(256) void k_range_commit_emit(ModelDev md, BlockDev bd, RangeDev rd, RangePlan pl, int pp)
+{
+	__shared__ int s_cnt[KMX_MAX_RANKS], s_base[KMX_MAX_RANKS];
+	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	const int n = bd.n[pp][i];
+	if ((int)blockIdx.x * 256 >= n) return;                             // uniform
+	const u64 row = (u64)i * KMX_BUCKET;
+	u64 word[NHM];
+	int dest[NHM];
+	u32 valid = 0;
+	if (x < n && bd.status[pp][row + x] != SLOT_FAILED) {
+		const u32 uw = bd.uw[pp][row + x], um = uw & 0xFFFFu, want = uw >> 16;
+		const CRec<NHM> cr = crec_load<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh);
+		u64 pos[NHM];
+#pragma unroll
+		for (int j = 0; j < NHM; j++)
+			if (j < md.nh) pos[j] = ((u64)crec_cell<NHM>(cr, j) << 4) | crec_nib<NHM>(cr, md.nh, j);
+#pragma unroll
+		for (int j = 0; j < NHM; j++)
+			if (j < md.nh && ((um >> j) & 1u)) {
+				word[j] = RT_MAKE(pos[j], value_at_position<NHM>(md, pos, um, want, j), i, 0, 0);
+				dest[j] = range_owner(pl, pos[j] >> 4);
+				valid |= 1u << j;
+			}
+	}
+	range_block_append<NHM>(rd, pl.world, word, dest, valid, nullptr, s_cnt, s_base);
+}
+// ... and their application on the owner
+__global__ __launch_bounds__(256) void k_range_commit_apply(ModelDev md, int t, const u64 *commits, u64 n)
+{
+	for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < n; q += (u64)gridDim.x * 256) {
+		const u64 tr = commits[q];
+		const u64 pos = RT_POS(tr);
+		const int a = (int)((RT_LIST(tr) + (u32)t) % (u32)md.nb);
+		const u32 b = bit_in_cell(pos);
+		atomicOr(md.cells[a] + (pos >> 4), CELL_TAG(b) | (RT_WANT(tr) ? CELL_VAL(b) : 0u));
+	}
+}
+
+namespace kmxk {
+
+static inline unsigned range_grid(u64 n) { return (unsigned)std::min<u64>((n + 255) / 256, 1u << 16); }
+
+void range_emit(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangePlan &pl, int t, int pp, hipStream_t st)
+{
+	hipMemsetAsync(rd.send_cnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, st);
+	hipMemsetAsync(rd.n_contended, 0, sizeof(int) * KMX_MAX_NB * KMX_CTR_STRIDE, st);
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_range_emit<W, NHM>), dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, md, bd, rd, pl, t, pp));
+}
+// obd: the owner's view (scratch status, its own overflow flags; the claim bins of the handle, unused by the list side here)
+void range_verdict(const ModelDev &md, const BlockDev &obd, int t, const u64 *triples, u64 n, unsigned char *verdict, hipStream_t st)
+{
+	if (!n) return;
+	if (md.nh <= 8) {
+		hipLaunchKernelGGL((k_range_verdict<8>), dim3(range_grid(n)), dim3(256), 0, st, md, obd, t, triples, n, verdict);
+		hipLaunchKernelGGL((k_round_detect<8, 1024>), dim3(KMX_CL_BINS(8), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0);
+	} else {
+		hipLaunchKernelGGL((k_range_verdict<16>), dim3(range_grid(n)), dim3(256), 0, st, md, obd, t, triples, n, verdict);
+		hipLaunchKernelGGL((k_round_detect<16, 1024>), dim3(KMX_CL_BINS(16), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0);
+	}
+	hipLaunchKernelGGL(k_range_verdict2, dim3(range_grid(n)), dim3(256), 0, st, obd, triples, n, verdict);
+	hipMemsetAsync(obd.status[0], 0, (u64)md.nb * KMX_BUCKET, st);
+	hipMemsetAsync(obd.cl_ovf, 0, sizeof(int) * md.nb, st);
+}
+void range_resolve(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangePlan &pl, int t, int pp, const unsigned char *verdict, hipStream_t st)
+{
+	const dim3 grid(KMX_BUCKET / 256, md.nb);
+	if (md.nh <= 8) {
+		hipLaunchKernelGGL((k_range_apply<8>), grid, dim3(256), 0, st, md, bd, rd, pl.world, pp, verdict);
+		hipLaunchKernelGGL((k_range_resolve<8>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl.world, pp);
+		hipMemsetAsync(rd.send_cnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, st);
+		hipLaunchKernelGGL((k_range_commit_emit<8>), grid, dim3(256), 0, st, md, bd, rd, pl, pp);
+	} else {
+		hipLaunchKernelGGL((k_range_apply<16>), grid, dim3(256), 0, st, md, bd, rd, pl.world, pp, verdict);
+		hipLaunchKernelGGL((k_range_resolve<16>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl.world, pp);
+		hipMemsetAsync(rd.send_cnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, st);
+		hipLaunchKernelGGL((k_range_commit_emit<16>), grid, dim3(256), 0, st, md, bd, rd, pl, pp);
+	}
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, md.nb), dim3(256), 0, st, md, bd, t, pp, 0));   // (no REC_WON records here: Un stays 0)
+}
+void range_commit_apply(const ModelDev &md, int t, const u64 *commits, u64 n, hipStream_t st)
+{
+	if (n) hipLaunchKernelGGL(k_range_commit_apply, dim3(range_grid(n)), dim3(256), 0, st, md, t, commits, n);
+}
+
+}   // namespace kmxk
