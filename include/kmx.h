@@ -125,6 +125,26 @@ int kmx_ring_stale_dup_dev(kmx_model *m, int first_unused_row);
 int kmx_shard_local(kmx_model *m, kmx_stats *partial, void **d_rest_kmers, void **d_rest_counts);
 /* kld->build() on the survivors of ALL ranks + the summed statistics; the handle becomes a full replica (kmodel.hpp:80) */
 int kmx_shard_complete(kmx_model *m, const uint64_t *d_rest_kmers, const int32_t *d_rest_counts, uint64_t n_rest, const kmx_stats *totals);
+/* ---- the same model with every coupled array cut by POSITION RANGE over the ranks: rank q owns the cells
+ * [cell_lo[q], cell_lo[q+1]) -- 16 positions each -- of every array; list i of a block lives on rank i % world for the whole
+ * block and its k-mers never move.  A round of insert_array (kmodel.hpp:543-555, :560-565; check :604-610, set :611-618) is
+ * three exchanges of 64-bit words that the CALLER moves between the ranks (all-to-all over RCCL): triples -> verdicts ->
+ * commits.  kmx_count_classes_dev, kmx_shard_classify_dev, kmx_ring_stale_dup_dev, kmx_shard_local / _complete and
+ * kmx_dev_view are shared with the ring.                                                                               */
+int kmx_range_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world);
+/* the send regions: region q (cap_words 64-bit words apart) holds what the last emit / resolve left for rank q         */
+int kmx_range_buffers(kmx_model *m, void **d_send, uint64_t *cap_words, uint64_t *cell_lo /* [world + 1] */);
+/* step 1, list rank: every position of every attempt of its lists as a triple, by owner rank; counts[world] on the host.
+ * t == 0: `lists` = the fresh buffers of the block this rank holds (list, n_host, src_kmers, src_counts)              */
+int kmx_range_emit_dev(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists, uint64_t *counts);
+/* step 2, owner: conflict | untagged | wanted with both values this round -- one byte per received triple, same order   */
+int kmx_range_verdict_dev(kmx_model *m, int t, const uint64_t *d_triples, uint64_t n, uint8_t *d_verdict);
+/* step 3, list rank: verdicts in the order the triples left (regions concatenated in rank order) -> winners (the contended
+ * ones decided in list order), their commits by owner rank in the send regions, reorder_buffer (:529-540), km_back, rest */
+int kmx_range_resolve_dev(kmx_model *m, int t, const uint8_t *d_verdict, uint64_t *counts);
+/* ... owner: the received commits set tag and value bits                                                                */
+int kmx_range_commit_dev(kmx_model *m, int t, const uint64_t *d_commits, uint64_t n);
+
 /* device memory of filter / array storage for the caller's collectives: which 0 bf[i], 1 bf_back[i], 2 km_back
  * (bytes rounded up to 32-bit words), 3 the cells of coupled array i (value+tag interleaved, 8 bytes per 16 positions)  */
 int kmx_dev_view(kmx_model *m, int which, int index, void **ptr, uint64_t *bytes);

@@ -45,6 +45,7 @@ ABI_SYMBOLS = [
     "kmx_count_classes_dev", "kmx_shard_begin", "kmx_shard_classify_dev", "kmx_ring_msg_bytes", "kmx_ring_round_dev",
     "kmx_ring_stale_dup_dev", "kmx_shard_local", "kmx_shard_complete", "kmx_dev_view", "kmx_or_words_dev",
     "kmx_debug_pack_strings", "kmx_kernel_classes", "kmx_abi_version",
+    "kmx_range_begin", "kmx_range_buffers", "kmx_range_emit_dev", "kmx_range_verdict_dev", "kmx_range_resolve_dev", "kmx_range_commit_dev",
 ]
 
 
@@ -128,6 +129,12 @@ def load_library():
     L.kmx_shard_local.argtypes = [vp, C.POINTER(Stats), C.POINTER(vp), C.POINTER(vp)]
     L.kmx_shard_complete.argtypes = [vp, vp, vp, u64, C.POINTER(Stats)]
     L.kmx_dev_view.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(u64)]
+    L.kmx_range_begin.argtypes = [vp, i32, C.POINTER(u64), u64, i32, i32]
+    L.kmx_range_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
+    L.kmx_range_emit_dev.argtypes = [vp, i32, C.POINTER(RingList), i32, C.POINTER(u64)]
+    L.kmx_range_verdict_dev.argtypes = [vp, i32, vp, u64, vp]
+    L.kmx_range_resolve_dev.argtypes = [vp, i32, vp, C.POINTER(u64)]
+    L.kmx_range_commit_dev.argtypes = [vp, i32, vp, u64]
     L.kmx_or_words_dev.argtypes = [vp, vp, vp, u64]
     L.kmx_debug_pack_strings.argtypes = [vp, vp, i32, i32, u64, vp, C.POINTER(i32)]
     L.kmx_kernel_classes.argtypes = []
@@ -305,6 +312,37 @@ class KModel:
 
     def shard_complete(self, d_rest_kmers_ptr: int, d_rest_counts_ptr: int, n_rest: int, totals: Stats) -> None:
         _chk(self.L.kmx_shard_complete(self.h, d_rest_kmers_ptr or None, d_rest_counts_ptr or None, n_rest, C.byref(totals)))
+
+    # ---- position-range partition (include/kmx.h, kmx_range_*)
+    def range_begin(self, k: int, n_bf, n_total: int, rank: int, world: int) -> None:
+        arr = (C.c_uint64 * 3)(*[int(x) for x in list(n_bf) + [0, 0, 0]][:3])
+        _chk(self.L.kmx_range_begin(self.h, k, arr, n_total, rank, world))
+        self._range_world = world
+
+    def range_buffers(self):
+        p, cap = C.c_void_p(), C.c_uint64()
+        lo = (C.c_uint64 * (self._range_world + 1))()
+        _chk(self.L.kmx_range_buffers(self.h, C.byref(p), C.byref(cap), lo))
+        return p.value or 0, int(cap.value), [int(x) for x in lo]
+
+    def range_emit_dev(self, t: int, lists):
+        arr = (RingList * max(len(lists), 1))()
+        for j, (i, n, pk, pc) in enumerate(lists):
+            arr[j] = RingList(i, n, pk or None, pc or None, None, None)
+        counts = (C.c_uint64 * self._range_world)()
+        _chk(self.L.kmx_range_emit_dev(self.h, t, arr, len(lists), counts))
+        return [int(x) for x in counts]
+
+    def range_verdict_dev(self, t: int, d_triples_ptr: int, n: int, d_verdict_ptr: int) -> None:
+        _chk(self.L.kmx_range_verdict_dev(self.h, t, d_triples_ptr, n, d_verdict_ptr))
+
+    def range_resolve_dev(self, t: int, d_verdict_ptr: int):
+        counts = (C.c_uint64 * self._range_world)()
+        _chk(self.L.kmx_range_resolve_dev(self.h, t, d_verdict_ptr, counts))
+        return [int(x) for x in counts]
+
+    def range_commit_dev(self, t: int, d_commits_ptr: int, n: int) -> None:
+        _chk(self.L.kmx_range_commit_dev(self.h, t, d_commits_ptr, n))
 
     def dev_view(self, which: str, index: int = 0):
         """(device pointer, bytes) of a filter ("bf", "bf_back", "km_back") or of the cells of coupled array `index` ("cells")"""

@@ -42,6 +42,10 @@ void bs_apply(const BitScatter &, hipStream_t);
 void ring_import(const ModelDev &, const BlockDev &, int, const RingLists &, u64 *, u32 *, hipStream_t);
 void ring_export(const ModelDev &, const BlockDev &, int, const RingLists &, hipStream_t);
 void or_words(u32 *, const u32 *, u64, hipStream_t);
+void range_emit(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, hipStream_t);
+void range_verdict(const ModelDev &, const BlockDev &, int, const u64 *, u64, unsigned char *, hipStream_t);
+void range_resolve(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, const unsigned char *, hipStream_t);
+void range_commit_apply(const ModelDev &, int, const u64 *, u64, hipStream_t);
 void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *);
 void query_ascii(const ModelDev &, int, const unsigned char *, int, u64, int *, hipStream_t);
 void cells_from_disk(const unsigned char *, const unsigned char *, u64, cell_t *, u64, hipStream_t);
@@ -256,6 +260,17 @@ struct kmx_model {
 		hipStream_t to_dev = nullptr, to_host = nullptr;
 		hipEvent_t ev_in[S] = {nullptr, nullptr, nullptr}, ev_k[S] = {nullptr, nullptr, nullptr}, ev_out[S] = {nullptr, nullptr, nullptr};
 	} qfeed;
+	// position-range partition over several GPUs (kmx_range_*): this rank's exchange buffers, its resolver tables, and the
+	// owner-side view of the block working set (scratch status + overflow flags for the detect kernel on received claims)
+	struct RangeState {
+		bool on = false;
+		RangeDev rd = {};
+		RangePlan plan = {};
+		BlockDev obd = {};
+		unsigned char *d_ostatus = nullptr;
+		int *d_oovf = nullptr, *h_cnt = nullptr;                   // h_cnt: pinned copy of rd.send_cnt
+		u64 alloc_key = 0;                                         // nb, nh, world the buffers were sized for
+	} range;
 	bool ring = false;                                         // built by several GPUs (kmx_shard_begin): this handle holds ONE rank's share
 	int ring_rank = 0, ring_world = 1;
 	int nsub = 1;                                              // grid-wide ordered passes in round 0 (see process_block)
@@ -459,6 +474,16 @@ static void free_feed(kmx_model *m)
 	f.raw_cap = f.km_cap = f.dk_cap = f.lut_cap = 0;
 }
 
+static void free_range(kmx_model *m)
+{
+	auto &R = m->range;
+	hipFree(R.rd.send); hipFree(R.rd.send_cnt); hipFree(R.rd.tidx); hipFree(R.rd.contended); hipFree(R.rd.n_contended);
+	hipFree(R.rd.rt_key); hipFree(R.rd.rt_resv); hipFree(R.rd.rt_mark); hipFree(R.rd.rt_eidx); hipFree(R.rd.rt_um);
+	hipFree(R.d_ostatus); hipFree(R.d_oovf);
+	if (R.h_cnt) hipHostFree(R.h_cnt);
+	R = kmx_model::RangeState();
+}
+
 static void free_query_feed(kmx_model *m)
 {
 	auto &f = m->qfeed;
@@ -490,6 +515,7 @@ static int kmx_destroy_impl(kmx_model *m)
 	if (m->h_totals) hipHostFree(m->h_totals);
 	free_feed(m);
 	free_query_feed(m);
+	free_range(m);
 	for (hipEvent_t e : m->prof_events) hipEventDestroy(e);
 	delete m;
 	return KMX_OK;
@@ -1737,7 +1763,155 @@ static int kmx_shard_complete_impl(kmx_model *m, const uint64_t *d_rest_kmers, c
 	m->blocks = totals->blocks; m->rounds = totals->rounds;
 	fill_model_dev(m);
 	m->ring = false;
+	m->range.on = false;
 	m->state = ST_READY;
+	return KMX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ position-range partition (range_kernels.h)
+// Every coupled array cut by position range over the ranks (the north star's partition); the caller moves
+// the words between the ranks (three all-to-alls per round: kmcex_amd/dist.py build_sharded(partition="range")).
+static int kmx_range_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world)
+{
+	if (world > KMX_MAX_RANKS) return fail(KMX_E_ARG, "the range partition takes up to %d ranks", KMX_MAX_RANKS);
+	TRY(kmx_shard_begin_impl(m, k, n_bf, n_total, rank, world));   // whole-model sizes; a rank works on its cell range of every array
+	if (m->km_byte_size * 8 > (1ULL << 36)) { m->state = ST_EMPTY; return fail(KMX_E_ARG, "the range partition addresses up to 2^36 positions per array"); }
+	auto &R = m->range;
+	const int nb = m->nb, nh = m->nh;
+	const u64 key = ((u64)nb << 32) | ((u64)nh << 16) | (u64)world;
+	if (R.alloc_key != key) {
+		HIPCHK(hipStreamSynchronize(m->stream));
+		free_range(m);
+		const u64 held = (u64)((nb + world - 1) / world), slots = (u64)nb * KMX_BUCKET;
+		R.rd.cap = held * KMX_BUCKET * (u64)nh;
+		R.rd.rt_bits = nh <= 8 ? 22 : 23;
+		TRY(dalloc(&R.rd.send, (u64)world * R.rd.cap, false, m->stream));
+		TRY(dalloc(&R.rd.send_cnt, (u64)KMX_MAX_RANKS * KMX_CTR_STRIDE, true, m->stream));
+		TRY(dalloc(&R.rd.tidx, slots * nh, false, m->stream));
+		TRY(dalloc(&R.rd.contended, slots, false, m->stream));
+		TRY(dalloc(&R.rd.n_contended, (u64)KMX_MAX_NB * KMX_CTR_STRIDE, true, m->stream));
+		TRY(dalloc(&R.rd.rt_key, held << R.rd.rt_bits, false, m->stream));
+		TRY(dalloc(&R.rd.rt_resv, held << R.rd.rt_bits, false, m->stream));
+		TRY(dalloc(&R.rd.rt_mark, held << R.rd.rt_bits, false, m->stream));
+		TRY(dalloc(&R.rd.rt_eidx, slots * nh, false, m->stream));
+		TRY(dalloc(&R.rd.rt_um, slots, false, m->stream));
+		TRY(dalloc(&R.d_ostatus, slots, true, m->stream));
+		TRY(dalloc(&R.d_oovf, (u64)KMX_MAX_NB, true, m->stream));
+		HIPCHK(hipHostMalloc((void **)&R.h_cnt, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE));
+		R.alloc_key = key;
+	}
+	HIPCHK(hipMemsetAsync(R.d_ostatus, 0, (u64)nb * KMX_BUCKET, m->stream));
+	HIPCHK(hipMemsetAsync(R.d_oovf, 0, sizeof(int) * KMX_MAX_NB, m->stream));
+	R.plan.rank = rank; R.plan.world = world;
+	for (int q = 0; q <= world; q++) R.plan.cell_lo[q] = (u64)(((unsigned __int128)m->ncells * (unsigned)q) / (unsigned)world);
+	R.obd = m->bd;                                                  // (kmx_begin carved it; the claim bins are the owner's here)
+	R.obd.status[0] = R.obd.status[1] = R.d_ostatus;
+	R.obd.cl_ovf = R.d_oovf;
+	R.on = true;
+	return KMX_OK;
+}
+
+static int range_check(kmx_model *m, int t)
+{
+	if (!m) return fail(KMX_E_ARG, "null model");
+	if (m->state != ST_BUILDING || !m->ring || !m->range.on) return fail(KMX_E_STATE, "kmx_range_* before kmx_range_begin");
+	if (t < 0 || t >= m->nb) return fail(KMX_E_ARG, "bad round %d", t);
+	HIPCHK(hipSetDevice(m->device));
+	return KMX_OK;
+}
+// words per destination rank of what the last emit left in the send regions
+static int range_counts(kmx_model *m, uint64_t *counts)
+{
+	auto &R = m->range;
+	HIPCHK(hipMemcpyAsync(R.h_cnt, R.rd.send_cnt, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipStreamSynchronize(m->stream));
+	for (int q = 0; q < R.plan.world; q++) counts[q] = (uint64_t)R.h_cnt[q * KMX_CTR_STRIDE];
+	return KMX_OK;
+}
+
+// Round t, step 1, on the lists this rank holds (t == 0: `lists` are the fresh buffers of the block, i = rank, rank + world, ...;
+// later rounds work on what the last reorder left): triples by destination rank in the send regions, counts[world] on the host.
+static int kmx_range_emit_dev_impl(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists, uint64_t *counts)
+{
+	TRY(range_check(m, t));
+	if (!counts || (n_lists && !lists)) return fail(KMX_E_ARG, "null argument");
+	auto &R = m->range;
+	for (int q = 0; q < R.plan.world; q++) counts[q] = 0;
+	if (m->km_byte_size == 0) return KMX_OK;                       // divergence D2: no arrays to insert into
+	if (t == 0) {
+		RingLists rl;
+		memset(&rl, 0, sizeof rl);
+		for (int e = 0; e < n_lists; e++) {
+			const kmx_ring_list &l = lists[e];
+			if (l.list < 0 || l.list >= m->nb || rl.e[l.list].active || l.list % R.plan.world != R.plan.rank) return fail(KMX_E_ARG, "list %d is not this rank's", l.list);
+			if (l.n_host < 0 || l.n_host > (int)KMX_BUCKET || (l.n_host > 0 && (!l.src_kmers || !l.src_counts))) return fail(KMX_E_ARG, "list %d: bad source", l.list);
+			RingList &r = rl.e[l.list];
+			r.active = 1; r.n_host = l.n_host;
+			r.src_kmers = (const u64 *)l.src_kmers; r.src_counts = (const u32 *)l.src_counts;
+		}
+		kmxk::ring_import(m->md, m->bd, m->pp, rl, m->d_stg_kmers, m->d_stg_counts, m->stream);
+	}
+	kmxk::range_emit(m->md, m->bd, R.rd, R.plan, t, m->pp, m->stream);
+	HIPCHK(hipGetLastError());
+	return range_counts(m, counts);
+}
+
+static int kmx_range_buffers_impl(kmx_model *m, void **d_send, uint64_t *cap_words, uint64_t *cell_lo)
+{
+	if (!m || !m->range.on) return fail(KMX_E_STATE, "kmx_range_* before kmx_range_begin");
+	if (d_send) *d_send = m->range.rd.send;
+	if (cap_words) *cap_words = m->range.rd.cap;
+	if (cell_lo) for (int q = 0; q <= m->range.plan.world; q++) cell_lo[q] = m->range.plan.cell_lo[q];
+	return KMX_OK;
+}
+
+// step 2 on the owner: one verdict byte per received triple (same order)
+static int kmx_range_verdict_dev_impl(kmx_model *m, int t, const uint64_t *d_triples, uint64_t n, uint8_t *d_verdict)
+{
+	TRY(range_check(m, t));
+	if (n && (!d_triples || !d_verdict)) return fail(KMX_E_ARG, "null argument");
+	if (m->km_byte_size == 0) return KMX_OK;
+	kmxk::range_verdict(m->md, m->range.obd, t, (const u64 *)d_triples, n, d_verdict, m->stream);
+	HIPCHK(hipGetLastError());
+	return KMX_OK;
+}
+
+// step 3 on the list rank: verdicts (in the order the triples left) -> failures, winners, the contended in list order; the
+// winners' commits by destination rank in the send regions (counts[world] on the host); reorder, km_back, rest table
+static int kmx_range_resolve_dev_impl(kmx_model *m, int t, const uint8_t *d_verdict, uint64_t *counts)
+{
+	TRY(range_check(m, t));
+	if (!counts) return fail(KMX_E_ARG, "null argument");
+	auto &R = m->range;
+	for (int q = 0; q < R.plan.world; q++) counts[q] = 0;
+	if (m->km_byte_size == 0) return KMX_OK;
+	const int nb = m->nb, pp = m->pp;
+	kmxk::range_resolve(m->md, m->bd, R.rd, R.plan, t, pp, d_verdict, m->stream);
+	HIPCHK(hipGetLastError());
+	TRY(range_counts(m, counts));
+	const int held = (nb + R.plan.world - 1 - R.plan.rank) / R.plan.world;
+	if (held > 0) TRY(kmback_emit(m, t, pp, -1, (u64)held * KMX_BUCKET));
+	m->pp ^= 1;
+	m->rounds++;
+	if (t == nb - 1) {
+		for (int i = R.plan.rank; i < nb; i += R.plan.world) {
+			TRY(ensure_rest_capacity(m, (u64)KMX_BUCKET + (u64)nb));
+			kmxk::rest_append(m->md, m->bd, m->pp, i, 1, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream);
+		}
+		m->blocks++;
+	}
+	HIPCHK(hipGetLastError());
+	return KMX_OK;
+}
+
+// ... and on the owner: the winners' tag / value bits (kmodel.hpp:611-618)
+static int kmx_range_commit_dev_impl(kmx_model *m, int t, const uint64_t *d_commits, uint64_t n)
+{
+	TRY(range_check(m, t));
+	if (n && !d_commits) return fail(KMX_E_ARG, "null argument");
+	if (m->km_byte_size == 0) return KMX_OK;
+	kmxk::range_commit_apply(m->md, t, (const u64 *)d_commits, n, m->stream);
+	HIPCHK(hipGetLastError());
 	return KMX_OK;
 }
 
@@ -2455,6 +2629,12 @@ extern "C" int kmx_ring_round_dev(kmx_model *m, int t, const kmx_ring_list *list
 extern "C" int kmx_ring_stale_dup_dev(kmx_model *m, int first_unused_row) { return guarded([&] { return kmx_ring_stale_dup_dev_impl(m, first_unused_row); }); }
 extern "C" int kmx_shard_local(kmx_model *m, kmx_stats *partial, void **d_rest_kmers, void **d_rest_counts) { return guarded([&] { return kmx_shard_local_impl(m, partial, d_rest_kmers, d_rest_counts); }); }
 extern "C" int kmx_shard_complete(kmx_model *m, const uint64_t *d_rest_kmers, const int32_t *d_rest_counts, uint64_t n_rest, const kmx_stats *totals) { return guarded([&] { return kmx_shard_complete_impl(m, d_rest_kmers, d_rest_counts, n_rest, totals); }); }
+extern "C" int kmx_range_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world) { return guarded([&] { return kmx_range_begin_impl(m, k, n_bf, n_total, rank, world); }); }
+extern "C" int kmx_range_buffers(kmx_model *m, void **d_send, uint64_t *cap_words, uint64_t *cell_lo) { return guarded([&] { return kmx_range_buffers_impl(m, d_send, cap_words, cell_lo); }); }
+extern "C" int kmx_range_emit_dev(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists, uint64_t *counts) { return guarded([&] { return kmx_range_emit_dev_impl(m, t, lists, n_lists, counts); }); }
+extern "C" int kmx_range_verdict_dev(kmx_model *m, int t, const uint64_t *d_triples, uint64_t n, uint8_t *d_verdict) { return guarded([&] { return kmx_range_verdict_dev_impl(m, t, d_triples, n, d_verdict); }); }
+extern "C" int kmx_range_resolve_dev(kmx_model *m, int t, const uint8_t *d_verdict, uint64_t *counts) { return guarded([&] { return kmx_range_resolve_dev_impl(m, t, d_verdict, counts); }); }
+extern "C" int kmx_range_commit_dev(kmx_model *m, int t, const uint64_t *d_commits, uint64_t n) { return guarded([&] { return kmx_range_commit_dev_impl(m, t, d_commits, n); }); }
 extern "C" int kmx_dev_view(kmx_model *m, int which, int index, void **ptr, uint64_t *bytes) { return guarded([&] { return kmx_dev_view_impl(m, which, index, ptr, bytes); }); }
 extern "C" int kmx_or_words_dev(kmx_model *m, void *d_dst, const void *d_src, uint64_t n_words) { return guarded([&] { return kmx_or_words_dev_impl(m, d_dst, d_src, n_words); }); }
 extern "C" int kmx_kmc_info(const char *db_prefix, int *k, uint64_t *total_kmers) { return guarded([&] { return kmx_kmc_info_impl(db_prefix, k, total_kmers); }); }

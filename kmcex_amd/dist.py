@@ -93,15 +93,16 @@ def _segments(off: int, c: int, nb: int):
     return np.stack([lo, hi, seg % nb], axis=1)
 
 
-def plan_routing(counts_per_rank, nb: int, world: int, rank: int):
-    """All-to-all plan that brings every buffer of the coupled-array stream to the rank owning the array it meets first.
+def plan_routing(counts_per_rank, nb: int, world: int, rank: int, own=None):
+    """All-to-all plan that brings every buffer of the coupled-array stream to the rank owning the array it meets first
+    (`own[i]`: the rank buffer i of every block goes to; default: the ring's owner of array i).
 
     `counts_per_rank[q]` = coupled-array k-mers rank q holds (its listing slice, in listing order; slices are in rank
     order).  Returns (send_slices, send_splits, recv_splits): local [lo, hi) slices in send order (grouped by
     destination, ascending stream position inside a destination) and the per-rank split sizes.  Received pieces, taken
     in source-rank order, are this rank's buffers in ascending stream position."""
     offs = np.concatenate([[0], np.cumsum(np.asarray(counts_per_rank, dtype=np.int64))])
-    own = np.array([owner_of_array(a, nb, world) for a in range(nb)], dtype=np.int64)
+    own = np.array([owner_of_array(a, nb, world) for a in range(nb)] if own is None else own, dtype=np.int64)
     recv_splits = []
     for q in range(world):
         seg = _segments(int(offs[q]), int(counts_per_rank[q]), nb)
@@ -146,6 +147,7 @@ class Comm:
         self.world = dist.get_world_size(group) if self.on else 1
         self.staged = self.on and dist.get_backend(group) != "nccl"
         self.bytes_sent = 0                                 # payload this rank handed to the backend (reporting)
+        self.collectives = 0                                # data all-to-alls this rank took part in
 
     def _wire(self, t: torch.Tensor) -> torch.Tensor:
         return t.cpu() if (self.staged and t.is_cuda) else t
@@ -165,6 +167,15 @@ class Comm:
         dist.all_gather_into_tensor(out, t, group=self.group)
         return [int(v) for v in out.tolist()]
 
+    def all_to_all_ints(self, values, device):
+        """values[q] goes to rank q; returns what every rank sent here (the split sizes of a ragged all-to-all)"""
+        if self.world == 1 and self.shortcut:
+            return [int(v) for v in values]
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64, device="cpu" if self.staged else device)
+        out = torch.empty_like(t)
+        dist.all_to_all_single(out, t, group=self.group)
+        return [int(v) for v in out.tolist()]
+
     def all_to_all_v(self, send: torch.Tensor, send_splits, recv_splits) -> torch.Tensor:
         """rows of `send` grouped by destination -> rows received, grouped by source"""
         if self.world == 1 and self.shortcut:
@@ -173,6 +184,7 @@ class Comm:
         w = self._wire(send.contiguous())
         out = torch.empty((n_recv,) + tuple(send.shape[1:]), dtype=send.dtype, device=w.device)
         dist.all_to_all_single(out, w, [int(x) for x in recv_splits], [int(x) for x in send_splits], group=self.group)
+        self.collectives += 1
         self.bytes_sent += (int(sum(send_splits)) - int(send_splits[self.rank])) * send.element_size() * int(np.prod(send.shape[1:], dtype=np.int64))
         return out.to(send.device) if out.device != send.device else out
 
@@ -313,6 +325,36 @@ class DeviceEngine:
     def stale_dup(self, first_unused_row):
         self.m.ring_stale_dup_dev(first_unused_row)
 
+    # ---- position-range partition (include/kmx.h kmx_range_*): words by destination rank in device "send regions"
+    def range_begin(self, k, n_bf, n_total, rank, world):
+        self.k, self.W = k, (k + 31) // 32
+        self.m.range_begin(k, n_bf, n_total, rank, world)
+        p, self._cap, self.cell_lo = self.m.range_buffers()
+        self._send = dev_tensor(p, self._cap * world, torch.int64, self.device)
+
+    def _regions(self, counts):
+        """what the last emit / resolve left for every rank, concatenated in rank order (the order the verdicts come back in)"""
+        parts = [self._send[q * self._cap: q * self._cap + c] for q, c in enumerate(counts) if c]
+        return torch.cat(parts) if parts else self._send[:0]
+
+    def range_emit(self, t, lists):
+        counts = self.m.range_emit_dev(t, [(l["list"], l["n"], l["kmers"].data_ptr() if l["n"] else 0, l["counts"].data_ptr() if l["n"] else 0) for l in lists])
+        return self._regions(counts), counts
+
+    def range_verdict(self, t, triples):
+        ver = torch.empty(triples.numel(), dtype=torch.uint8, device=self.device)
+        if triples.numel():
+            self.m.range_verdict_dev(t, triples.data_ptr(), triples.numel(), ver.data_ptr())
+        return ver
+
+    def range_resolve(self, t, verdicts):
+        counts = self.m.range_resolve_dev(t, verdicts.data_ptr() if verdicts.numel() else 0)
+        return self._regions(counts), counts
+
+    def range_commit(self, t, commits):
+        if commits.numel():
+            self.m.range_commit_dev(t, commits.data_ptr(), commits.numel())
+
     def local(self):
         st, pk, pc = self.m.shard_local()
         n = int(st.rest_entries)
@@ -338,11 +380,17 @@ class DeviceEngine:
 STAT_FIELDS = ("attempts", "successes", "fast_commits", "contended", "finisher_iters")
 
 
-def build_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: torch.Tensor, counts: torch.Tensor, n_total: int | None = None):
+def build_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: torch.Tensor, counts: torch.Tensor, n_total: int | None = None, partition: str = "ring"):
     """KModel::init (kmodel.hpp:57-86) of ONE model by `comm.world` ranks.  `kmers` / `counts`: this rank's contiguous slice
     of the listing (slices in rank order = listing order).  On return every rank holds the whole model.
+    `partition`: "ring" -- arrays owned whole, lists travel (module docstring); "range" -- every array cut by position
+    range, k-mers stay, triples / verdicts / commits travel by all-to-all (`build_range_sharded`).
 
     Returns a dict of figures (n_km, blocks, bytes this rank sent)."""
+    if partition == "range":
+        return build_range_sharded(eng, comm, k, nb, bf_num, kmers, counts, n_total)
+    if partition != "ring":
+        raise ValueError(f"partition {partition!r}: ring or range")
     rank, world, dev = comm.rank, comm.world, counts.device
     sent0 = comm.bytes_sent
     # pass 1 (get_km_kmer_count, kmodel.hpp:423-434): class histogram of the slice, summed over the ranks
@@ -424,6 +472,78 @@ def build_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: torch.Te
                 comm.broadcast(v, own[a])
     eng.complete(rest_km_all, rest_cnt_all, st)
     return {"n_km": n_km, "blocks": n_blocks, "bytes_sent": comm.bytes_sent - sent0, "arrays_owned": [a for a in range(nb) if own[a] == rank]}
+
+
+def build_range_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: torch.Tensor, counts: torch.Tensor, n_total: int | None = None):
+    """The north star's partition: "shard the bit arrays by hash-range across up to 8 GPUs with an RCCL all-to-all".  Rank q
+    owns the cells [cell_lo[q], cell_lo[q+1]) of EVERY array; list i of a block lives on rank i % world, which hashes its
+    k-mers, keeps the list order and reorders locally -- k-mers are routed once (the same all-to-all as the ring's, to the
+    list's rank) and never move again.  A round (list i against array (i + t) % nb, kmodel.hpp:560-565) is three all-to-alls
+    of 64-bit words / bytes: triples to the range owners, one verdict byte per triple back, the winners' commits
+    (`range_kernels.h` has the kernels and why the outcome is the sequential one).  Every rank works in every round, whatever
+    nb is; what the partition pays is three collectives inside every round of the ordered chain."""
+    rank, world, dev = comm.rank, comm.world, counts.device
+    sent0, coll0 = comm.bytes_sent, comm.collectives
+    local_hist = eng.count_classes(counts)
+    tot = comm.all_reduce_ints(local_hist + [counts.numel()], dev)
+    n_bf, n_all = tot[:3], tot[3]
+    eng.range_begin(k, n_bf, n_all if n_total is None else n_total, rank, world)
+    km_loc, cnt_loc = eng.classify(kmers, counts)
+    per_rank = comm.all_gather_ints(cnt_loc.shape[0], dev)
+    n_km = int(sum(per_rank))
+    own = [i % world for i in range(nb)]                        # buffer i of every block -> the rank that holds list i
+    send_slices, send_splits, recv_splits = plan_routing(per_rank, nb, world, rank, own)
+    if world > 1:
+        pick = lambda t: torch.cat([t[lo:hi] for lo, hi in send_slices]) if send_slices else t[:0]      # noqa: E731
+        km_mine = comm.all_to_all_v(pick(km_loc), send_splits, recv_splits)
+        cnt_mine = comm.all_to_all_v(pick(cnt_loc), send_splits, recv_splits)
+    else:
+        km_mine, cnt_mine = km_loc, cnt_loc
+    del km_loc, cnt_loc
+    blk = nb * BUCKET
+    n_blocks = -(-n_km // blk)
+    pos = 0
+    for b in range(n_blocks):
+        n_in_block = min(blk, n_km - b * blk)
+        if n_in_block < blk and b > 0:                          # final partial block: quirk Q1 (kmodel.hpp:520-527), on the rank that holds the list
+            row = (n_in_block - 1) // BUCKET
+            if row + 1 < nb:
+                eng.stale_dup(row + 1)
+        for t in range(nb):
+            lists = []
+            if t == 0:
+                for i in range(rank, nb, world):
+                    n_i = list_length(n_km, nb, b, i)
+                    lists.append({"list": i, "n": n_i, "kmers": km_mine[pos:pos + n_i], "counts": cnt_mine[pos:pos + n_i]})
+                    pos += n_i
+            triples, out_counts = eng.range_emit(t, lists)                              # 1. triples -> range owners
+            in_counts = comm.all_to_all_ints(out_counts, dev)
+            got = comm.all_to_all_v(triples, out_counts, in_counts)
+            ver = eng.range_verdict(t, got)                                             # 2. verdicts back, same order
+            back = comm.all_to_all_v(ver, in_counts, out_counts)
+            commits, c_out = eng.range_resolve(t, back)                                 # 3. the winners' commits -> range owners
+            c_in = comm.all_to_all_ints(c_out, dev)
+            eng.range_commit(t, comm.all_to_all_v(commits, c_out, c_in))
+    st, rest_km, rest_cnt = eng.local()
+    rest_counts = comm.all_gather_ints(int(st.rest_entries), dev)
+    rest_km_all = comm.all_gather_v(rest_km, rest_counts)
+    rest_cnt_all = comm.all_gather_v(rest_cnt, rest_counts)
+    sums = comm.all_reduce_ints([getattr(st, f) for f in STAT_FIELDS], dev)
+    for f, v in zip(STAT_FIELDS, sums):
+        setattr(st, f, v)
+    st.blocks, st.rounds = n_blocks, n_blocks * nb
+    if world > 1:
+        for i in range(bf_num):
+            comm.or_allreduce(eng.view("bf", i), eng.or_into)
+            comm.or_allreduce(eng.view("bf_back", i), eng.or_into)
+        comm.or_allreduce(eng.view("km_back"), eng.or_into)
+        lo = eng.cell_lo
+        for a in range(nb):                                      # every rank's cell range of every array -> every rank
+            for v in eng.array_views(a):
+                v.copy_(comm.all_gather_v(v[lo[rank]:lo[rank + 1]], [lo[q + 1] - lo[q] for q in range(world)]))
+    eng.complete(rest_km_all, rest_cnt_all, st)
+    return {"n_km": n_km, "blocks": n_blocks, "bytes_sent": comm.bytes_sent - sent0, "collectives": comm.collectives - coll0,
+            "cells_owned": [int(eng.cell_lo[rank]), int(eng.cell_lo[rank + 1])], "partition": "range"}
 
 
 def query_replicas(model, comm: Comm, queries: torch.Tensor, k: int) -> torch.Tensor:

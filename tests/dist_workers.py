@@ -64,7 +64,7 @@ def _to_torch(km, cnt, k, device):
     return tk.to(device), tc.to(device)
 
 
-def gpu_worker(rank, world, port, spec, out_dir, q, load_dir=None):
+def gpu_worker(rank, world, port, spec, out_dir, q, load_dir=None, partition="ring"):
     """One rank of a single-model build (or, with load_dir, of a replica query) sharing cuda:0 with the others."""
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
@@ -92,7 +92,7 @@ def gpu_worker(rank, world, port, spec, out_dir, q, load_dir=None):
             tk, tc = _to_torch(km[lo:hi], cnt[lo:hi], k, dev)
             m = KModel(ci, cs, nh, nb)
             eng = kd.DeviceEngine(m, dev)
-            info = kd.build_sharded(eng, comm, k, nb, 1 if ci == 1 else 3, tk, tc)
+            info = kd.build_sharded(eng, comm, k, nb, 1 if ci == 1 else 3, tk, tc, partition=partition)
             st = m.stats()
             res.update(info=info, stats=(st.n_km, list(st.n_bf), st.attempts, st.successes, st.rest_entries, st.blocks, st.rounds))
             qk = queries_of(spec, base, k)
@@ -179,6 +179,24 @@ def rccl_worker(rank, world, port, spec, out_dir, q):
         w = cn[:999].clone()                                        # odd length: exercises the padding of the range split
         comm.or_allreduce(w, eng.or_into)
         assert torch.equal(w, cn[:999])
+        m.close()
+        # the range partition's exchanges: split sizes, 64-bit words, verdict bytes -- and one whole build through them
+        assert comm.all_to_all_ints([5], dev) == [5]
+        by = (cn[:300] & 7).to(torch.uint8)
+        assert torch.equal(comm.all_to_all_v(by, [300], [300]), by)
+        from common import CASE, sha_file
+        from kmcex_amd import synth
+        import json, tempfile
+        _, k, ci, cs, nh, nb, n = CASE["k31_multiblock_ci1"]
+        skm, scnt = synth.make_stream(n, k, ci, cs)
+        tk, tc = _to_torch(skm, scnt, k, dev)
+        m = KModel(ci, cs, nh, nb)
+        info = kd.build_sharded(kd.DeviceEngine(m, dev), comm, k, nb, 1, tk, tc, partition="range")
+        assert info["collectives"] >= 3 * info["blocks"] * nb
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["cases"]["k31_multiblock_ci1"]
+        with tempfile.TemporaryDirectory(prefix="kmx_rccl_") as d:
+            m.save(d)
+            assert {f: sha_file(os.path.join(d, f)) for f in ("header", "km.bin", "rest.bin")} == {f: g["sha256"][f] for f in ("header", "km.bin", "rest.bin")}
         m.close()
         dist.barrier()
         dist.destroy_process_group()

@@ -44,6 +44,32 @@ def test_single_model_over_ranks_is_bit_exact(spec, world, golden, tmp_path):
     assert owned == list(range(len(owned)))                        # every array has exactly one owner
 
 
+# The north star's partition: every array cut by position range, triples / verdicts / commits by all-to-all.
+@pytest.mark.parametrize("spec,world", [
+    (("synth", "tiny_k31"), 1),                    # one rank: the kernels of the partition alone, every word "sent" to itself
+    (("synth", "tiny_k31"), 2),
+    (("synth", "k31_multiblock_ci1"), 2),          # 3 lists on rank 0, 2 on rank 1; quirk Q1 on the ranks that hold the unused rows
+    (("synth", "k31_multiblock_ci1"), 3),
+    (("synth", "k31_multiblock_ci1"), 5),
+    (("synth", "k55_multiblock"), 2),              # two-word k-mers, nh 9 (16-wide templates), nb 6
+    (("synth", "k55_multiblock"), 5),
+    (("kmc2", "k31_kmc2_6bins"), 3),               # bin-major (unsorted) listing order
+    (("synth", "k31_multiblock_ci2"), 2),          # three Bloom classes
+    (("synth", "k31_nh3_nb1"), 3),                 # one list, three range owners
+], ids=lambda v: v[1] if isinstance(v, tuple) else f"w{v}")
+def test_range_partition_over_ranks_is_bit_exact(spec, world, golden, tmp_path):
+    g = _golden_of(golden, spec)
+    res = run_ranks(gpu_worker, world, spec, str(tmp_path), None, "range")
+    for r in res:
+        assert r["sha"] == {f: g["sha256"][f] for f in ("header", "km.bin", "rest.bin")}, f"rank {r['rank']} holds a different model"
+        assert r["occ_sha"] == g["occ_sha256"]
+        if "stats" in g:
+            assert r["stats"][2:5] == (g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
+        assert r["info"]["partition"] == "range" and r["info"]["collectives"] >= (3 * r["info"]["blocks"] * (len(res) > 1))
+    cells = sorted(tuple(r["info"]["cells_owned"]) for r in res)
+    assert cells[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cells, cells[1:]))       # the ranges tile every array
+
+
 def test_replica_query_of_reference_files():
     """2 ranks load the model the REFERENCE wrote (tests/golden/tiny) and answer the batch by slices."""
     d = os.path.join(ROOT, "tests", "golden", "tiny")
