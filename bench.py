@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-query-strings", action="store_true", help="skip the kmer_to_occ(vector<string>) leg")
     ap.add_argument("--no-single-model", action="store_true", help="skip the one-model-over-all-ranks leg")
     ap.add_argument("--single-model-steps", type=int, default=0, help="0: --steps when N > 1 (it is the headline there), 2 at N = 1")
+    ap.add_argument("--partition", choices=("ring", "range"), default="ring",
+                    help="how ONE model is spread over the ranks: ring = arrays owned whole, lists travel (send/recv); range = every array cut by "
+                         "position range, triples / verdicts / commits by all-to-all (the north star's partition, SURVEY.md 8e(1))")
     return ap.parse_args()
 
 
@@ -235,8 +238,11 @@ def promote_single_model(line, single, world):
     line["replica_query_ms_per_step"], line["query_ms_per_step"] = line["query_ms_per_step"], single["query_ms_per_step"]
     line["steps"] = single["steps"]
     line["value_is"] = "k-mers/s encoded into ONE model by all ranks together (single_model); replica_value = N independent models"
-    line["config"]["parallelism"] = (f"one model over {world} ranks: routing all-to-all + ring of whole arrays (min({world}, nb) array owners) + "
+    how = (f"ring of whole arrays (min({world}, nb) array owners)" if single.get("partition", "ring") == "ring" else
+           f"every array cut by position range over the {world} ranks, three all-to-alls per round (triples, verdicts, commits)")
+    line["config"]["parallelism"] = (f"one model over {world} ranks [--partition {single.get('partition', 'ring')}]: routing all-to-all + {how} + "
                                      f"OR-merged filters + replica queries; replica_value = {world} independent models")
+    line["scaling"] = "weak (one model: the ordered chain runs once per round whatever N is -- sub-linear by construction; replica_value scales with N)"
     return line
 
 
@@ -248,11 +254,11 @@ def single_model_leg(a, m, km, cnt, q, out, rank, world, dev, rehearsal, distrib
     eng = kd.DeviceEngine(m, dev)
     bf_num = 1 if a.ci == 1 else 3
     for _ in range(max(1, a.warmup if world > 1 else 1)):
-        info = kd.build_sharded(eng, comm, a.k, a.nb, bf_num, km, cnt)                  # warm-up (allocations)
+        info = kd.build_sharded(eng, comm, a.k, a.nb, bf_num, km, cnt, partition=a.partition)      # warm-up (allocations)
     sync_all(distributed)
     t0 = time.perf_counter()
     for _ in range(a.single_model_steps):
-        info = kd.build_sharded(eng, comm, a.k, a.nb, bf_num, km, cnt)
+        info = kd.build_sharded(eng, comm, a.k, a.nb, bf_num, km, cnt, partition=a.partition)
     sync_all(distributed)
     t_b = time.perf_counter() - t0
     st = m.stats()
@@ -262,8 +268,17 @@ def single_model_leg(a, m, km, cnt, q, out, rank, world, dev, rehearsal, distrib
         m.kmer_to_occ_dev(q.data_ptr(), q.numel(), out.data_ptr())
     sync_all(distributed)
     t_qq = time.perf_counter() - t0
-    (t_b, t_qq), (n_all, nq_all, sent) = kd.reduce_job([t_b, t_qq], [km.numel(), q.numel(), info["bytes_sent"]], device="cpu" if rehearsal else dev)
-    return {"what": "ONE model over all ranks' streams: routing all-to-all + ring of arrays (send/recv) + OR-merged filters + array broadcast; queries over replicas",
+    owns = 1 if (a.partition == "range" or info.get("arrays_owned")) else 0
+    (t_b, t_qq), (n_all, nq_all, sent, working) = kd.reduce_job([t_b, t_qq], [km.numel(), q.numel(), info["bytes_sent"], owns], device="cpu" if rehearsal else dev)
+    layout = ({"partition": "range", "cells_owned_rank0": info.get("cells_owned"), "all_to_alls_per_build": info.get("collectives"),
+               "ranks_holding_lists": min(world, a.nb)} if a.partition == "range" else
+              {"partition": "ring", "arrays_owned_rank0": info.get("arrays_owned"), "array_owners": min(world, a.nb),
+               "ring_hops_per_build": info["blocks"] * a.nb * sum(1 for x in range(a.nb) if kd.owner_of_array(x, a.nb, world) != kd.owner_of_array((x + 1) % a.nb, a.nb, world))})
+    return {"what": ("ONE model over all ranks' streams: routing all-to-all + ring of arrays (send/recv) + OR-merged filters + array broadcast; queries over replicas"
+                     if a.partition == "ring" else
+                     "ONE model over all ranks' streams: routing all-to-all + arrays cut by position range (triples / verdicts / commits by all-to-all) + "
+                     "OR-merged filters + all-gather of the ranges; queries over replicas"),
+            **layout, "ranks_doing_ordered_work": working, "idle_ranks_in_the_ordered_rounds": world - working,
             "transport": "gloo, ranks sharing one GPU (rehearsal: rates are not xGMI rates)" if rehearsal else ("nccl (RCCL)" if world > 1 else "none (one rank)"),
             "value": n_all * a.single_model_steps / t_b, "unit": "k-mers/s", "ms_per_build": t_b / a.single_model_steps * 1e3, "kmers": n_all,
             "query_value": nq_all * a.single_model_steps / t_qq, "query_ms_per_step": t_qq / a.single_model_steps * 1e3, "steps": a.single_model_steps, "scaling": "weak",
