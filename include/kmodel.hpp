@@ -75,7 +75,31 @@ public:
 	KModel &operator=(const KModel &) = delete;
 
 	// kmodel.hpp:57 -- two passes over the KMC listing, rest-table build
-	void init(std::string db_file) { check(kmx_build_from_kmc(h_, db_file.c_str())); }
+	// kmodel.hpp:57-86.  KMX_DEVICES=0,1,2,... (HIP device numbers, repeats allowed): the model is built by those GPUs
+	// together -- one host thread per device inside libkmx.so, the ring of whole arrays with peer copies
+	// (kmx_build_from_kmc_multi) -- and this object keeps the replica of the first one.  Unset: the current device alone.
+	void init(std::string db_file)
+	{
+		std::vector<int> devs;
+		if (const char *e = std::getenv("KMX_DEVICES")) {
+			for (const char *p = e; *p;) {
+				char *end = nullptr;
+				const long v = std::strtol(p, &end, 10);
+				if (end == p) break;
+				devs.push_back((int)v);
+				p = *end == ',' ? end + 1 : end;
+			}
+		}
+		if (devs.size() < 2) { check(kmx_build_from_kmc(h_, db_file.c_str())); return; }
+		kmx_stats st;
+		check(kmx_get_stats(h_, &st));
+		std::vector<kmx_model *> hs(devs.size(), nullptr);
+		for (size_t d = 0; d < devs.size(); d++) check(kmx_create_on(devs[d], st.ci, st.cs, st.nh, st.nb, &hs[d]));
+		check(kmx_build_from_kmc_multi(hs.data(), (int)hs.size(), db_file.c_str()));
+		kmx_destroy(h_);
+		h_ = hs[0];
+		for (size_t d = 1; d < hs.size(); d++) kmx_destroy(hs[d]);
+	}
 	void init_KModel(std::string db_file) { init(db_file); }                 // README.md:76
 
 	// kmodel.hpp:90 -- t_num is accepted for source compatibility; the batch runs on the GPU

@@ -72,6 +72,12 @@ int kmx_destroy(kmx_model *m);
 /* stream (hipStream_t) used by every later call on this model; NULL = the default stream       */
 int kmx_set_stream(kmx_model *m, void *hip_stream);
 
+/* a handle on a given HIP device (kmx_create uses the calling thread's current device)                                  */
+int kmx_create_on(int device, int ci, int cs, int nh, int nb, kmx_model **out);
+/* KModel::init(db_file) by several GPUs from ONE process (kmodel.hpp:57-86; main.cpp:143-149 is the caller): models[d] was
+ * created on the device it is to use (devices may repeat), all with the same parameters.  One host thread per handle
+ * drives the ring of whole arrays (below) with hipMemcpyPeerAsync hand-offs; on return EVERY handle holds the whole model. */
+int kmx_build_from_kmc_multi(kmx_model **models, int n_models, const char *db_prefix);
 /* KModel::init(db_file): two passes over the KMC listing + rest build      kmodel.hpp:57-86   */
 int kmx_build_from_kmc(kmx_model *m, const char *db_prefix);
 

@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "kmx_count_classes_dev", "kmx_shard_begin", "kmx_shard_classify_dev", "kmx_ring_msg_bytes", "kmx_ring_round_dev",
     "kmx_ring_stale_dup_dev", "kmx_shard_local", "kmx_shard_complete", "kmx_dev_view", "kmx_or_words_dev",
     "kmx_debug_pack_strings", "kmx_kernel_classes", "kmx_abi_version",
-    "kmx_range_begin", "kmx_range_buffers", "kmx_range_emit_dev", "kmx_range_verdict_dev", "kmx_range_resolve_dev", "kmx_range_commit_dev",
+    "kmx_create_on", "kmx_build_from_kmc_multi", "kmx_range_begin", "kmx_range_buffers", "kmx_range_emit_dev", "kmx_range_verdict_dev", "kmx_range_resolve_dev", "kmx_range_commit_dev",
 ]
 
 
@@ -129,6 +129,8 @@ def load_library():
     L.kmx_shard_local.argtypes = [vp, C.POINTER(Stats), C.POINTER(vp), C.POINTER(vp)]
     L.kmx_shard_complete.argtypes = [vp, vp, vp, u64, C.POINTER(Stats)]
     L.kmx_dev_view.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(u64)]
+    L.kmx_create_on.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.kmx_build_from_kmc_multi.argtypes = [C.POINTER(vp), i32, C.c_char_p]
     L.kmx_range_begin.argtypes = [vp, i32, C.POINTER(u64), u64, i32, i32]
     L.kmx_range_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.kmx_range_emit_dev.argtypes = [vp, i32, C.POINTER(RingList), i32, C.POINTER(u64)]
@@ -451,6 +453,14 @@ class KModel:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+def init_multi(models, db_file: str) -> None:
+    """KModel::init(db_file) (kmodel.hpp:57-86) by several handles together, from inside libkmx.so (kmx_build_from_kmc_multi:
+    one host thread per handle, ring of whole arrays, hipMemcpyPeerAsync hand-offs): every handle ends with the whole model."""
+    L = load_library()
+    arr = (C.c_void_p * len(models))(*[m.h for m in models])
+    _chk(L.kmx_build_from_kmc_multi(arr, len(models), db_file.encode()))
 
 
 def get_model(ci_or_dir=1, cs: int = 1023, num_hash: int = 7, num_bit: int = 5) -> KModel:

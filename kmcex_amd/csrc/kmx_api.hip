@@ -1768,6 +1768,270 @@ static int kmx_shard_complete_impl(kmx_model *m, const uint64_t *d_rest_kmers, c
 	return KMX_OK;
 }
 
+// ------------------------------------------------------------------------------------------ KModel::init(db) on several GPUs, from C++
+// The ring of whole arrays (above) driven from ONE process: a host thread per device, the hand-offs of the ring as
+// hipMemcpyPeerAsync between the devices' own streams (events order them), the merges as peer copies -- no Python, no
+// torch.distributed.  A caller of the reference's API (main.cpp:143-149 -> KModel::init) reaches it through
+// include/kmodel.hpp with KMX_DEVICES=0,1,...  `hs[d]` was created on the device it is to use (kmx_create_on); on return
+// EVERY handle holds the whole model (replicas, as after dist.build_sharded).  Devices may repeat (several handles on one
+// GPU: how the one-GPU pool tests the protocol).
+namespace {
+struct HostBarrier {
+	std::mutex mu; std::condition_variable cv; int n, waiting = 0; unsigned long gen = 0;
+	explicit HostBarrier(int n_) : n(n_) {}
+	void wait() { std::unique_lock<std::mutex> lk(mu); const unsigned long g = gen; if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); } else cv.wait(lk, [&] { return gen != g; }); }
+};
+}   // namespace
+
+static int kmx_dev_view_impl(kmx_model *m, int which, int index, void **ptr, uint64_t *bytes);
+static int owner_of_array_ring(int a, int nb, int world) { return a * std::min(world, nb) / nb; }   // kmcex_amd/dist.py owner_of_array
+
+static int kmx_build_from_kmc_multi_impl(kmx_model **hs, int P, const char *db_prefix)
+{
+	if (!hs || !db_prefix || P < 1) return fail(KMX_E_ARG, "null argument");
+	for (int d = 0; d < P; d++) {
+		if (!hs[d]) return fail(KMX_E_ARG, "null model");
+		if (hs[d]->ci != hs[0]->ci || hs[d]->cs != hs[0]->cs || hs[d]->nh != hs[0]->nh || hs[d]->nb != hs[0]->nb) return fail(KMX_E_ARG, "the handles of one model must share ci, cs, nh, nb");
+		for (int e = 0; e < d; e++) if (hs[e] == hs[d]) return fail(KMX_E_ARG, "a handle appears twice");
+	}
+	if (P == 1) return kmx_build_from_kmc_impl(hs[0], db_prefix);
+	kmx::KmcListing db;
+	if (!db.open(db_prefix)) return fail(KMX_E_IO, "can't open the kmer_data_base %s: %s", db_prefix, db.error().c_str());
+	const int k = (int)db.kmer_length(), W = db.words(), nb = hs[0]->nb;
+	const u64 N = db.records();
+	const size_t rb = db.record_bytes();
+	{   // a database with unlisted records (KMC never writes one) needs the host decoder: one device builds it
+		uint64_t nbf[3], bad = 0, not_listed = 0;
+		db.count_classes((u32)hs[0]->ci, (u32)hs[0]->cs, hs[0]->bf_num, nbf, &bad, &not_listed, 16);
+		if (bad) return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)bad, hs[0]->ci, hs[0]->cs);
+		if (not_listed) return fail(KMX_E_ARG, "the database holds records outside its header's count range: build it on one device");
+	}
+	struct Rank {
+		u64 *d_km = nullptr, *d_ck = nullptr, *d_rk = nullptr, *d_allk = nullptr, *d_lut = nullptr;
+		u32 *d_cnt = nullptr, *d_cc = nullptr, *d_rc = nullptr;
+		int *d_allc = nullptr;
+		unsigned char *d_raw = nullptr, *h_raw = nullptr;
+		u32 *d_tmp = nullptr;
+		u64 n = 0, n_c = 0, n_r = 0, rec_lo = 0;
+		uint64_t nbf[3] = {0, 0, 0};
+		std::vector<u64 *> msg;                                    // [nb * 2] list i, parity
+		hipEvent_t ev_round = nullptr, ev_copied = nullptr;
+		kmx_stats st;
+		void *rest_k = nullptr, *rest_c = nullptr;
+	};
+	std::vector<Rank> R((size_t)P);
+	std::vector<int> own((size_t)nb);
+	for (int a = 0; a < nb; a++) own[(size_t)a] = owner_of_array_ring(a, nb, P);
+	const u64 msg_words = ring_msg_bytes(k) / 8, blk = (u64)nb * KMX_BUCKET;
+	std::atomic<int> err{0};
+	std::mutex err_mu;
+	std::string err_msg;
+	auto note = [&](int rc) { if (rc) { std::lock_guard<std::mutex> lk(err_mu); if (!err.load()) { err = rc; err_msg = g_err; } } return rc; };
+	auto hip_ok = [&](hipError_t e, const char *what) { if (e != hipSuccess) { fail(KMX_E_NODEVICE, "%s: %s", what, hipGetErrorString(e)); note(KMX_E_NODEVICE); return false; } return true; };
+	HostBarrier bar(P);
+	uint64_t nbf_all[3] = {0, 0, 0};
+	u64 n_km = 0, n_blocks = 0, n_rest_all = 0;
+	std::vector<u64> offs((size_t)P + 1, 0), rest_off((size_t)P + 1, 0);
+	kmx_stats totals;
+	memset(&totals, 0, sizeof totals);
+	auto list_len = [&](u64 b, int i) { const u64 lo = (b * (u64)nb + (u64)i) * KMX_BUCKET; return (int)std::min<u64>(n_km > lo ? n_km - lo : 0, KMX_BUCKET); };
+	auto body = [&](int d) {
+		kmx_model *m = hs[d];
+		Rank &r = R[(size_t)d];
+		if (!hip_ok(hipSetDevice(m->device), "hipSetDevice")) { /* keep going to the barriers */ }
+		hipStream_t st = m->stream;
+		// ---- this rank's slice of the listing: raw records -> device -> decoded there (k_kmc_decode); pass 1 on the slice
+		r.rec_lo = N * (u64)d / (u64)P;
+		r.n = N * (u64)(d + 1) / (u64)P - r.rec_lo;
+		if (!err) {
+			const std::vector<uint64_t> &lut = db.lut();
+			bool ok = hip_ok(hipEventCreateWithFlags(&r.ev_round, hipEventDisableTiming), "event") && hip_ok(hipEventCreateWithFlags(&r.ev_copied, hipEventDisableTiming), "event") &&
+			          hip_ok(hipMalloc((void **)&r.d_lut, lut.size() * 8), "hipMalloc") && hip_ok(hipMemcpy(r.d_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice), "LUT copy") &&
+			          hip_ok(hipMalloc((void **)&r.d_km, std::max<u64>(r.n, 1) * W * 8), "hipMalloc") && hip_ok(hipMalloc((void **)&r.d_cnt, std::max<u64>(r.n, 1) * 4), "hipMalloc") &&
+			          hip_ok(hipMalloc((void **)&r.d_ck, std::max<u64>(r.n, 1) * W * 8), "hipMalloc") && hip_ok(hipMalloc((void **)&r.d_cc, std::max<u64>(r.n, 1) * 4), "hipMalloc");
+			const u64 B = u64(1) << 23;
+			if (ok) ok = hip_ok(hipHostMalloc((void **)&r.h_raw, std::min<u64>(B, std::max<u64>(r.n, 1)) * rb + 16), "hipHostMalloc") && hip_ok(hipMalloc((void **)&r.d_raw, std::min<u64>(B, std::max<u64>(r.n, 1)) * rb + 16), "hipMalloc");
+			KmcDecode kd;
+			kd.lut = r.d_lut; kd.n_lut = lut.size() - 1; kd.prefix_mask = db.prefix_mask();
+			kd.rec_bytes = (u32)rb; kd.suf_bytes = db.suffix_bytes(); kd.cnt_bytes = db.counter_bytes();
+			for (u64 done = 0; ok && done < r.n; done += B) {
+				const u64 c = std::min<u64>(B, r.n - done);
+				db.copy_records(r.rec_lo + done, c, r.h_raw);
+				ok = hip_ok(hipMemcpyAsync(r.d_raw, r.h_raw, c * rb, hipMemcpyHostToDevice, st), "H2D copy");
+				kd.recs = r.d_raw;
+				kmxk::kmc_decode(kd, W, r.rec_lo + done, c, r.d_km + done * W, r.d_cnt + done, st);
+				if (ok) ok = hip_ok(hipStreamSynchronize(st), "decode");          // the pinned slot is reused
+			}
+			if (ok && db.io_failed()) { fail(KMX_E_IO, "reading %s.kmc_suf failed", db_prefix); note(KMX_E_IO); ok = false; }
+			if (ok) note(kmx_count_classes_dev_impl(m, r.d_cnt, r.n, r.nbf));      // kmodel.hpp:423-428 on the slice
+		}
+		bar.wait();
+		if (d == 0) for (int q = 0; q < P; q++) for (int c = 0; c < 3; c++) nbf_all[c] += R[(size_t)q].nbf[c];
+		bar.wait();
+		// ---- sizes from the whole database (kmodel.hpp:402-456), front end on the slice (partial Bloom filters), the coupled class in order
+		if (!err) note(kmx_shard_begin_impl(m, k, nbf_all, db.kmer_count(), d, P));
+		if (!err) { uint64_t nc = 0; if (!note(kmx_shard_classify_dev_impl(m, (const uint64_t *)r.d_km, r.d_cnt, r.n, (uint64_t *)r.d_ck, r.d_cc, &nc))) r.n_c = nc; }
+		if (!err) hip_ok(hipStreamSynchronize(st), "classify");
+		bar.wait();
+		if (d == 0) {
+			for (int q = 0; q < P; q++) offs[(size_t)q + 1] = offs[(size_t)q] + R[(size_t)q].n_c;
+			n_km = offs[(size_t)P];
+			n_blocks = (n_km + blk - 1) / blk;
+		}
+		bar.wait();
+		// ---- routing: every buffer of the stream to the owner of the array it meets first, in block order (dist.plan_routing)
+		if (!err) {
+			for (u64 b = 0; b < n_blocks; b++) for (int i = 0; i < nb; i++) if (own[(size_t)i] == d) r.n_r += (u64)list_len(b, i);
+			bool ok = hip_ok(hipMalloc((void **)&r.d_rk, std::max<u64>(r.n_r, 1) * W * 8), "hipMalloc") && hip_ok(hipMalloc((void **)&r.d_rc, std::max<u64>(r.n_r, 1) * 4), "hipMalloc");
+			u64 at = 0;
+			for (u64 b = 0; ok && b < n_blocks; b++)
+				for (int i = 0; ok && i < nb; i++) {
+					if (own[(size_t)i] != d) continue;
+					const u64 g0 = (b * (u64)nb + (u64)i) * KMX_BUCKET, g1 = g0 + (u64)list_len(b, i);
+					for (int q = 0; ok && q < P; q++) {
+						const u64 lo = std::max(g0, offs[(size_t)q]), hi = std::min(g1, offs[(size_t)q + 1]);
+						if (lo >= hi) continue;
+						const Rank &sr = R[(size_t)q];
+						ok = hip_ok(hipMemcpyPeerAsync(r.d_rk + (at + lo - g0) * W, m->device, sr.d_ck + (lo - offs[(size_t)q]) * W, hs[q]->device, (hi - lo) * W * 8, st), "routing copy") &&
+						     hip_ok(hipMemcpyPeerAsync(r.d_rc + (at + lo - g0), m->device, sr.d_cc + (lo - offs[(size_t)q]), hs[q]->device, (hi - lo) * 4, st), "routing copy");
+					}
+					at += g1 - g0;
+				}
+			r.msg.assign((size_t)nb * 2, nullptr);
+			for (auto &p : r.msg) if (ok) { ok = hip_ok(hipMalloc((void **)&p, msg_words * 8), "hipMalloc") && hip_ok(hipMemsetAsync(p, 0, msg_words * 8, st), "memset"); }
+			if (ok) hip_ok(hipStreamSynchronize(st), "routing");
+		}
+		bar.wait();
+		// ---- the rounds (kmodel.hpp:560-565): this rank attempts the lists whose array it owns; survivors travel as messages
+		u64 pos = 0;
+		for (u64 b = 0; b < n_blocks; b++) {
+			const u64 n_in_block = std::min<u64>(blk, n_km - b * blk);
+			if (!err && n_in_block < blk && b > 0) {                         // quirk Q1 (kmodel.hpp:520-527)
+				const int row = (int)((n_in_block - 1) / KMX_BUCKET);
+				if (row + 1 < nb) note(kmx_ring_stale_dup_dev_impl(m, row + 1));
+			}
+			for (int t = 0; t < nb; t++) {
+				std::vector<kmx_ring_list> lists;
+				std::vector<std::pair<int, int>> recvs, sends;             // (list, peer rank)
+				for (int i = 0; i < nb; i++) {
+					const int n_i = list_len(b, i), a = (i + t) % nb;
+					if (n_i == 0) continue;
+					if (own[(size_t)a] == d) {
+						kmx_ring_list l;
+						memset(&l, 0, sizeof l);
+						l.list = i;
+						l.dst_msg = t + 1 < nb ? r.msg[(size_t)i * 2 + ((t + 1) & 1)] : nullptr;
+						if (t == 0) { l.n_host = n_i; l.src_kmers = r.d_rk + pos * W; l.src_counts = r.d_rc + pos; pos += (u64)n_i; }
+						else { l.n_host = -1; l.src_msg = r.msg[(size_t)i * 2 + (t & 1)]; }
+						lists.push_back(l);
+						if (t + 1 < nb && own[(size_t)((a + 1) % nb)] != d) sends.push_back({i, own[(size_t)((a + 1) % nb)]});
+					} else if (t + 1 < nb && own[(size_t)((a + 1) % nb)] == d) recvs.push_back({i, own[(size_t)a]});
+				}
+				if (!err && !lists.empty()) note(kmx_ring_round_dev_impl(m, t, lists.data(), (int)lists.size()));
+				if (!err) hip_ok(hipEventRecord(r.ev_round, st), "event");
+				bar.wait();
+				if (!err) {
+					for (auto &rv : recvs) {                                 // the survivors of list rv.first, from the rank that just attempted it
+						const Rank &sr = R[(size_t)rv.second];
+						hip_ok(hipStreamWaitEvent(st, sr.ev_round, 0), "wait");
+						hip_ok(hipMemcpyPeerAsync(r.msg[(size_t)rv.first * 2 + ((t + 1) & 1)], m->device, sr.msg[(size_t)rv.first * 2 + ((t + 1) & 1)], hs[rv.second]->device, msg_words * 8, st), "hand-off");
+					}
+					hip_ok(hipEventRecord(r.ev_copied, st), "event");
+				}
+				bar.wait();
+				if (!err) for (auto &sd : sends) hip_ok(hipStreamWaitEvent(st, R[(size_t)sd.second].ev_copied, 0), "wait");   // before this buffer is written again
+				bar.wait();                                                 // (ev_round / ev_copied are recorded again only after everybody has enqueued its waits)
+			}
+		}
+		// ---- merge: survivors to every rank, filters OR-ed (set_bit is an OR, kmodel.hpp:576-581), every array from its owner
+		if (!err) note(kmx_shard_local_impl(m, &r.st, &r.rest_k, &r.rest_c));
+		bar.wait();
+		if (d == 0) {
+			for (int q = 0; q < P; q++) {
+				const kmx_stats &s2 = R[(size_t)q].st;
+				rest_off[(size_t)q + 1] = rest_off[(size_t)q] + s2.rest_entries;
+				totals.attempts += s2.attempts; totals.successes += s2.successes; totals.fast_commits += s2.fast_commits;
+				totals.contended += s2.contended; totals.finisher_iters += s2.finisher_iters;
+			}
+			n_rest_all = rest_off[(size_t)P];
+			totals.blocks = n_blocks; totals.rounds = n_blocks * (u64)nb;
+		}
+		bar.wait();
+		if (!err) {
+			bool ok = hip_ok(hipMalloc((void **)&r.d_allk, std::max<u64>(n_rest_all, 1) * W * 8), "hipMalloc") && hip_ok(hipMalloc((void **)&r.d_allc, std::max<u64>(n_rest_all, 1) * 4), "hipMalloc");
+			for (int q = 0; ok && q < P; q++) {
+				const u64 c = rest_off[(size_t)q + 1] - rest_off[(size_t)q];
+				if (!c) continue;
+				ok = hip_ok(hipMemcpyPeerAsync(r.d_allk + rest_off[(size_t)q] * W, m->device, R[(size_t)q].rest_k, hs[q]->device, c * W * 8, st), "survivor copy") &&
+				     hip_ok(hipMemcpyPeerAsync(r.d_allc + rest_off[(size_t)q], m->device, R[(size_t)q].rest_c, hs[q]->device, c * 4, st), "survivor copy");
+			}
+			if (ok) hip_ok(hipStreamSynchronize(st), "survivor gather");
+		}
+		bar.wait();
+		auto filter = [&](kmx_model *mm, int which, int idx, u32 **p, u64 *words) {
+			void *vp = nullptr; uint64_t bytes = 0;
+			kmx_dev_view_impl(mm, which, idx, &vp, &bytes);
+			*p = (u32 *)vp; *words = bytes / 4;
+		};
+		if (!err && d == 0) {                                              // rank 0 ORs everybody's partial filters ...
+			u64 wmax = 0;
+			for (int f = 0; f < 2 * m->bf_num + 1; f++) { u32 *p; u64 w; filter(m, f < m->bf_num ? 0 : (f < 2 * m->bf_num ? 1 : 2), f % m->bf_num, &p, &w); wmax = std::max(wmax, w); }
+			bool ok = hip_ok(hipMalloc((void **)&r.d_tmp, std::max<u64>(wmax, 1) * 4), "hipMalloc");
+			for (int f = 0; ok && f < 2 * m->bf_num + 1; f++) {
+				const int which = f < m->bf_num ? 0 : (f < 2 * m->bf_num ? 1 : 2), idx = which == 2 ? 0 : f % m->bf_num;
+				u32 *mine; u64 w;
+				filter(m, which, idx, &mine, &w);
+				for (int q = 1; ok && q < P && w; q++) {
+					u32 *theirs; u64 w2;
+					filter(hs[q], which, idx, &theirs, &w2);
+					ok = hip_ok(hipMemcpyPeerAsync(r.d_tmp, m->device, theirs, hs[q]->device, w * 4, st), "filter copy");
+					kmxk::or_words(mine, r.d_tmp, w, st);
+				}
+			}
+			if (ok) hip_ok(hipStreamSynchronize(st), "filter merge");
+		}
+		bar.wait();
+		if (!err) {                                                        // ... and everybody takes the merged filters and the arrays it does not own
+			if (d != 0)
+				for (int f = 0; f < 2 * m->bf_num + 1; f++) {
+					const int which = f < m->bf_num ? 0 : (f < 2 * m->bf_num ? 1 : 2), idx = which == 2 ? 0 : f % m->bf_num;
+					u32 *mine, *theirs; u64 w, w2;
+					filter(m, which, idx, &mine, &w);
+					filter(hs[0], which, idx, &theirs, &w2);
+					if (w) hip_ok(hipMemcpyPeerAsync(mine, m->device, theirs, hs[0]->device, w * 4, st), "filter copy");
+				}
+			for (int a = 0; a < nb; a++)
+				if (own[(size_t)a] != d) hip_ok(hipMemcpyPeerAsync(m->d_cells[a], m->device, hs[own[(size_t)a]]->d_cells[a], hs[own[(size_t)a]]->device, m->ncells * sizeof(cell_t), st), "array copy");
+			hip_ok(hipStreamSynchronize(st), "merge");
+		}
+		bar.wait();
+		if (!err) note(kmx_shard_complete_impl(m, (const uint64_t *)r.d_allk, r.d_allc, n_rest_all, &totals));
+		hipStreamSynchronize(st);
+		bar.wait();                                                         // nobody frees what a peer may still be reading
+		hipFree(r.d_km); hipFree(r.d_cnt); hipFree(r.d_ck); hipFree(r.d_cc); hipFree(r.d_rk); hipFree(r.d_rc); hipFree(r.d_allk); hipFree(r.d_allc);
+		hipFree(r.d_lut); hipFree(r.d_raw); hipFree(r.d_tmp);
+		if (r.h_raw) hipHostFree(r.h_raw);
+		for (u64 *p : r.msg) hipFree(p);
+		if (r.ev_round) hipEventDestroy(r.ev_round);
+		if (r.ev_copied) hipEventDestroy(r.ev_copied);
+	};
+	std::vector<std::thread> th;
+	for (int d = 1; d < P; d++) th.emplace_back(body, d);
+	body(0);
+	for (auto &x : th) x.join();
+	if (err) { snprintf(g_err, sizeof g_err, "%s", err_msg.c_str()); for (int d = 0; d < P; d++) if (hs[d]->state == ST_BUILDING) hs[d]->state = ST_EMPTY; return err; }
+	return KMX_OK;
+}
+
+static int kmx_create_on_impl(int device, int ci, int cs, int nh, int nb, kmx_model **out)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(KMX_E_NODEVICE, "no HIP device: libkmx has no CPU fallback");
+	if (device < 0 || device >= n) return fail(KMX_E_ARG, "device %d: this process sees %d", device, n);
+	HIPCHK(hipSetDevice(device));
+	return kmx_create_impl(ci, cs, nh, nb, out);
+}
+
 // ------------------------------------------------------------------------------------------ position-range partition (range_kernels.h)
 // Every coupled array cut by position range over the ranks (the north star's partition); the caller moves
 // the words between the ranks (three all-to-alls per round: kmcex_amd/dist.py build_sharded(partition="range")).
@@ -2629,6 +2893,8 @@ extern "C" int kmx_ring_round_dev(kmx_model *m, int t, const kmx_ring_list *list
 extern "C" int kmx_ring_stale_dup_dev(kmx_model *m, int first_unused_row) { return guarded([&] { return kmx_ring_stale_dup_dev_impl(m, first_unused_row); }); }
 extern "C" int kmx_shard_local(kmx_model *m, kmx_stats *partial, void **d_rest_kmers, void **d_rest_counts) { return guarded([&] { return kmx_shard_local_impl(m, partial, d_rest_kmers, d_rest_counts); }); }
 extern "C" int kmx_shard_complete(kmx_model *m, const uint64_t *d_rest_kmers, const int32_t *d_rest_counts, uint64_t n_rest, const kmx_stats *totals) { return guarded([&] { return kmx_shard_complete_impl(m, d_rest_kmers, d_rest_counts, n_rest, totals); }); }
+extern "C" int kmx_create_on(int device, int ci, int cs, int nh, int nb, kmx_model **out) { return guarded([&] { return kmx_create_on_impl(device, ci, cs, nh, nb, out); }); }
+extern "C" int kmx_build_from_kmc_multi(kmx_model **models, int n_models, const char *db_prefix) { return guarded([&] { return kmx_build_from_kmc_multi_impl(models, n_models, db_prefix); }); }
 extern "C" int kmx_range_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world) { return guarded([&] { return kmx_range_begin_impl(m, k, n_bf, n_total, rank, world); }); }
 extern "C" int kmx_range_buffers(kmx_model *m, void **d_send, uint64_t *cap_words, uint64_t *cell_lo) { return guarded([&] { return kmx_range_buffers_impl(m, d_send, cap_words, cell_lo); }); }
 extern "C" int kmx_range_emit_dev(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists, uint64_t *counts) { return guarded([&] { return kmx_range_emit_dev_impl(m, t, lists, n_lists, counts); }); }

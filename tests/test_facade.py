@@ -37,6 +37,21 @@ def test_driver_reproduces_reference_model_files(tmp_path):
         assert sha_file(os.path.join(str(tmp_path), "db", f)) == sha_file(os.path.join(tiny, f)), f
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0", "0,0,0,0,0"])
+def test_driver_on_several_devices_reproduces_reference_model_files(tmp_path, devices):
+    """KMX_DEVICES: KModel::init from C++ on several handles (all on device 0 here: the pool has one GPU) -- one host thread per
+    handle, the ring of whole arrays with hipMemcpyPeerAsync hand-offs (kmx_build_from_kmc_multi) -- writes the reference's files."""
+    exe = _compile(tmp_path)
+    tiny = os.path.join(ROOT, "tests", "golden", "tiny")
+    env = dict(os.environ, KMC_BIN="/nonexistent", KMX_DEVICES=devices)
+    p = subprocess.run([exe, "-k31", "-nh7", "-nb5", "-ci1", "-cs1023", "reads.fq", os.path.join(tiny, "db"), str(tmp_path)],
+                       capture_output=True, text=True, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    for f in ("header", "km.bin", "rest.bin"):
+        assert sha_file(os.path.join(str(tmp_path), "db", f)) == sha_file(os.path.join(tiny, f)), f
+
+
 def test_facade_query_program_compiles(tmp_path):
     _compile(tmp_path, os.path.join(ROOT, "tests", "facade_query.cpp"), "facade_query")
 
