@@ -725,18 +725,28 @@ __device__ __forceinline__ void dt_lookup(const u32 *s_t, u32 tmask, u64 e, unsi
 }
 
 // keep_own: this round's winners will be committed beside the next round's check, whose k_round_detect reads (and resets) the bins.
-template <int NHM, int BT> __global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(NHM <= 8 ? 8 : 4)))
-void k_round_detect(BlockDev bd, int nb, int pp, int use_delta, int keep_own)
+// TBITS: log2 of the table.  The full-size form (KMX_CL_TBITS: 64 KB at nh <= 8, two 1024-thread workgroups per CU) takes every
+// tuple of a full bin.  The SMALL form (KMX_CL_TBITS_SMALL, 256 threads, 16 KB: every bin of every list resident at once) is
+// for the late rounds, whose bins hold a few hundred tuples: a launch of it is one generation of workgroups instead of three.
+// A bin that does not fit a small table raises cl_ovf[i] -- the whole list takes the ordered path, exact like any other
+// overflow -- and reports its fill (`late`: ST_MAX_LATE_BIN), from which the host decides which form the late rounds get.
+template <int NHM, int BT, int TBITS> __global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(NHM <= 8 ? 8 : 4)))
+void k_round_detect(BlockDev bd, int nb, int pp, int use_delta, int keep_own, int late)
 {
-	constexpr int NBIN = KMX_CL_BINS(NHM), TBITS = KMX_CL_TBITS(NHM), T = 1 << TBITS, CAP = KMX_CL_CAP_OF(NHM);
-	static_assert(CAP <= T / 4 * 3, "the table of a bin must take every tuple of a full bin with room to spare");
-	__shared__ u32 s_t[T];                                           // exactly 64 KB at nh <= 8: two workgroups per CU
+	constexpr int NBIN = KMX_CL_BINS(NHM), T = 1 << TBITS, CAP = KMX_CL_CAP_OF(NHM), TCAP = T / 4 * 3;
+	static_assert(TBITS < KMX_CL_TBITS(NHM) || CAP <= TCAP, "the full-size table of a bin must take every tuple of a full bin with room to spare");
+	__shared__ u32 s_t[T];                                           // exactly 64 KB at nh <= 8 (full size): two workgroups per CU
 	const int i = (int)blockIdx.y, b = blockIdx.x;
 	const int id = (i + 1) % nb;                                     // list that visited this array one round earlier
 	int *gc = bd.cl_cnt[pp] + i * KMX_CL_MAXBINS + b;
 	int *gd = bd.cl_cnt[pp ^ 1] + id * KMX_CL_MAXBINS + b;
 	int cnt = *gc, dcnt = *gd;
+	if (late && threadIdx.x == 0 && cnt > 1024) atomicMax(bd.stats + ST_MAX_LATE_BIN, (u64)cnt);
 	if (cnt > CAP) cnt = CAP;                                        // check_emit has raised cl_ovf[i]
+	if (cnt > TCAP) {                                                // (small form only) the bin does not fit: the list takes the ordered path
+		if (threadIdx.x == 0) bd.cl_ovf[i] = 1;
+		cnt = 0;
+	}
 	if (dcnt > CAP) dcnt = CAP;                                      // (that list had no uncontended winner then: nothing of it passes the filter)
 	if (!use_delta) dcnt = 0;
 	if (cnt) {                                                       // uniform
@@ -744,7 +754,7 @@ void k_round_detect(BlockDev bd, int nb, int pp, int use_delta, int keep_own)
 		const u64 *dp = bd.cl_tup[pp ^ 1] + ((u64)id * NBIN + b) * CAP;
 		const unsigned char *dstatus = bd.status[pp ^ 1] + (u64)id * KMX_BUCKET;
 		unsigned char *status = bd.status[pp] + (u64)i * KMX_BUCKET, *dfail = bd.dfail + (u64)i * KMX_BUCKET;
-		int tb = 10;
+		int tb = TBITS < 10 ? TBITS : 10;
 		while ((1 << tb) < 4 * cnt && tb < TBITS) tb++;              // load <= 1/4 (<= 3/4 for a full bin): short probe chains
 		const u32 tmask = (1u << tb) - 1;
 		for (int q = threadIdx.x; q < (1 << tb); q += BT) s_t[q] = 0;
@@ -1797,8 +1807,8 @@ template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev b
 	__shared__ int s_cnt;
 	__shared__ unsigned long long s_base;
 	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // the block's contention figures go straight to the host's pinned words
-		feedback[0] = bd.stats[ST_MAX_U0]; feedback[1] = bd.stats[ST_MAX_UFIN];
-		bd.stats[ST_MAX_U0] = 0; bd.stats[ST_MAX_UFIN] = 0;
+		feedback[0] = bd.stats[ST_MAX_U0]; feedback[1] = bd.stats[ST_MAX_UFIN]; feedback[2] = bd.stats[ST_MAX_LATE_BIN];
+		bd.stats[ST_MAX_U0] = 0; bd.stats[ST_MAX_UFIN] = 0; bd.stats[ST_MAX_LATE_BIN] = 0;
 	}
 	if (threadIdx.x == 0) s_cnt = 0;
 	__syncthreads();
@@ -2547,8 +2557,12 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	}
 	KPROF_BEGIN(prof, KC_DETECT, st);
 	const int keep_own = (flags & KMX_ROUND_KEEP) ? 1 : 0;
-	if (md.nh <= 8) hipLaunchKernelGGL((k_round_detect<8, 1024>), dim3(KMX_CL_BINS(8), nb), dim3(1024), 0, st, bd, nb, pp, pending, keep_own);   // (256 threads for the late rounds' few
-	else hipLaunchKernelGGL((k_round_detect<16, 1024>), dim3(KMX_CL_BINS(16), nb), dim3(1024), 0, st, bd, nb, pp, pending, keep_own);           //  hundred tuples per bin measured slower)
+	const int late = t >= 2 ? 1 : 0;
+	if (late && (flags & KMX_ROUND_SMALL_DETECT)) {                  // the late rounds' few hundred tuples per bin: small tables, every bin resident at once
+		if (md.nh <= 8) hipLaunchKernelGGL((k_round_detect<8, 256, KMX_CL_TBITS_SMALL>), dim3(KMX_CL_BINS(8), nb), dim3(256), 0, st, bd, nb, pp, pending, keep_own, late);
+		else hipLaunchKernelGGL((k_round_detect<16, 256, KMX_CL_TBITS_SMALL>), dim3(KMX_CL_BINS(16), nb), dim3(256), 0, st, bd, nb, pp, pending, keep_own, late);
+	} else if (md.nh <= 8) hipLaunchKernelGGL((k_round_detect<8, 1024, KMX_CL_TBITS(8)>), dim3(KMX_CL_BINS(8), nb), dim3(1024), 0, st, bd, nb, pp, pending, keep_own, late);
+	else hipLaunchKernelGGL((k_round_detect<16, 1024, KMX_CL_TBITS(16)>), dim3(KMX_CL_BINS(16), nb), dim3(1024), 0, st, bd, nb, pp, pending, keep_own, late);
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_FILE, st);
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_file<W, NHM>), dim3(KMX_FILE_WGS, nb), dim3(1024), 0, st, md, bd, pp, eb));

@@ -284,6 +284,7 @@ struct kmx_model {
 	// test hooks, read from the environment by kmx_begin: forced pass counts, forced older code
 	// paths (KMX_ROUND_* flags of kmx_types.h), a trace of the pass-count controller
 	int dbg_nsub0 = -1, dbg_nsub1 = -1, dbg_flags = 0;
+	int dbg_small_detect = -1;                                 // KMX_SMALL_DETECT=0/1: force the form of the late rounds' k_round_detect (test hook)
 	bool dbg_ctrl = false;
 	u64 h_stats[ST_N] = {0};
 	double t_insert_kernels = 0, t_total = 0;
@@ -439,12 +440,13 @@ static int create_device_side(kmx_model *m)
 	HIPCHK(hipHostMalloc((void **)&m->h_total, 64));
 	HIPCHK(hipHostMalloc((void **)&m->h_feedback, 64, hipHostMallocMapped));
 	HIPCHK(hipHostGetDevicePointer((void **)&m->d_feedback, m->h_feedback, 0));
-	m->h_feedback[0] = ~0ULL; m->h_feedback[1] = 0;
+	m->h_feedback[0] = ~0ULL; m->h_feedback[1] = 0; m->h_feedback[2] = 0;
 	{
 		auto env_int = [](const char *name, int dflt) { const char *v = hook_env(name); return v ? atoi(v) : dflt; };
 		m->dbg_nsub0 = env_int("KMX_NSUB0", -1);
 		m->dbg_nsub1 = env_int("KMX_NSUB1", -1);
 		m->dbg_flags = (env_int("KMX_FIN_GLOBAL", 0) ? KMX_ROUND_FIN_GLOBAL : 0) | (env_int("KMX_RESOLVE_GATHER", 0) ? KMX_ROUND_RESOLVE_GATHER : 0);
+		m->dbg_small_detect = env_int("KMX_SMALL_DETECT", -1);
 		m->dbg_no_defer = env_int("KMX_PIPE", 1) == 0;                      // KMX_PIPE=0: commit after every round, check against the committed state only
 		m->dbg_ctrl = env_int("KMX_CTRL_DEBUG", 0) != 0;
 		m->dbg_kmb_direct = env_int("KMX_KMB_DIRECT", 0) != 0;
@@ -865,7 +867,7 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 	HIPCHK(hipMemsetAsync(m->d_stale_counts, 0, (u64)nb * 4, m->stream));
 	HIPCHK(hipMemsetAsync(m->d_stats, 0, ST_N * 8, m->stream));
 	m->blocks = 0; m->rounds = 0;
-	m->h_feedback[0] = ~0ULL; m->h_feedback[1] = 0;
+	m->h_feedback[0] = ~0ULL; m->h_feedback[1] = 0; m->h_feedback[2] = 0;
 	{   // first guess of the contended set per list in round 0: a candidate is contended when one of its nh positions
 		// is also claimed with the other value by one of the ~2^18*nh/2 opposite claims spread over the L positions
 		const double L = (double)m->km_byte_size * 8.0;
@@ -960,7 +962,11 @@ static int flush_pending_commit(kmx_model *m)
 static_assert(KMX_CL_MIX_BITS == 36, "kmx_begin's defer gate, cl_mix's mask and the 8 + 28-bit table entry of k_round_detect all assume 36 bits");
 static int run_round(kmx_model *m, int t, bool defer, const KmbackJob *job)
 {
-	const int flags = m->dbg_flags | (m->pending ? KMX_ROUND_PENDING : 0) | (defer ? KMX_ROUND_KEEP : 0);
+	// late rounds: small detect tables while the fullest late bin the device reported stays far below what they take (a
+	// launch-shape heuristic like steer_passes: a bin that does not fit only sends its list down the ordered path, never changes the result)
+	const u64 late_bin = ((volatile u64 *)m->h_feedback)[2];
+	const bool small_detect = m->dbg_small_detect >= 0 ? m->dbg_small_detect != 0 : late_bin <= 2048;
+	const int flags = m->dbg_flags | (m->pending ? KMX_ROUND_PENDING : 0) | (defer ? KMX_ROUND_KEEP : 0) | (small_detect ? KMX_ROUND_SMALL_DETECT : 0);
 	kmxk::round(m->md, m->bd, t, m->pp, passes_of_round(m, t), &m->epoch, flags, m->stream, &m->prof, job, &m->kmb);
 	m->pending = true; m->pending_t = t;
 	m->pp ^= 1;

@@ -75,6 +75,7 @@ struct KmcDecode {
 enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, ST_BAD_COUNT, ST_MAX_U0, ST_MAX_UFIN,
        ST_PIPE_ATTEMPTS, ST_PIPE_SUCC,        // attempts examined / winners committed inside fused commit|check launches (accounting only)
        ST_PIPE_GATHERS, ST_PIPE_ATOMICS,      // random 4-byte loads / 32-bit atomic ORs issued inside those launches (the staged fetch stops early; one atomic per NEW tag bit)
+       ST_MAX_LATE_BIN,                       // fullest claim bin of a late round (t >= 2) since the last block: picks the form of their k_round_detect
        ST_DELTA_FAILS,                        // candidates of a stale check that a still-uncommitted winner of the previous visit ruled out (k_round_detect)
        ST_N };
 
@@ -86,7 +87,8 @@ enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, 
 #define KMX_APPLY_WGS 8                         // extra workgroups per list in k_reorder that apply the finisher's decisions
 enum { KMX_ROUND_FIN_GLOBAL = 1, KMX_ROUND_RESOLVE_GATHER = 2,     // test hooks of kmxk::round (older code paths)
        KMX_ROUND_PENDING = 4,                                        // the previous round's winners are not committed yet: their commit rides with this round's check
-       KMX_ROUND_KEEP = 8 };                                         // this round's winners will be committed beside the next round's check (its detect re-reads the claims)
+       KMX_ROUND_KEEP = 8,
+       KMX_ROUND_SMALL_DETECT = 16 };                               // rounds t >= 2: k_round_detect with small tables (their bins hold a few hundred tuples)                                         // this round's winners will be committed beside the next round's check (its detect re-reads the claims)
 #define KMX_NSLOW 2                            // contended-record levels, ping-pong: pass s reads level s&1, defers to (s+1)&1
 #define KMX_MAX_NSUB 16                        // most grid-wide ordered passes per round
 #define KMX_CTR_STRIDE 32                      // ints between per-list counters: one 128-byte line each (same-line atomics serialise)
@@ -143,6 +145,7 @@ struct BlockDev {
 // 2^TBITS > capacity slots: the table of a bin can always take every tuple.  64 KB of LDS at nh <= 8: two 1024-thread
 // workgroups per CU, so one's loads run under the other's table phase
 #define KMX_CL_TBITS(NHM) ((NHM) <= 8 ? 14 : 15)
+#define KMX_CL_TBITS_SMALL 12                  // the late rounds' form: 16 KB, 256 threads; takes bins of up to 3072 tuples
 
 #define LIST_HOLE 0x80000000u
 

@@ -346,10 +346,10 @@ void range_verdict(const ModelDev &md, const BlockDev &obd, int t, const u64 *tr
 	if (!n) return;
 	if (md.nh <= 8) {
 		hipLaunchKernelGGL((k_range_verdict<8>), dim3(range_grid(n)), dim3(256), 0, st, md, obd, t, triples, n, verdict);
-		hipLaunchKernelGGL((k_round_detect<8, 1024>), dim3(KMX_CL_BINS(8), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0);
+		hipLaunchKernelGGL((k_round_detect<8, 1024, KMX_CL_TBITS(8)>), dim3(KMX_CL_BINS(8), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, 0);
 	} else {
 		hipLaunchKernelGGL((k_range_verdict<16>), dim3(range_grid(n)), dim3(256), 0, st, md, obd, t, triples, n, verdict);
-		hipLaunchKernelGGL((k_round_detect<16, 1024>), dim3(KMX_CL_BINS(16), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0);
+		hipLaunchKernelGGL((k_round_detect<16, 1024, KMX_CL_TBITS(16)>), dim3(KMX_CL_BINS(16), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, 0);
 	}
 	hipLaunchKernelGGL(k_range_verdict2, dim3(range_grid(n)), dim3(256), 0, st, obd, triples, n, verdict);
 	hipMemsetAsync(obd.status[0], 0, (u64)md.nb * KMX_BUCKET, st);
