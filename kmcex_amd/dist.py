@@ -355,6 +355,9 @@ class DeviceEngine:
         if commits.numel():
             self.m.range_commit_dev(t, commits.data_ptr(), commits.numel())
 
+    def array_ranges(self, a):
+        return [(self.view("cells", a), self.cell_lo)]
+
     def local(self):
         st, pk, pc = self.m.shard_local()
         n = int(st.rest_entries)
@@ -537,9 +540,8 @@ def build_range_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: to
             comm.or_allreduce(eng.view("bf", i), eng.or_into)
             comm.or_allreduce(eng.view("bf_back", i), eng.or_into)
         comm.or_allreduce(eng.view("km_back"), eng.or_into)
-        lo = eng.cell_lo
         for a in range(nb):                                      # every rank's cell range of every array -> every rank
-            for v in eng.array_views(a):
+            for v, lo in eng.array_ranges(a):                    # (a view of the array and the ranks' bounds in its elements)
                 v.copy_(comm.all_gather_v(v[lo[rank]:lo[rank + 1]], [lo[q + 1] - lo[q] for q in range(world)]))
     eng.complete(rest_km_all, rest_cnt_all, st)
     return {"n_km": n_km, "blocks": n_blocks, "bytes_sent": comm.bytes_sent - sent0, "collectives": comm.collectives - coll0,

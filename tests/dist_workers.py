@@ -111,7 +111,7 @@ def gpu_worker(rank, world, port, spec, out_dir, q, load_dir=None, partition="ri
         q.put({"rank": rank, "error": traceback.format_exc()})
 
 
-def cpu_worker(rank, world, port, spec, out_dir, q):
+def cpu_worker(rank, world, port, spec, out_dir, q, partition="ring"):
     """One rank of the same orchestration (kmcex_amd.dist.build_sharded) over gloo with the ORACLE as the per-rank engine:
     checks the protocol -- routing all-to-all, ring of arrays, OR-merge, survivor gather -- without a GPU."""
     try:
@@ -123,13 +123,14 @@ def cpu_worker(rank, world, port, spec, out_dir, q):
         from common import sha_file, sha_occ
         from kmcex_amd import dist as kd
         from oracle_engine import OracleEngine
+        from range_engine import RangeOracleEngine
         dist.init_process_group("gloo", rank=rank, world_size=world)
         comm = kd.Comm()
         k, ci, cs, nh, nb, km, cnt, base = listing_of(spec)
         lo, hi = kd.split_batch(len(cnt), world, rank)
         tk, tc = _to_torch(km[lo:hi], cnt[lo:hi], k, "cpu")
-        eng = OracleEngine(ci, cs, nh, nb)
-        info = kd.build_sharded(eng, comm, k, nb, eng.bf_num, tk, tc)
+        eng = (RangeOracleEngine if partition == "range" else OracleEngine)(ci, cs, nh, nb)
+        info = kd.build_sharded(eng, comm, k, nb, eng.bf_num, tk, tc, partition=partition)
         so = eng.o.stats()
         res = {"rank": rank, "info": info, "stats": (so.n_km, list(so.n_bf), so.attempts, so.successes, so.rest_entries)}
         d = os.path.join(out_dir, f"rank{rank}")

@@ -124,6 +124,26 @@ def test_single_model_protocol_with_oracle_engine(spec, world, golden, tmp_path)
     assert res[0]["occ_sha"] == g["occ_sha256"]
 
 
+@pytest.mark.parametrize("spec,world", [
+    (("synth", "tiny_k31"), 2),
+    (("synth", "k31_ci2_200k"), 3),                # three Bloom classes; 5 lists on 3 ranks
+    (("synth", "k31_multiblock_ci1"), 2),          # several blocks, the partial last one with unused rows: quirk Q1 on the ranks that hold those lists
+    (("synth", "tiny_k31"), 8),                    # a whole node: 5 lists on ranks 0-4, every rank owns an eighth of every array
+], ids=lambda v: v[1] if isinstance(v, tuple) else f"w{v}")
+def test_range_partition_protocol_with_numpy_engine(spec, world, golden, tmp_path):
+    """kmcex_amd.dist.build_sharded(partition="range") -- buffer i routed to rank i % P, split sizes, triples / verdicts / commits
+    by all-to-all, all-gather of the cell ranges -- over gloo with a numpy engine on the oracle's arrays (tests/range_engine.py):
+    every rank ends with the reference's files.  (The device engine runs the same orchestration in tests/test_gpu_dist.py.)"""
+    from dist_workers import cpu_worker, run_ranks
+    g = golden["cases"][spec[1]]
+    res = run_ranks(cpu_worker, world, spec, str(tmp_path), "range", timeout=900)
+    for r in res:
+        assert r["sha"] == {f: g["sha256"][f] for f in ("header", "km.bin", "rest.bin")}, f"rank {r['rank']} holds a different model"
+        assert r["stats"][2:5] == (g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
+        assert r["info"]["partition"] == "range" and r["info"]["collectives"] >= 3 * r["info"]["blocks"]
+    assert res[0]["occ_sha"] == g["occ_sha256"]
+
+
 def test_ring_message_pieces_cover_exactly_the_survivors():
     """the staged transport ships header + n k-mers + n counts of a ring message, not the 2^18-entry buffer"""
     for W in (1, 2):
