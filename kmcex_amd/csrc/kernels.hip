@@ -1530,144 +1530,10 @@ __device__ __forceinline__ void finish_global(const ModelDev &md, const BlockDev
 // (`job`: its staging region and survivor flags) runs in the same launch, one 1024-thread workgroup per 1024 k-mers --
 // throughput work that costs the launch (almost) nothing.  (Hosted by the late rounds' check launches instead it cost
 // 15-24 us per launch: its LDS cut the check's occupancy from 8 to 3 workgroups per CU.)
-// The late rounds (t >= 2, lists of a few ten thousand slots, a dozen contended k-mers) as ONE launch for file + finisher +
-// reorder: the finisher workgroup of a list does the other two steps for its list itself (`tail`), under the rider workgroups
-// that bound the launch anyway -- two launches (and their boundaries) fewer per late round.
-// tail_file = k_round_file for one list by one workgroup: no barrier inside the sweep; the contended slots are appended to
-// Urec[0] (slot number first, the record in a second pass), failures found by k_round_detect are counted per tile.
-template <int W, int NHM> __device__ __forceinline__ int tail_file(const ModelDev &md, const BlockDev &bd, int pp, u64 epoch, int i, int *s_nq, int *s_df)
-{
-	const int n = bd.n[pp][i];
-	const u64 row = (u64)i * KMX_BUCKET;
-	const bool all_contended = bd.cl_ovf[i] != 0;
-	u32 *status32 = (u32 *)(bd.status[pp] + row), *dfail32 = (u32 *)(bd.dfail + row);
-	if (threadIdx.x == 0) { *s_nq = 0; *s_df = 0; }
-	__syncthreads();
-	for (int w = threadIdx.x; 4 * w < n; w += 1024) {
-		const int x0 = 4 * w;
-		const u32 st = status32[w], df = dfail32[w];
-		u32 st_new = st;
-		int nfail = 0;
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			if (x0 + k >= n) break;
-			const u32 sk = (st >> (8 * k)) & 0xFFu;
-			if (sk == SLOT_FAILED) continue;
-			if ((df >> (8 * k)) & 0xFFu) {
-				st_new = (st_new & ~(0xFFu << (8 * k))) | ((u32)SLOT_FAILED << (8 * k));
-				nfail++;
-			} else if (sk == SLOT_CONTENDED || (sk == SLOT_UNDECIDED && all_contended)) {
-				st_new &= ~(0xFFu << (8 * k));                           // SLOT_UNDECIDED: the ordered path decides it
-				bd.Urec[0][(row + (u64)atomicAdd(s_nq, 1)) * (1 + W)] = (u64)(x0 + k);
-			}
-		}
-		if (st_new != st) status32[w] = st_new;
-		if (df) dfail32[w] = 0;
-		if (nfail) { atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (x0 >> 10), nfail); atomicAdd(s_df, nfail); }
-	}
-	drain_vmem();
-	__syncthreads();
-	const int nq = *s_nq;
-	for (int e = threadIdx.x; e < nq; e += 1024) {
-		const u32 x = (u32)bd.Urec[0][(row + (u64)e) * (1 + W)];
-		const u32 idx = bd.list[pp][row + x];
-		u64 v[W];
-		load_kmer<W>(bd.kmers, row + idx, v);
-		const u32 uw = bd.uw[pp][row + x], um = uw & 0xFFFFu, bin = uw >> 16;
-		const CRec<NHM> rec = crec_load<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh);
-		const u64 key = resv_key(epoch, x);
-#pragma unroll
-		for (int j = 0; j < NHM; j++)
-			if (j < md.nh && ((um >> j) & 1u)) {
-				const u64 pos = ((u64)crec_cell<NHM>(rec, j) << 4) | crec_nib<NHM>(rec, md.nh, j);
-				atomicMax(resv_slot(bd, i, pos), key);
-			}
-		rec_store<W>(bd.Urec[0], row + (u64)e, x, bin, v, um);
-	}
-	if (threadIdx.x == 0) {
-		bd.Un[UN_IDX(0, i, md.nb)] = nq;
-		if (*s_df) atomicAdd(bd.stats + ST_DELTA_FAILS, (u64)*s_df);
-	}
-	drain_vmem();
-	__syncthreads();
-	return nq;
-}
-// tail_reorder = k_reorder for one list by one workgroup: every thread takes a CONTIGUOUS run of slots, one scan of the
-// per-thread survivor counts gives each run its place (no tile counts needed); applies the finisher's REC_WON records first.
-template <int W, int NHM> __device__ __forceinline__ void tail_reorder(const ModelDev &md, const BlockDev &bd, int t, int pp, int i, int nrec, int *s_w)
-{
-	const int nb = md.nb, n = bd.n[pp][i];
-	const u64 row = (u64)i * KMX_BUCKET;
-	for (int u = threadIdx.x; u < nrec; u += 1024) {
-		const u64 *rec = bd.Urec[0] + (row + u) * (1 + W);
-		if (rec[0] & REC_WON) {
-			const int a = (i + t) % nb;
-			u32 x, bin;
-			u64 v[W];
-			rec_load<W>(bd.Urec[0], row + u, x, bin, v);
-			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
-			cell_t *cells = md.cells[a];
-#pragma unroll
-			for (int j = 0; j < NHM; j++)
-				if (j < md.nh) {
-					const u64 pos = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(a * md.nh + j) & 127]), md.km_mod);
-					const u32 b = bit_in_cell(pos);
-					atomicOr(cells + (pos >> 4), CELL_TAG(b) | (((bin >> j) & 1u) ? CELL_VAL(b) : 0u));
-				}
-		}
-	}
-	const int S = ((n + 1023) / 1024 + 3) & ~3;                     // slots per thread, whole status words
-	const int lo = (int)threadIdx.x * S, hi = lo + S < n ? lo + S : n;
-	const unsigned char *status = bd.status[pp] + row;
-	int c = 0;
-	for (int x = lo; x < hi; x += 4) {
-		const u32 st = *(const u32 *)(status + x);
-#pragma unroll
-		for (int k = 0; k < 4; k++) c += (x + k < hi && ((st >> (8 * k)) & 0xFFu) == SLOT_FAILED) ? 1 : 0;
-	}
-	// exclusive scan of c over the 1024 threads
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	int incl = c;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		const int tt = __shfl_up(incl, d, 64);
-		if (lane >= d) incl += tt;
-	}
-	if (lane == 63) s_w[wave] = incl;
-	__syncthreads();
-	int before = incl - c, m = 0;
-#pragma unroll
-	for (int w = 0; w < 16; w++) {
-		const int cw = s_w[w];
-		if (w < wave) before += cw;
-		m += cw;
-	}
-	const u32 *oldl = bd.list[pp] + row;
-	u32 *newl = bd.list[pp ^ 1] + row;
-	u32 *mv = bd.mover[pp ^ 1] + row;
-	for (int x = lo; x < hi; x += 4) {
-		const u32 st = *(const u32 *)(status + x);
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			if (x + k >= hi) break;
-			const int f = ((st >> (8 * k)) & 0xFFu) == SLOT_FAILED ? 1 : 0;
-			if (x + k < m) newl[x + k] = f ? oldl[x + k] : (LIST_HOLE | (u32)(x + k - before));     // hole number x-before, left to right
-			else if (f) mv[m - before - 1] = oldl[x + k];                                         // survivor number m-before-1 from the right
-			before += f;
-		}
-	}
-	for (int q = threadIdx.x; q < (int)KMX_NTILES; q += 1024) bd.tile_cnt[pp ^ 1][i * KMX_NTILES + q] = 0;
-	if (threadIdx.x == 0) {
-		bd.cl_ovf[i] = 0;
-		if (n > m) atomicAdd(bd.stats + ST_SUCCESSES, (u64)(n - m));
-		bd.n[pp ^ 1][i] = m;
-	}
-}
-
-template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch_b, u64 epoch0, int force_global, KmbackJob job, BitScatter kmb, int tail)
+template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(ModelDev md, BlockDev bd, int t, int pp, int s, u64 epoch_b, u64 epoch0, int force_global, KmbackJob job, BitScatter kmb)
 {
 	constexpr int RKPT = KMX_FIN_RIDER_KPT(NHM);
-	constexpr int FIN_BYTES = (2 * KMX_FIN_T + KMX_FIN_RPT(NHM) * 1024) * 4 + 32 * 4, RIDER_BYTES = BS_LDS_BYTES(RKPT * (NHM - 2), 1024);
+	constexpr int FIN_BYTES = (2 * KMX_FIN_T + KMX_FIN_RPT(NHM) * 1024) * 4 + 8 * 4, RIDER_BYTES = BS_LDS_BYTES(RKPT * (NHM - 2), 1024);
 	__shared__ __align__(16) unsigned char pool[FIN_BYTES > RIDER_BYTES ? FIN_BYTES : RIDER_BYTES];
 	if ((int)blockIdx.x >= md.nb) {
 		const int r = (int)blockIdx.x - md.nb, gxk = KMX_BUCKET / (1024 * RKPT);
@@ -1678,29 +1544,21 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 	int *s_pending = (int *)(s_list + KMX_FIN_RPT(NHM) * 1024);
 	int &s_succ = s_pending[3], &s_count = s_pending[4];
 	const int i = blockIdx.x, lv = s & 1;
-	int n;
-	if (tail) n = tail_file<W, NHM>(md, bd, pp, epoch_b, i, &s_pending[5], &s_pending[6]);     // (tail: s == 0, the records are level 0's)
-	else n = bd.Un[UN_IDX(lv, i, md.nb)];
-	if (n != 0) {
-		const int a = (i + t) % md.nb;
-		constexpr int RPT = KMX_FIN_RPT(NHM);
-		const bool lds_path = n <= KMX_FIN_RANGES * RPT * 1024 && !force_global && md.km_mod.d < KMX_FIN_MAX_POS;
-		if (threadIdx.x == 0) {
-			s_succ = 0;
-			s_pending[0] = 0;
-			atomicMax(bd.stats + ST_MAX_UFIN, (u64)n);
-			if (s == 0) { atomicAdd(bd.stats + ST_CONTENDED, (u64)n); atomicMax(bd.stats + ST_MAX_U0, (u64)n); }
-		}
-		__syncthreads();
-		const bool snap = s == 0 && snapshot_ok(bd, i);
-		if (lds_path) finish_lds_ranges<W, NHM, RPT>(md, bd, pp, i, a, lv, n, snap, s_t1, s_t2, s_list, &s_count, s_pending, &s_succ);
-		else finish_global<W, NHM>(md, bd, pp, i, a, lv, n, snap, epoch_b, epoch0, s_pending, &s_succ);
+	const int n = bd.Un[UN_IDX(lv, i, md.nb)];
+	if (n == 0) return;
+	const int a = (i + t) % md.nb;
+	constexpr int RPT = KMX_FIN_RPT(NHM);
+	const bool lds_path = n <= KMX_FIN_RANGES * RPT * 1024 && !force_global && md.km_mod.d < KMX_FIN_MAX_POS;
+	if (threadIdx.x == 0) {
+		s_succ = 0;
+		s_pending[0] = 0;
+		atomicMax(bd.stats + ST_MAX_UFIN, (u64)n);
+		if (s == 0) { atomicAdd(bd.stats + ST_CONTENDED, (u64)n); atomicMax(bd.stats + ST_MAX_U0, (u64)n); }
 	}
-	if (tail) {
-		drain_vmem();                                                // status bytes, REC_WON flags and failure marks of the finisher are out
-		__syncthreads();
-		tail_reorder<W, NHM>(md, bd, t, pp, i, n, &s_pending[8]);
-	}
+	__syncthreads();
+	const bool snap = s == 0 && snapshot_ok(bd, i);
+	if (lds_path) finish_lds_ranges<W, NHM, RPT>(md, bd, pp, i, a, lv, n, snap, s_t1, s_t2, s_list, &s_count, s_pending, &s_succ);
+	else finish_global<W, NHM>(md, bd, pp, i, a, lv, n, snap, epoch_b, epoch0, s_pending, &s_succ);
 }
 
 // ------------------------------------------------------------------------------------------ R: reorder
@@ -2706,13 +2564,9 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	} else if (md.nh <= 8) hipLaunchKernelGGL((k_round_detect<8, 1024, KMX_CL_TBITS(8)>), dim3(KMX_CL_BINS(8), nb), dim3(1024), 0, st, bd, nb, pp, pending, keep_own, late);
 	else hipLaunchKernelGGL((k_round_detect<16, 1024, KMX_CL_TBITS(16)>), dim3(KMX_CL_BINS(16), nb), dim3(1024), 0, st, bd, nb, pp, pending, keep_own, late);
 	KPROF_END(prof, st);
-	// late rounds without grid-wide passes: file + finisher + reorder in ONE launch (k_slow_finish with `tail`)
-	const int tail = (flags & KMX_ROUND_TAIL) && t >= 2 && nsub == 0 ? 1 : 0;
-	if (!tail) {
-		KPROF_BEGIN(prof, KC_FILE, st);
-		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_file<W, NHM>), dim3(KMX_FILE_WGS, nb), dim3(1024), 0, st, md, bd, pp, eb));
-		KPROF_END(prof, st);
-	}
+	KPROF_BEGIN(prof, KC_FILE, st);
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_file<W, NHM>), dim3(KMX_FILE_WGS, nb), dim3(1024), 0, st, md, bd, pp, eb));
+	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_SLOW, st);
 	const bool legacy0 = flags & KMX_ROUND_RESOLVE_GATHER;      // test hook: the gathering resolve kernel for level 0 too
 	for (int s = 0; s < nsub; s++) {
@@ -2731,14 +2585,12 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 		KmbackJob none = {nullptr, nullptr, 0, 0, 0};
 		const KmbackJob &jb = job && job->n_lists > 0 && kmb ? *job : none;
 		const int riders = jb.n_lists * (int)(KMX_BUCKET / (1024 * KMX_FIN_RIDER_KPT(md.nh <= 8 ? 8 : 16)));   // one workgroup per 2048 (1024) k-mers of the hosted lists
-		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb + riders, 1), dim3(1024), 0, st, md, bd, t, pp, nsub, eb, e0, force_global, jb, kmb ? *kmb : BitScatter(), tail));
+		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_slow_finish<W, NHM>), dim3(nb + riders, 1), dim3(1024), 0, st, md, bd, t, pp, nsub, eb, e0, force_global, jb, kmb ? *kmb : BitScatter()));
 	}
 	KPROF_END(prof, st);
-	if (!tail) {
-		KPROF_BEGIN(prof, KC_REORDER, st);
-		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, nb), dim3(256), 0, st, md, bd, t, pp, nsub & 1));
-		KPROF_END(prof, st);
-	}
+	KPROF_BEGIN(prof, KC_REORDER, st);
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, nb), dim3(256), 0, st, md, bd, t, pp, nsub & 1));
+	KPROF_END(prof, st);
 }
 
 // the commit of round t (parity pp) in a launch of its own: end of the build, or a caller that needs the arrays up to date

@@ -284,7 +284,6 @@ struct kmx_model {
 	// test hooks, read from the environment by kmx_begin: forced pass counts, forced older code
 	// paths (KMX_ROUND_* flags of kmx_types.h), a trace of the pass-count controller
 	int dbg_nsub0 = -1, dbg_nsub1 = -1, dbg_flags = 0;
-	int dbg_tail = 1;                                          // KMX_TAIL=0: the late rounds file and reorder in launches of their own (test hook)
 	int dbg_small_detect = -1;                                 // KMX_SMALL_DETECT=0/1: force the form of the late rounds' k_round_detect (test hook)
 	bool dbg_ctrl = false;
 	u64 h_stats[ST_N] = {0};
@@ -448,7 +447,6 @@ static int create_device_side(kmx_model *m)
 		m->dbg_nsub1 = env_int("KMX_NSUB1", -1);
 		m->dbg_flags = (env_int("KMX_FIN_GLOBAL", 0) ? KMX_ROUND_FIN_GLOBAL : 0) | (env_int("KMX_RESOLVE_GATHER", 0) ? KMX_ROUND_RESOLVE_GATHER : 0);
 		m->dbg_small_detect = env_int("KMX_SMALL_DETECT", -1);
-		m->dbg_tail = env_int("KMX_TAIL", 1);
 		m->dbg_no_defer = env_int("KMX_PIPE", 1) == 0;                      // KMX_PIPE=0: commit after every round, check against the committed state only
 		m->dbg_ctrl = env_int("KMX_CTRL_DEBUG", 0) != 0;
 		m->dbg_kmb_direct = env_int("KMX_KMB_DIRECT", 0) != 0;
@@ -968,7 +966,7 @@ static int run_round(kmx_model *m, int t, bool defer, const KmbackJob *job)
 	// launch-shape heuristic like steer_passes: a bin that does not fit only sends its list down the ordered path, never changes the result)
 	const u64 late_bin = ((volatile u64 *)m->h_feedback)[2];
 	const bool small_detect = m->dbg_small_detect >= 0 ? m->dbg_small_detect != 0 : late_bin <= 2048;
-	const int flags = m->dbg_flags | (m->pending ? KMX_ROUND_PENDING : 0) | (defer ? KMX_ROUND_KEEP : 0) | (small_detect ? KMX_ROUND_SMALL_DETECT : 0) | (m->dbg_tail ? KMX_ROUND_TAIL : 0);
+	const int flags = m->dbg_flags | (m->pending ? KMX_ROUND_PENDING : 0) | (defer ? KMX_ROUND_KEEP : 0) | (small_detect ? KMX_ROUND_SMALL_DETECT : 0);
 	kmxk::round(m->md, m->bd, t, m->pp, passes_of_round(m, t), &m->epoch, flags, m->stream, &m->prof, job, &m->kmb);
 	m->pending = true; m->pending_t = t;
 	m->pp ^= 1;

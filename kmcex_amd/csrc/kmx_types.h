@@ -88,8 +88,7 @@ enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, 
 enum { KMX_ROUND_FIN_GLOBAL = 1, KMX_ROUND_RESOLVE_GATHER = 2,     // test hooks of kmxk::round (older code paths)
        KMX_ROUND_PENDING = 4,                                        // the previous round's winners are not committed yet: their commit rides with this round's check
        KMX_ROUND_KEEP = 8,
-       KMX_ROUND_SMALL_DETECT = 16,
-       KMX_ROUND_TAIL = 32 };                                       // rounds t >= 2 without grid-wide passes: file + finisher + reorder in one launch                               // rounds t >= 2: k_round_detect with small tables (their bins hold a few hundred tuples)                                         // this round's winners will be committed beside the next round's check (its detect re-reads the claims)
+       KMX_ROUND_SMALL_DETECT = 16 };                               // rounds t >= 2: k_round_detect with small tables (their bins hold a few hundred tuples)                                         // this round's winners will be committed beside the next round's check (its detect re-reads the claims)
 #define KMX_NSLOW 2                            // contended-record levels, ping-pong: pass s reads level s&1, defers to (s+1)&1
 #define KMX_MAX_NSUB 16                        // most grid-wide ordered passes per round
 #define KMX_CTR_STRIDE 32                      // ints between per-list counters: one 128-byte line each (same-line atomics serialise)

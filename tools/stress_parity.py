@@ -14,8 +14,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
 HOOKS = [dict(), dict(KMX_NSUB0="0", KMX_NSUB1="0"), dict(KMX_NSUB0="1", KMX_NSUB1="1"), dict(KMX_NSUB0="3", KMX_NSUB1="2"),
          dict(KMX_FIN_GLOBAL="1"), dict(KMX_NSUB0="2", KMX_RESOLVE_GATHER="1"), dict(KMX_KMB_DIRECT="1"), dict(KMX_KMB_DIRECT="1", KMX_NSUB0="1"),
          dict(KMX_PIPE="0"), dict(KMX_PIPE="8"), dict(KMX_PIPE="3", KMX_NSUB0="1", KMX_NSUB1="1"), dict(KMX_PIPE="0", KMX_FIN_GLOBAL="1"), dict(KMX_KMB_HOST="0"), dict(KMX_KMB_HOST="0", KMX_PIPE="0"),
-         dict(KMX_SMALL_DETECT="1"), dict(KMX_SMALL_DETECT="0"), dict(KMX_SMALL_DETECT="1", KMX_NSUB0="1", KMX_NSUB1="1"), dict(KMX_SMALL_DETECT="1", KMX_PIPE="0"),
-         dict(KMX_TAIL="0"), dict(KMX_TAIL="0", KMX_SMALL_DETECT="0"), dict(KMX_TAIL="1", KMX_NSUB0="0", KMX_NSUB1="0"), dict(KMX_TAIL="1", KMX_FIN_GLOBAL="1", KMX_NSUB1="0"), dict(KMX_TAIL="1", KMX_PIPE="0", KMX_NSUB1="0")]   # the big rounds unpipelined / list by list / in 3 groups; km_back emission in launches of its own
+         dict(KMX_SMALL_DETECT="1"), dict(KMX_SMALL_DETECT="0"), dict(KMX_SMALL_DETECT="1", KMX_NSUB0="1", KMX_NSUB1="1"), dict(KMX_SMALL_DETECT="1", KMX_PIPE="0")]   # the big rounds unpipelined / list by list / in 3 groups; km_back emission in launches of its own
 SIZES = [600000, 1500000, 3000000, 5000000] if "big" in sys.argv else ([40, 300, 3000, 12000, 30000] if "small" in sys.argv else [40, 300, 3000, 30000, 120000, 300000, 700000])   # big: several blocks, final partial block
 t0 = time.time(); done = 0; contended = 0
 while time.time() - t0 < budget:
@@ -33,7 +32,7 @@ while time.time() - t0 < budget:
     o.build(k, km, cnt); so = o.stats()
     g1 = int(rng.integers(1, nh + 1)); g2 = int(rng.integers(g1, nh + 1))       # groups the check fetches its positions in (forced path only)
     for env in [dict(HOOKS[int(rng.integers(0, len(HOOKS)))], KMX_NH_FIRST=str(g1), KMX_NH_SECOND=str(g2)), HOOKS[0]]:
-        for v in ("KMX_NSUB0", "KMX_NSUB1", "KMX_FIN_GLOBAL", "KMX_RESOLVE_GATHER", "KMX_KMB_DIRECT", "KMX_PIPE", "KMX_KMB_HOST", "KMX_NH_FIRST", "KMX_NH_SECOND", "KMX_SMALL_DETECT", "KMX_TAIL"): os.environ.pop(v, None)
+        for v in ("KMX_NSUB0", "KMX_NSUB1", "KMX_FIN_GLOBAL", "KMX_RESOLVE_GATHER", "KMX_KMB_DIRECT", "KMX_PIPE", "KMX_KMB_HOST", "KMX_NH_FIRST", "KMX_NH_SECOND", "KMX_SMALL_DETECT"): os.environ.pop(v, None)
         os.environ.update(env)
         m = KModel(ci, cs, nh, nb); m.build_packed(k, km, cnt); st = m.stats()
         tag = (k, ci, cs, nh, nb, n, seed, env)
