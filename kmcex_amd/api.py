@@ -129,22 +129,29 @@ def load_library():
     L.kmx_shard_local.argtypes = [vp, C.POINTER(Stats), C.POINTER(vp), C.POINTER(vp)]
     L.kmx_shard_complete.argtypes = [vp, vp, vp, u64, C.POINTER(Stats)]
     L.kmx_dev_view.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(u64)]
-    L.kmx_create_on.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
-    L.kmx_build_from_kmc_multi.argtypes = [C.POINTER(vp), i32, C.c_char_p]
-    L.kmx_range_begin.argtypes = [vp, i32, C.POINTER(u64), u64, i32, i32]
-    L.kmx_range_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
-    L.kmx_range_emit_dev.argtypes = [vp, i32, C.POINTER(RingList), i32, C.POINTER(u64)]
-    L.kmx_range_verdict_dev.argtypes = [vp, i32, vp, u64, vp]
-    L.kmx_range_resolve_dev.argtypes = [vp, i32, vp, C.POINTER(u64)]
-    L.kmx_range_commit_dev.argtypes = [vp, i32, vp, u64]
+    _sig(L, "kmx_create_on", [i32, i32, i32, i32, i32, C.POINTER(vp)])
+    _sig(L, "kmx_build_from_kmc_multi", [C.POINTER(vp), i32, C.c_char_p])
+    _sig(L, "kmx_range_begin", [vp, i32, C.POINTER(u64), u64, i32, i32])
+    _sig(L, "kmx_range_buffers", [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)])
+    _sig(L, "kmx_range_emit_dev", [vp, i32, C.POINTER(RingList), i32, C.POINTER(u64)])
+    _sig(L, "kmx_range_verdict_dev", [vp, i32, vp, u64, vp])
+    _sig(L, "kmx_range_resolve_dev", [vp, i32, vp, C.POINTER(u64)])
+    _sig(L, "kmx_range_commit_dev", [vp, i32, vp, u64])
     L.kmx_or_words_dev.argtypes = [vp, vp, vp, u64]
-    L.kmx_debug_pack_strings.argtypes = [vp, vp, i32, i32, u64, vp, C.POINTER(i32)]
-    L.kmx_kernel_classes.argtypes = []
-    L.kmx_abi_version.argtypes = []
+    _sig(L, "kmx_debug_pack_strings", [vp, vp, i32, i32, u64, vp, C.POINTER(i32)])
+    _sig(L, "kmx_kernel_classes", [])
+    _sig(L, "kmx_abi_version", [])
     L.kmx_set_profile.argtypes = [vp, i32]
     L.kmx_get_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), i32]
     _lib = L
     return L
+
+
+def _sig(L, name, argtypes):
+    """argtypes of an entry point a variant library (KMX_LIBRARY: an earlier round's build, for same-box comparisons) may lack"""
+    f = getattr(L, name, None)
+    if f is not None:
+        f.argtypes = argtypes
 
 
 def _chk(rc: int):
