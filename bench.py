@@ -371,6 +371,7 @@ def main():
         for _ in range(a.steps):
             query_step()
         kt = m.kernel_times(reset=True)
+        stp = m.stats()                                                  # the issue counters are collected by the profiled build only
         m.set_profile(False)
         A, S, nbf = st.attempts, st.successes, sum(st.n_bf)
         W8 = 8 * ((a.k + 31) // 32) + 4
@@ -419,10 +420,10 @@ def main():
         if dom == "commit_check":
             # what the fused launches actually ISSUED (device counters): the staged fetch stops at the first conflicting group and a
             # winner sets only the positions it saw untagged -- priced like the formula at G bytes per random operation
-            issued = (st.piped_gathers + st.piped_atomics) * G + Ap * W8
+            issued = (stp.piped_gathers + stp.piped_atomics) * G + Ap * W8
             roof["issued_frac"] = issued / (dv["seconds"] / a.steps) / 8e12
-            roof["issued"] = {"gathers_per_step": st.piped_gathers, "atomics_per_step": st.piped_atomics,
-                              "random_ops_per_s": (st.piped_gathers + 2 * st.piped_atomics) / (dv["seconds"] / a.steps),
+            roof["issued"] = {"gathers_per_step": stp.piped_gathers, "atomics_per_step": stp.piped_atomics,
+                              "random_ops_per_s": (stp.piped_gathers + 2 * stp.piped_atomics) / (dv["seconds"] / a.steps),
                               "note": "random_ops_per_s counts an atomic as a read and a write at the DRAM (DESIGN.md 4: one budget of ~56 G/s)"}
         # the random-access ceiling of this chip for 8-byte touches over a footprint like the coupled arrays'
         foot = max(int(st.km_byte_size) * 2 * a.nb, 1 << 26)              # the cells of all arrays (4 bytes per 16 positions)

@@ -577,7 +577,9 @@ template <int NHM> __device__ __forceinline__ u32 crec_nib(const CRec<NHM> &r, i
 // (bx of gx workgroups work on list i: the kernels below map their grids onto these bodies)
 // LDS of one check_emit workgroup, carved out of a byte pool the kernel owns (kernels that run one of several bodies per workgroup)
 #define CHECK_LDS_BYTES(NHM) (256 * (NHM) * 8 + (3 * KMX_CL_BINS(NHM) + 8) * 4)
-template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const ModelDev &md, const BlockDev &bd, int t, int pp, int i, int bx, int gx, unsigned char *lds, int stat_slot)
+// COUNT: also count the random loads the launch issues (ST_PIPE_GATHERS) -- only the profiled leg of bench.py asks for it:
+// the three ballots per wave and the live `stages` cost the fused launches 8 % (same-box A/B, profiles/r04_*).
+template <int W, int NHM, bool COUNT = false> __device__ __forceinline__ void check_emit_body(const ModelDev &md, const BlockDev &bd, int t, int pp, int i, int bx, int gx, unsigned char *lds, int stat_slot)
 {
 	constexpr int NBIN = KMX_CL_BINS(NHM);
 	u64 *s_tup = (u64 *)lds;                                         // [256 * NHM]
@@ -591,7 +593,7 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 		if (stat_slot && n) atomicAdd(bd.stats + stat_slot, (u64)n);   // accounting: attempts examined inside fused launches
 		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, md.nb)] = 0;   // k_round_file files this round's records
 	}
-	if (threadIdx.x == 0) s_gath = 0;                                // (the loop's first barrier orders this)
+	if (COUNT && threadIdx.x == 0) s_gath = 0;                       // (the loop's first barrier orders this)
 	constexpr int CAP = KMX_CL_CAP_OF(NHM);
 	u64 *tup = bd.cl_tup[pp] + (u64)i * NBIN * CAP;
 	int *gcnt = bd.cl_cnt[pp] + i * KMX_CL_MAXBINS;
@@ -633,7 +635,7 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 		// survivors are counted per 1024-slot tile as they fail, so the reorder needs no counting pass
 		const u64 mask = __ballot(failed);
 		if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&s_fail, (int)__popcll(mask));
-		if (stat_slot) {                                                 // random 4-byte loads this wave issued (the staged fetch stops early)
+		if (COUNT && stat_slot) {                                        // random 4-byte loads this wave issued (the staged fetch stops early)
 			const int g1 = (int)__popcll(__ballot(stages >= 1)), g2 = (int)__popcll(__ballot(stages >= 2)), g3 = (int)__popcll(__ballot(stages >= 3));
 			if ((threadIdx.x & 63) == 0 && g1) atomicAdd(&s_gath, g1 * md.nh_first + g2 * (md.nh_second - md.nh_first) + g3 * (md.nh - md.nh_second));
 		}
@@ -668,7 +670,7 @@ template <int W, int NHM> __device__ __forceinline__ void check_emit_body(const 
 		}
 		__syncthreads();
 	}
-	if (stat_slot && threadIdx.x == 0 && s_gath) atomicAdd(bd.stats + ST_PIPE_GATHERS, (u64)s_gath);
+	if (COUNT && stat_slot && threadIdx.x == 0 && s_gath) atomicAdd(bd.stats + ST_PIPE_GATHERS, (u64)s_gath);
 }
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_check_emit(ModelDev md, BlockDev bd, int t, int pp)
 {
@@ -933,7 +935,7 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_round_file(M
 // wanted values): no k-mer, no hash, no second look at the cells.  Deferred by one round: the commit of round r rides with
 // the check of round r+1 (k_round_commit_check), whose detect treats these positions as settled.
 // (a = the array list i visited in the round being committed; pp = that round's parity)
-template <int NHM> __device__ __forceinline__ void commit_body(const ModelDev &md, const BlockDev &bd, int a, int pp, int i, int bx, int gx, unsigned char *lds, int stat_slot)
+template <int NHM, bool COUNT = false> __device__ __forceinline__ void commit_body(const ModelDev &md, const BlockDev &bd, int a, int pp, int i, int bx, int gx, unsigned char *lds, int stat_slot)
 {
 	int &s_cnt = ((int *)lds)[0], &s_atom = ((int *)lds)[1];
 	const int n = bd.n[pp][i];
@@ -959,17 +961,19 @@ template <int NHM> __device__ __forceinline__ void commit_body(const ModelDev &m
 		}
 		if (stat_slot) {
 			const u64 wm = __ballot(win);
-			if (wm) {                                                    // (uniform per wave) atomics this wave issued: one per untagged position of a winner
+			if (wm) {                                                    // (uniform per wave)
 				int at = 0;
+				if (COUNT) {                                             // atomics this wave issued: one per untagged position of a winner
 #pragma unroll
-				for (int j = 0; j < NHM; j++) at += (int)__popcll(__ballot((um >> j) & 1u));
-				if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt, (int)__popcll(wm)); atomicAdd(&s_atom, at); }
+					for (int j = 0; j < NHM; j++) at += (int)__popcll(__ballot((um >> j) & 1u));
+				}
+				if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt, (int)__popcll(wm)); if (COUNT) atomicAdd(&s_atom, at); }
 			}
 		}
 	}
 	if (stat_slot) {
 		__syncthreads();
-		if (threadIdx.x == 0 && s_cnt) { atomicAdd(bd.stats + stat_slot, (u64)s_cnt); atomicAdd(bd.stats + ST_PIPE_ATOMICS, (u64)s_atom); }
+		if (threadIdx.x == 0 && s_cnt) { atomicAdd(bd.stats + stat_slot, (u64)s_cnt); if (COUNT) atomicAdd(bd.stats + ST_PIPE_ATOMICS, (u64)s_atom); }
 	}
 }
 // commit of the round with parity pp, whose list i visited array (i + t) % nb
@@ -991,13 +995,13 @@ template <int NHM> __global__ __launch_bounds__(256) void k_round_commit(ModelDe
 // tail of atomics.
 // gk / gc workgroups per list check / commit (powers of two; the committed lists are about twice as long as the checked
 // ones -- or, across a block boundary, 16 times shorter -- and every workgroup that is launched costs dispatch time).
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_round_commit_check(ModelDev md, BlockDev bd, int t, int pp, int gk, int gc)
+template <int W, int NHM, bool COUNT> __global__ __launch_bounds__(256) void k_round_commit_check(ModelDev md, BlockDev bd, int t, int pp, int gk, int gc)
 {
 	__shared__ __align__(16) unsigned char lds[CHECK_LDS_BYTES(NHM)];
 	const int nb = md.nb, G = gk < gc ? gk : gc, rk = gk / G, rc = gc / G, per = nb * (rk + rc);
 	const int p = (int)blockIdx.x / per, r = (int)blockIdx.x % per, l = r % nb, s = r / nb;
-	if (s < rk) check_emit_body<W, NHM>(md, bd, t, pp, l, p * rk + s, gk, lds, ST_PIPE_ATTEMPTS);
-	else commit_body<NHM>(md, bd, (l + t + nb - 1) % nb, pp ^ 1, l, p * rc + (s - rk), gc, lds, ST_PIPE_SUCC);
+	if (s < rk) check_emit_body<W, NHM, COUNT>(md, bd, t, pp, l, p * rk + s, gk, lds, ST_PIPE_ATTEMPTS);
+	else commit_body<NHM, COUNT>(md, bd, (l + t + nb - 1) % nb, pp ^ 1, l, p * rc + (s - rk), gc, lds, ST_PIPE_SUCC);
 }
 
 // ------------------------------------------------------------------------------------------ S: ordered slow path
@@ -2548,7 +2552,8 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	if (pending) {
 		KPROF_BEGIN(prof, KC_COMMIT_CHECK, st);
 		const int gc = round_gx(t > 0 ? t - 1 : nb - 1);
-		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit_check<W, NHM>), dim3(nb * (gx + gc), 1), blk, 0, st, md, bd, t, pp, gx, gc));
+		if (prof && prof->on) DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit_check<W, NHM, true>), dim3(nb * (gx + gc), 1), blk, 0, st, md, bd, t, pp, gx, gc));   // + the issue counters
+		else DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit_check<W, NHM, false>), dim3(nb * (gx + gc), 1), blk, 0, st, md, bd, t, pp, gx, gc));
 		KPROF_END(prof, st);
 	} else {
 		KPROF_BEGIN(prof, KC_CHECK_CLAIM, st);
