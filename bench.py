@@ -371,11 +371,14 @@ def main():
         for _ in range(a.steps):
             query_step()
         kt = m.kernel_times(reset=True)
-        stp = m.stats()                                                  # the issue counters are collected by the profiled build only
+        m.set_profile(2)                                                 # one more build with the fused launches' accounting variant (never timed:
+        insert_step()                                                    # its counters cost the kernel 8 %): what they examined, committed, issued
+        torch.cuda.synchronize()
+        stp = m.stats()
         m.set_profile(False)
         A, S, nbf = st.attempts, st.successes, sum(st.n_bf)
         W8 = 8 * ((a.k + 31) // 32) + 4
-        Ap, Sp = st.piped_attempts, st.piped_commits                     # the part of A and S handled inside the fused commit|check launches of the big rounds
+        Ap, Sp = stp.piped_attempts, stp.piped_commits                   # the part of A and S handled inside the fused commit|check launches
         alg = {  # algorithmic bytes of ONE step per kernel class (SURVEY.md §8d formula, split by kernel)
             "check": G * (A - Ap) * a.nh + (A - Ap) * W8,                # reads: every attempt looks at its nh positions
             "commit": G * max(st.fast_commits - Sp, 0) * a.nh,           # write-backs in launches of their own (km_back's 2*S*(nh-2) term is k_kmback_emit + k_bs_apply now)

@@ -52,7 +52,7 @@ typedef struct kmx_stats {
 	int32_t  device, reserved;
 	uint64_t rest_bytes;      /* KRestData::get_all_byte_size (rest.hpp:257-259)                */
 	uint64_t piped_attempts;  /* attempts examined / successes committed inside the fused commit|check launches   */
-	uint64_t piped_commits;   /* of the big rounds (accounting for the per-kernel roofline only)                   */
+	uint64_t piped_commits;   /* (accounting for the per-kernel roofline: collected only by builds under kmx_set_profile(m, 2)) */
 	uint64_t piped_gathers;   /* random 4-byte loads / 32-bit atomic ORs those launches actually ISSUED: the check     */
 	uint64_t piped_atomics;   /* stops at the first conflicting group, a winner sets only its untagged positions      */
 } kmx_stats;
@@ -209,6 +209,9 @@ int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double
  * must size both arrays with the macro of the header it was compiled against and check kmx_kernel_classes() == it.  */
 #define KMX_KERNEL_CLASSES 10
 int kmx_kernel_classes(void);           /* what this library writes: KMX_KERNEL_CLASSES of ITS header */
+/* on = 1: time the kernel classes of the next builds / queries; on = 2: no timing, but the fused launches of the next builds
+ * run their ACCOUNTING variant (kmx_stats piped_*: what they examined, committed and issued) -- it is slower than the
+ * product's kernel, so it is never the one that is timed; 0: neither                                                    */
 int kmx_set_profile(kmx_model *m, int on);
 int kmx_get_kernel_times(kmx_model *m, double *seconds, uint64_t *launches, int reset);
 

@@ -436,7 +436,8 @@ class KModel:
 
     KERNEL_CLASSES = ["classify", "check", "commit", "slow_path", "reorder", "rest_append", "query", "detect", "commit_check", "file"]
 
-    def set_profile(self, on: bool) -> None:
+    def set_profile(self, on) -> None:
+        """True / 1: time the kernel classes; 2: the next builds run the fused launches' accounting variant (stats().piped_*)"""
         _chk(self.L.kmx_set_profile(self.h, int(on)))
 
     def kernel_times(self, reset: bool = True) -> dict:

@@ -590,7 +590,7 @@ template <int W, int NHM, bool COUNT = false> __device__ __forceinline__ void ch
 	const int a = (i + t) % md.nb;                                  // kmodel.hpp:563
 	if (bx == 0 && threadIdx.x == 0) {
 		if (n) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
-		if (stat_slot && n) atomicAdd(bd.stats + stat_slot, (u64)n);   // accounting: attempts examined inside fused launches
+		if (COUNT && stat_slot && n) atomicAdd(bd.stats + stat_slot, (u64)n);   // accounting: attempts examined inside fused launches
 		for (int s = 0; s < KMX_NSLOW; s++) bd.Un[UN_IDX(s, i, md.nb)] = 0;   // k_round_file files this round's records
 	}
 	if (COUNT && threadIdx.x == 0) s_gath = 0;                       // (the loop's first barrier orders this)
@@ -942,8 +942,8 @@ template <int NHM, bool COUNT = false> __device__ __forceinline__ void commit_bo
 	const u64 row = (u64)i * KMX_BUCKET;
 	cell_t *cells = md.cells[a];
 	const unsigned char *status = bd.status[pp] + row;
-	if (stat_slot && threadIdx.x == 0) { s_cnt = 0; s_atom = 0; }
-	if (stat_slot) __syncthreads();
+	if (COUNT && stat_slot && threadIdx.x == 0) { s_cnt = 0; s_atom = 0; }
+	if (COUNT && stat_slot) __syncthreads();
 	for (int base = bx * 256; base < n; base += gx * 256) {
 		const int x = base + threadIdx.x;
 		const bool win = x < n && status[x] == SLOT_UNDECIDED;
@@ -959,21 +959,19 @@ template <int NHM, bool COUNT = false> __device__ __forceinline__ void commit_bo
 					atomicOr(cells + crec_cell<NHM>(rec, j), CELL_TAG(b) | (((want >> j) & 1u) ? CELL_VAL(b) : 0u));
 				}
 		}
-		if (stat_slot) {
+		if (COUNT && stat_slot) {
 			const u64 wm = __ballot(win);
-			if (wm) {                                                    // (uniform per wave)
+			if (wm) {                                                    // (uniform per wave) winners; atomics issued: one per untagged position of a winner
 				int at = 0;
-				if (COUNT) {                                             // atomics this wave issued: one per untagged position of a winner
 #pragma unroll
-					for (int j = 0; j < NHM; j++) at += (int)__popcll(__ballot((um >> j) & 1u));
-				}
-				if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt, (int)__popcll(wm)); if (COUNT) atomicAdd(&s_atom, at); }
+				for (int j = 0; j < NHM; j++) at += (int)__popcll(__ballot((um >> j) & 1u));
+				if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt, (int)__popcll(wm)); atomicAdd(&s_atom, at); }
 			}
 		}
 	}
-	if (stat_slot) {
+	if (COUNT && stat_slot) {
 		__syncthreads();
-		if (threadIdx.x == 0 && s_cnt) { atomicAdd(bd.stats + stat_slot, (u64)s_cnt); if (COUNT) atomicAdd(bd.stats + ST_PIPE_ATOMICS, (u64)s_atom); }
+		if (threadIdx.x == 0 && s_cnt) { atomicAdd(bd.stats + stat_slot, (u64)s_cnt); atomicAdd(bd.stats + ST_PIPE_ATOMICS, (u64)s_atom); }
 	}
 }
 // commit of the round with parity pp, whose list i visited array (i + t) % nb
@@ -2552,7 +2550,7 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	if (pending) {
 		KPROF_BEGIN(prof, KC_COMMIT_CHECK, st);
 		const int gc = round_gx(t > 0 ? t - 1 : nb - 1);
-		if (prof && prof->on) DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit_check<W, NHM, true>), dim3(nb * (gx + gc), 1), blk, 0, st, md, bd, t, pp, gx, gc));   // + the issue counters
+		if (prof && prof->count) DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit_check<W, NHM, true>), dim3(nb * (gx + gc), 1), blk, 0, st, md, bd, t, pp, gx, gc));   // + the issue counters
 		else DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_commit_check<W, NHM, false>), dim3(nb * (gx + gc), 1), blk, 0, st, md, bd, t, pp, gx, gc));
 		KPROF_END(prof, st);
 	} else {

@@ -2854,7 +2854,8 @@ static int kmx_microbench_impl(int mode, uint64_t bytes, uint64_t touches, int i
 static int kmx_set_profile_impl(kmx_model *m, int on)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
-	m->prof.on = on != 0;
+	m->prof.on = on == 1;                                         // 1: per-class timing of the product's kernels
+	m->prof.count = on == 2;                                      // 2: no timing; the fused launches run their accounting variant (kmx_stats piped_*)
 	return KMX_OK;
 }
 

@@ -187,7 +187,9 @@ enum { SLOT_UNDECIDED = 0, SLOT_FAILED = 1, SLOT_INSERTED = 2, SLOT_CONTENDED = 
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
 enum { KC_CLASSIFY = 0, KC_CHECK_CLAIM, KC_VERIFY_COMMIT, KC_SLOW, KC_REORDER, KC_REST, KC_QUERY, KC_DETECT, KC_COMMIT_CHECK, KC_FILE, KC_N };   // CHECK_CLAIM = check + emit, VERIFY_COMMIT = commit
 struct KernelProf {
-	bool on = false;
+	bool on = false;             // HIP events around every launch of a kernel class
+	bool count = false;          // the fused launches also count what they examine, commit and issue (the ST_PIPE_* statistics): their
+	                             // accounting variant is slower than the product's, so it is never the one that is timed
 	void *events = nullptr;      // std::vector<hipEvent_t>* owned by the host side
 	void *spans = nullptr;       // std::vector<int>* : class of span i uses events 2i, 2i+1
 	void (*begin)(KernelProf *, int cls, hipStream_t) = nullptr;
