@@ -7,8 +7,10 @@ rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(("void
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
 starts = [i for i, r in enumerate(rows) if name(r) == "k_histogram"]
-st = starts[-1]
-en = next((i for i in range(st + 1, len(rows)) if name(rows[i]) in ("k_query", "k_histogram")), len(rows))
+ends = [next((i for i in range(st + 1, len(rows)) if name(rows[i]) in ("k_query", "k_histogram")), len(rows)) for st in starts]
+# the last build made of the PRODUCT's kernels (bench.py's last build runs the fused launches' accounting variant, <..., true>)
+pick = [j for j in range(len(starts)) if not any(", true>" in r["Kernel_Name"] for r in rows[starts[j]:ends[j]])]
+st, en = (starts[pick[-1]], ends[pick[-1]]) if pick else (starts[-1], ends[-1])
 b = rows[st:en]
 span = (int(b[-1]["End_Timestamp"]) - int(b[0]["Start_Timestamp"])) / 1e3
 busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in b) / 1e3
