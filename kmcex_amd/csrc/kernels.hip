@@ -236,32 +236,6 @@ __global__ __launch_bounds__(256) void k_histogram(const u32 *counts, u64 n, int
 
 // block-wide exclusive scan of one int per thread over the first 256 threads (the other threads of a larger workgroup
 // only take part in the barriers and get the total)
-// workgroup barrier for LDS-only hand-offs: __syncthreads() would also wait for every outstanding global store and
-// atomic of the wave (status bytes, commit records, claim tuples: 2-4 us each time under load)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// block_excl_scan_256 whose two barriers only order LDS (the check's claim staging: nothing in global memory is handed over)
-__device__ __forceinline__ int block_excl_scan_256_lds(int v, int *s_tmp, int *total)
-{
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	int incl = v;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		int t = __shfl_up(incl, d, 64);
-		if (lane >= d) incl += t;
-	}
-	if (lane == 63 && wave < 4) s_tmp[wave] = incl;
-	lds_barrier();
-	int wbase = 0, tot = 0;
-#pragma unroll
-	for (int w = 0; w < 4; w++) {
-		int c = s_tmp[w];
-		if (w < wave) wbase += c;
-		tot += c;
-	}
-	lds_barrier();
-	if (total) *total = tot;
-	return wbase + incl - v;
-}
 __device__ __forceinline__ int block_excl_scan_256(int v, int *s_tmp, int *total)
 {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -628,8 +602,8 @@ template <int W, int NHM, bool COUNT = false> __device__ __forceinline__ void ch
 	for (int base = bx * 256; base < n; base += gx * 256) {
 		if (threadIdx.x == 0) s_fail = 0;
 		if (threadIdx.x < NBIN) s_cnt[threadIdx.x] = 0;
-		lds_barrier();                                               // (every barrier of this loop hands over LDS only: the global stores of an
-		const int x = base + threadIdx.x;                              //  iteration -- status, uw, commit record, tuples -- are read by LATER launches)
+		__syncthreads();
+		const int x = base + threadIdx.x;
 		bool failed = false;
 		u32 um = 0, bin = 0;
 		int rank[NHM], stages = 0;
@@ -665,21 +639,19 @@ template <int W, int NHM, bool COUNT = false> __device__ __forceinline__ void ch
 			const int g1 = (int)__popcll(__ballot(stages >= 1)), g2 = (int)__popcll(__ballot(stages >= 2)), g3 = (int)__popcll(__ballot(stages >= 3));
 			if ((threadIdx.x & 63) == 0 && g1) atomicAdd(&s_gath, g1 * md.nh_first + g2 * (md.nh_second - md.nh_first) + g3 * (md.nh - md.nh_second));
 		}
-		lds_barrier();
+		__syncthreads();
 		if (threadIdx.x == 0 && s_fail) atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (base >> 10), s_fail);
-		// one run per bin: its place in the bin (ONE global atomic per run, issued first: its round trip runs under the scan)
-		// and its offset in the LDS staging area (scan)
+		// one run per bin: its offset in the LDS staging area (scan) and its place in the bin (ONE global atomic per run)
 		int total;
 		{
 			const int c = threadIdx.x < NBIN ? s_cnt[threadIdx.x] : 0;
-			const int gbase = (threadIdx.x < NBIN && c) ? atomicAdd(gcnt + threadIdx.x, c) : 0;
-			const int ex = block_excl_scan_256_lds(c, s_tmp, &total);
+			const int ex = block_excl_scan_256(c, s_tmp, &total);
 			if (threadIdx.x < NBIN) {
 				s_off[threadIdx.x] = ex;
-				s_base[threadIdx.x] = gbase;
+				s_base[threadIdx.x] = c ? atomicAdd(gcnt + threadIdx.x, c) : 0;
 			}
 		}
-		lds_barrier();
+		__syncthreads();
 		if (um) {
 #pragma unroll
 			for (int j = 0; j < NHM; j++)
@@ -688,7 +660,7 @@ template <int W, int NHM, bool COUNT = false> __device__ __forceinline__ void ch
 					s_tup[s_off[cl_bin(mx)] + rank[j]] = CL_TUPLE(mx, (bin >> j) & 1u, x);
 				}
 		}
-		lds_barrier();
+		__syncthreads();
 		for (int q = threadIdx.x; q < total; q += 256) {               // consecutive lanes, consecutive tuples of a run
 			const u64 tp = s_tup[q];
 			const u32 b = cl_bin(CL_MIXED(tp));
@@ -696,7 +668,7 @@ template <int W, int NHM, bool COUNT = false> __device__ __forceinline__ void ch
 			if (g < CAP) tup[(u64)b * CAP + g] = tp;
 			else bd.cl_ovf[i] = 1;                                     // the whole list takes the ordered path this round
 		}
-		lds_barrier();
+		__syncthreads();
 	}
 	if (COUNT && stat_slot && threadIdx.x == 0 && s_gath) atomicAdd(bd.stats + ST_PIPE_GATHERS, (u64)s_gath);
 }
@@ -1200,6 +1172,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_slow_resolve0
 #define FIN_MARK 0x80000000u
 // workgroup barrier for LDS-only hand-offs: __syncthreads() would also wait for every outstanding global store and
 // atomic of the wave (status bytes, failure counters), 2-4 us each time
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ u32 fin_ident(u64 q) { return (u32)(q >> KMX_FIN_LOG2) & 0x3FFFFFu; }        // tag13 | hi9 << 13
 __device__ __forceinline__ u32 fin_key(u32 x, u64 q) { return ((0x3FFFFu - x) << 13) | ((u32)(q >> KMX_FIN_LOG2) & 0x1FFFu); }
 __device__ __forceinline__ u32 fin_slot1(u64 q) { return (u32)q & (KMX_FIN_T - 1); }
