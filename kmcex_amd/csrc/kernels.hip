@@ -28,7 +28,6 @@
 //   the km_back emission of the previous block as extra workgroups.
 #include "kmx_types.h"
 #include <cstdlib>
-#include <cstring>
 
 __constant__ u32 c_seeds[128] = {   // tools.hpp:9 -- 128 consecutive primes (data)
 	46757, 46769, 46771, 46807, 46811, 46817, 46819, 46829, 46831, 46853, 46861, 46867, 46877, 46889, 46901, 46919,
@@ -1572,13 +1571,10 @@ template <int W, int NHM> __global__ __launch_bounds__(1024) void k_slow_finish(
 // Also closes the round's books: successes = n - m.
 // Before that, it applies what the finisher decided but left undone (REC_WON records of level lv): tag/value bits
 // (kmodel.hpp:611-618, every position: an already tagged one carries the same value) and the km_back insert (:548-550).
-// ro.on (the last round of a block of the single-GPU build): the survivors go to the rest table from here (k_rest_append's
-// work: k-mer, count, survivor flag, slot 0 of the NEW list remembered for quirk Q1, the block's contention figures).
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(ModelDev md, BlockDev bd, int t, int pp, int lv, RestOut ro)
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(ModelDev md, BlockDev bd, int t, int pp, int lv)
 {
 	__shared__ int s_tmp[4];
 	__shared__ int s_m, s_off;
-	__shared__ unsigned long long s_rbase;
 	const int nb = md.nb;
 	const int i = blockIdx.y, tile = blockIdx.x;
 	const int n = bd.n[pp][i];
@@ -1622,10 +1618,6 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 		f[q] = (x < n && bd.status[pp][row + x] == SLOT_FAILED) ? 1 : 0;
 		c += f[q];
 	}
-	if (ro.on && threadIdx.x == 0) {                                 // ONE reservation per tile for its survivors (the scan's barriers publish it)
-		const int tc = bd.tile_cnt[pp][i * KMX_NTILES + tile];
-		s_rbase = tc ? atomicAdd(ro.n, (unsigned long long)tc) : 0ULL;
-	}
 	int before = block_excl_scan_256(c, s_tmp, nullptr) + s_off;
 	const u32 *oldl = bd.list[pp] + row;
 	u32 *newl = bd.list[pp ^ 1] + row;
@@ -1636,19 +1628,6 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 		if (x < n) {
 			if (x < m) newl[x] = f[q] ? oldl[x] : (LIST_HOLE | (u32)(x - before));     // hole number x-before, left to right
 			else if (f[q]) mv[m - before - 1] = oldl[x];                                // survivor number m-before-1 from the right
-			if (ro.on && f[q]) {                                                        // kmodel.hpp:567-571
-				const u32 idx = oldl[x];
-				u64 v[W];
-				load_kmer<W>(bd.kmers, row + idx, v);
-				const int cnt = (int)bd.counts[row + idx];
-				const u64 p = s_rbase + (u64)(before - s_off);
-				store_kmer<W>(ro.kmers, p, v);
-				ro.counts[p] = cnt;
-				bd.surv[row + idx] = 1;
-				// slot 0 of the NEW list (Q1): the survivor that stays there, or -- slot 0 a hole -- the one that fills it first:
-				// survivor number 0 from the right, the last failed slot of the list
-				if (x == 0 || (x >= m && before == m - 1 && bd.status[pp][row] != SLOT_FAILED)) { store_kmer<W>(ro.stale_kmers, (u64)i, v); ro.stale_counts[i] = cnt; }
-			}
 		}
 		before += f[q];
 	}
@@ -1657,11 +1636,6 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_reorder(Model
 		bd.cl_ovf[i] = 0;
 		if (n > m) atomicAdd(bd.stats + ST_SUCCESSES, (u64)(n - m));
 		bd.n[pp ^ 1][i] = m;                                       // (the record counters are reset by the next check_emit)
-		if (ro.on && m == 0) ro.stale_counts[i] = 0;
-		if (ro.on && i == 0) {                                       // the block's contention figures go straight to the host's pinned words
-			ro.feedback[0] = bd.stats[ST_MAX_U0]; ro.feedback[1] = bd.stats[ST_MAX_UFIN]; ro.feedback[2] = bd.stats[ST_MAX_LATE_BIN];
-			bd.stats[ST_MAX_U0] = 0; bd.stats[ST_MAX_UFIN] = 0; bd.stats[ST_MAX_LATE_BIN] = 0;
-		}
 	}
 }
 
@@ -2564,7 +2538,7 @@ static inline int round_gx(int t) { return (int)(KMX_BUCKET / 256) >> (t < 4 ? t
 // round, or calls commit_flush.  The single-workgroup finisher decides whatever the sub-rounds leave (everything when
 // nsub == 0), so nsub only trades launches for finisher iterations; the host picks it from the contention it has observed.
 // t_prev: the round index of the pending commit (t - 1, or nb - 1 of the previous block).
-void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 *epoch, int flags, hipStream_t st, KernelProf *prof, const KmbackJob *job, const BitScatter *kmb, const RestOut *rest)
+void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 *epoch, int flags, hipStream_t st, KernelProf *prof, const KmbackJob *job, const BitScatter *kmb)
 {
 	const int nb = md.nb;
 	if (nsub < 0) nsub = 0;
@@ -2618,10 +2592,7 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 	}
 	KPROF_END(prof, st);
 	KPROF_BEGIN(prof, KC_REORDER, st);
-	RestOut ro_off;
-	memset(&ro_off, 0, sizeof ro_off);
-	const RestOut ro = rest ? *rest : ro_off;
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, nb), dim3(256), 0, st, md, bd, t, pp, nsub & 1, ro));
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, nb), dim3(256), 0, st, md, bd, t, pp, nsub & 1));
 	KPROF_END(prof, st);
 }
 

@@ -34,7 +34,7 @@ int classify_tiles(u64 n);
 void classify_count(const ModelDev &, const u64 *, const u32 *, u64, u64, int *, int *, int *, u64 *, const BitScatter &, int, hipStream_t, KernelProf *);
 void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int *, u64 *, u32 *, u64, hipStream_t);
 void block_init(const BlockDev &, int, int, int, hipStream_t);
-void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *, const KmbackJob *, const BitScatter *, const RestOut *);
+void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *, const KmbackJob *, const BitScatter *);
 void commit_flush(const ModelDev &, const BlockDev &, int, int, hipStream_t, KernelProf *);
 void rest_append(const ModelDev &, const BlockDev &, int, int, int, u64 *, int *, unsigned long long *, u64 *, int *, u64 *, hipStream_t);
 void kmback_emit(const ModelDev &, const BlockDev &, const u64 *, const unsigned char *, int, int, int, int, int, const BitScatter &, hipStream_t);
@@ -960,14 +960,14 @@ static int flush_pending_commit(kmx_model *m)
 // the claims its detect needs as settled positions are its own.  Deferring is sound only while cl_mix is a bijection on the
 // positions of an array -- the gate in kmx_begin and the static_assert below tie the two together.
 static_assert(KMX_CL_MIX_BITS == 36, "kmx_begin's defer gate, cl_mix's mask and the 8 + 28-bit table entry of k_round_detect all assume 36 bits");
-static int run_round(kmx_model *m, int t, bool defer, const KmbackJob *job, const RestOut *rest = nullptr)
+static int run_round(kmx_model *m, int t, bool defer, const KmbackJob *job)
 {
 	// late rounds: small detect tables while the fullest late bin the device reported stays far below what they take (a
 	// launch-shape heuristic like steer_passes: a bin that does not fit only sends its list down the ordered path, never changes the result)
 	const u64 late_bin = ((volatile u64 *)m->h_feedback)[2];
 	const bool small_detect = m->dbg_small_detect >= 0 ? m->dbg_small_detect != 0 : late_bin <= 2048;
 	const int flags = m->dbg_flags | (m->pending ? KMX_ROUND_PENDING : 0) | (defer ? KMX_ROUND_KEEP : 0) | (small_detect ? KMX_ROUND_SMALL_DETECT : 0);
-	kmxk::round(m->md, m->bd, t, m->pp, passes_of_round(m, t), &m->epoch, flags, m->stream, &m->prof, job, &m->kmb, rest);
+	kmxk::round(m->md, m->bd, t, m->pp, passes_of_round(m, t), &m->epoch, flags, m->stream, &m->prof, job, &m->kmb);
 	m->pending = true; m->pending_t = t;
 	m->pp ^= 1;
 	m->rounds++;
@@ -987,16 +987,6 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 	// The previous block's km_back emission rides along with this block's finisher launches, one list per round: 128
 	// rider workgroups beside the nb finisher workgroups, one wave of workgroups on 256 CUs.
 	KmbackJob &job = m->kmb_job;
-	// the survivors of the block go to the rest table from the last round's reorder launch (kmodel.hpp:567-571); the stale-slot
-	// duplicates of the final partial block (quirk Q1) read what the PREVIOUS block left in the stale slots: before that launch
-	TRY(ensure_rest_capacity(m, n_in_block + (u64)nb));
-	if (final_partial) {
-		int row = (int)((n_in_block - 1) / KMX_BUCKET);
-		if (row + 1 < nb && m->blocks > 0)
-			hipLaunchKernelGGL(k_stale_dup, dim3(1), dim3(64), 0, m->stream, row + 1, nb, m->W, (const u64 *)m->d_stale_kmers,
-			                   (const int *)m->d_stale_counts, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stats);
-	}
-	const RestOut ro = {1, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback};
 	for (int t = 0; t < nb; t++) {
 		KmbackJob part = {nullptr, nullptr, 0, 0, 0};
 		if (job.n_lists > 0) {
@@ -1007,9 +997,17 @@ static int process_block(kmx_model *m, u64 head, u64 n_in_block, bool final_part
 			job.i0 += part.n_lists;
 			job.n_lists -= part.n_lists;
 		}
-		TRY(run_round(m, t, m->defer, part.n_lists ? &part : nullptr, t == nb - 1 ? &ro : nullptr));
+		TRY(run_round(m, t, m->defer, part.n_lists ? &part : nullptr));
 	}
 	const int pp = m->pp;                                          // the lists the last reorder wrote: the block's survivors
+	TRY(ensure_rest_capacity(m, n_in_block + (u64)nb));
+	if (final_partial) {
+		int row = (int)((n_in_block - 1) / KMX_BUCKET);
+		if (row + 1 < nb && m->blocks > 0)
+			hipLaunchKernelGGL(k_stale_dup, dim3(1), dim3(64), 0, m->stream, row + 1, nb, m->W, (const u64 *)m->d_stale_kmers,
+			                   (const int *)m->d_stale_counts, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stats);
+	}
+	kmxk::rest_append(m->md, m->bd, pp, 0, nb, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream);
 	// km_back insert of everything the block inserted (kmodel.hpp:548-550): handed to the next block's finisher launches,
 	// or done here when there is no next block to host it (or the filter takes the direct path)
 	if (m->kmb_deferred && m->dbg_kmb_host && !final_partial) {

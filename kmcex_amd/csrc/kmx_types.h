@@ -60,17 +60,6 @@ struct KmbackJob {
 	int n_in_block;
 	int i0, n_lists;             // this launch emits lists [i0, i0 + n_lists) of that block; n_lists == 0: nothing hosted
 };
-// The rest table as the LAST round's k_reorder sees it (single-GPU build: the survivors of the block go there in the
-// launch that finds them, kmodel.hpp:567-571, instead of a k_rest_append launch of their own); on == 0: not this round
-struct RestOut {
-	int on;
-	u64 *kmers;
-	int *counts;
-	unsigned long long *n;
-	u64 *stale_kmers;
-	int *stale_counts;
-	u64 *feedback;
-};
 #define BS_MAX_TILES_LOG2 8                    // tiles per bin at most, two-level (the split counts them in 256 LDS counters)
 
 // Raw KMC records on the device (k_kmc_decode): fixed-size [suffix bytes big-endian | counter bytes little-endian];

@@ -369,9 +369,7 @@ void range_resolve(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, c
 		hipMemsetAsync(rd.send_cnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, st);
 		hipLaunchKernelGGL((k_range_commit_emit<16>), grid, dim3(256), 0, st, md, bd, rd, pl, pp);
 	}
-	RestOut ro_off;
-	memset(&ro_off, 0, sizeof ro_off);
-	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, md.nb), dim3(256), 0, st, md, bd, t, pp, 0, ro_off));   // (no REC_WON records here: Un stays 0)
+	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, md.nb), dim3(256), 0, st, md, bd, t, pp, 0));   // (no REC_WON records here: Un stays 0)
 }
 void range_commit_apply(const ModelDev &md, int t, const u64 *commits, u64 n, hipStream_t st)
 {
