@@ -31,3 +31,27 @@ for r in b:
 print("kernel time of that call:")
 for k, (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:14]:
     print(f"  {k:32s} {n:5d} x {t / n:8.2f} us = {t / 1e3:7.3f} ms")
+
+# timeline around one batch boundary (the 4th idle gap above 200 us): kernels and memory copies
+import os
+mc = (glob.glob(sys.argv[1] + "/*memory_copy_trace.csv") + glob.glob(sys.argv[1] + "/*/*memory_copy_trace.csv"))
+big = [i for i in range(1, len(b)) if int(b[i]["Start_Timestamp"]) - max(int(r["End_Timestamp"]) for r in b[max(0, i - 3):i]) > 200_000]
+if big and mc:
+    i = big[min(3, len(big) - 1)]
+    g0, g1 = int(b[i - 1]["End_Timestamp"]), int(b[i]["Start_Timestamp"])
+    t0 = g0 - 7_000_000
+    print(f"\ntimeline around one batch boundary (times in ms relative to the start of the idle gap; gap = {(g1 - g0) / 1e3:.0f} us):")
+    ev = []
+    for r in b:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if e >= t0 and s <= g1 + 1_500_000 and name(r) in ("k_kmc_decode", "k_classify_count", "k_classify_scatter", "k_kmback_emit", "k_block_init", "k_rest_append"):
+            ev.append((s, e, "kernel " + name(r)))
+    rows_mc = list(csv.DictReader(open(mc[0])))
+    print("  (memory copy columns:", ", ".join(rows_mc[0].keys()) if rows_mc else "none", ")")
+    for r in rows_mc:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if e >= t0 and s <= g1 + 1_500_000:
+            ev.append((s, e, "copy   " + " ".join(str(r.get(k, "")) for k in ("Direction", "Bytes", "Stream_Id") if k in r)))
+    for s, e, what in sorted(ev):
+        if e - s > 20_000 or what.startswith("copy"):
+            print(f"  {(s - g0) / 1e6:8.3f} .. {(e - g0) / 1e6:8.3f} ms  {what}")
