@@ -1490,7 +1490,9 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 				const uint64_t rec0 = rec;
 				if (raw) {
 					got = (size_t)std::min<uint64_t>(B, db.records() > rec ? db.records() - rec : 0);
+					const auto t_fill = std::chrono::steady_clock::now();
 					if (got) db.copy_records(rec, got, slot[s].raw);
+					if (trace && got) fprintf(stderr, "[kmx] init(db) producer: %zu records into slot %d in %.2f ms\n", got, s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fill).count() * 1e3);
 					rec += got;
 				} else got = db.next_batch((uint64_t *)slot[s].km, slot[s].cnt, B);
 				{ std::lock_guard<std::mutex> lk(mu); slot[s].n = got; slot[s].rec0 = rec0; slot[s].last = got == 0; slot[s].full = true; }
