@@ -243,13 +243,12 @@ struct kmx_model {
 	// feed of KModel::init(db): pinned slots, device buffers, copy stream -- kept across calls on the handle (allocating and
 	// freeing ~300 MB of pinned + device memory costs ~30 ms per call on this stack)
 	struct KmcFeed {
-		static const int NS = 3;                                   // slots: one being inserted, one on the link, one being filled by the producer
-		unsigned char *raw[NS] = {nullptr, nullptr, nullptr}, *draw[NS] = {nullptr, nullptr, nullptr};
-		u64 *km[NS] = {nullptr, nullptr, nullptr}, *dk[NS] = {nullptr, nullptr, nullptr}, *d_lut = nullptr;
-		u32 *cnt[NS] = {nullptr, nullptr, nullptr}, *dc[NS] = {nullptr, nullptr, nullptr};
+		unsigned char *raw[2] = {nullptr, nullptr}, *draw[2] = {nullptr, nullptr};
+		u64 *km[2] = {nullptr, nullptr}, *dk[2] = {nullptr, nullptr}, *d_lut = nullptr;
+		u32 *cnt[2] = {nullptr, nullptr}, *dc[2] = {nullptr, nullptr};
 		size_t raw_cap = 0, km_cap = 0, dk_cap = 0, lut_cap = 0;   // bytes / bytes / k-mer words / entries
 		hipStream_t copy = nullptr;
-		hipEvent_t ev_copied[NS] = {nullptr, nullptr, nullptr}, ev_free[NS] = {nullptr, nullptr, nullptr};
+		hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
 	} feed;
 	// feed of kmer_to_occ(vector<string>): three slots of pinned + device buffers (strings in, answers out), a copy stream
 	// each way -- kept on the handle like the KMC feed
@@ -463,7 +462,7 @@ static void free_feed(kmx_model *m)
 {
 	auto &f = m->feed;
 	if (f.copy) { hipStreamSynchronize(f.copy); hipStreamDestroy(f.copy); f.copy = nullptr; }
-	for (int s = 0; s < f.NS; s++) {
+	for (int s = 0; s < 2; s++) {
 		if (f.raw[s]) hipHostFree(f.raw[s]);
 		if (f.km[s]) hipHostFree(f.km[s]);
 		if (f.cnt[s]) hipHostFree(f.cnt[s]);
@@ -1102,22 +1101,22 @@ static int ensure_host_feed(kmx_model *m, size_t B, int W)
 	if (!F.copy) HIPCHK(hipStreamCreateWithFlags(&F.copy, hipStreamNonBlocking));
 	for (int s = 0; s < 2; s++) {
 		if (!F.ev_copied[s]) { HIPCHK(hipEventCreateWithFlags(&F.ev_copied[s], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&F.ev_free[s], hipEventDisableTiming)); }
-		if (F.km_cap < B * (size_t)W || !F.km[s]) {
+		if (F.km_cap < B * (size_t)W) {
 			if (F.km[s]) hipHostFree(F.km[s]);
 			if (F.cnt[s]) hipHostFree(F.cnt[s]);
 			F.km[s] = nullptr; F.cnt[s] = nullptr;
-			HIPCHK(hipHostMalloc((void **)&F.km[s], std::max(F.km_cap, B * (size_t)W) * 8));
-			HIPCHK(hipHostMalloc((void **)&F.cnt[s], std::max(F.km_cap, B * (size_t)W) / W * 4));
+			HIPCHK(hipHostMalloc((void **)&F.km[s], B * W * 8));
+			HIPCHK(hipHostMalloc((void **)&F.cnt[s], B * 4));
 		}
-		if (F.dk_cap < B * (size_t)W || !F.dk[s]) {
+		if (F.dk_cap < B * (size_t)W) {
 			hipFree(F.dk[s]); hipFree(F.dc[s]);
 			F.dk[s] = nullptr; F.dc[s] = nullptr;
-			HIPCHK(hipMalloc((void **)&F.dk[s], std::max(F.dk_cap, B * (size_t)W) * 8));
-			HIPCHK(hipMalloc((void **)&F.dc[s], std::max(F.dk_cap, B * (size_t)W) / W * 4));
+			HIPCHK(hipMalloc((void **)&F.dk[s], B * W * 8));
+			HIPCHK(hipMalloc((void **)&F.dc[s], B * 4));
 		}
 	}
-	if (F.km_cap < B * (size_t)W) { if (F.km[2]) { hipHostFree(F.km[2]); hipHostFree(F.cnt[2]); F.km[2] = nullptr; F.cnt[2] = nullptr; } F.km_cap = B * (size_t)W; }   // (the third slot is the KMC feed's: it re-allocates what is missing)
-	if (F.dk_cap < B * (size_t)W) { if (F.dk[2]) { hipFree(F.dk[2]); hipFree(F.dc[2]); F.dk[2] = nullptr; F.dc[2] = nullptr; } F.dk_cap = B * (size_t)W; }
+	F.km_cap = std::max(F.km_cap, B * (size_t)W);
+	F.dk_cap = std::max(F.dk_cap, B * (size_t)W);
 	return KMX_OK;
 }
 
@@ -1421,9 +1420,8 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 	lap("database open");
 	const char *force_host = hook_env("KMX_KMC_HOST_DECODE");
 	bool gpu_decode = !(force_host && atoi(force_host));
+	FeedSlot slot[2];
 	auto &F = m->feed;
-	constexpr int NS = kmx_model::KmcFeed::NS;
-	FeedSlot slot[NS];
 	std::mutex mu;
 	std::condition_variable cv;
 	bool stop = false, alloc_done = false;
@@ -1443,19 +1441,18 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 	allocator = std::thread([&] {
 		if (hipSetDevice(m->device) != hipSuccess) return;
 		bool good = F.copy || hipStreamCreateWithFlags(&F.copy, hipStreamNonBlocking) == hipSuccess;
-		for (int s = 0; s < NS && good; s++) {
+		for (int s = 0; s < 2 && good; s++) {
 			if (!F.ev_copied[s]) good = hipEventCreateWithFlags(&F.ev_copied[s], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&F.ev_free[s], hipEventDisableTiming) == hipSuccess;
-			if (good && (F.raw_cap < B * rb + 16 || !F.raw[s])) {
+			if (good && F.raw_cap < B * rb + 16) {
 				if (F.raw[s]) hipHostFree(F.raw[s]);
 				hipFree(F.draw[s]);
 				F.raw[s] = nullptr; F.draw[s] = nullptr;
 				good = hipHostMalloc((void **)&F.raw[s], B * rb + 16) == hipSuccess && hipMalloc((void **)&F.draw[s], B * rb + 16) == hipSuccess;
 			}
-			if (good && (F.dk_cap < B * (size_t)W || !F.dk[s])) {
+			if (good && F.dk_cap < B * (size_t)W) {
 				hipFree(F.dk[s]); hipFree(F.dc[s]);
 				F.dk[s] = nullptr; F.dc[s] = nullptr;
-				const size_t cap = std::max(F.dk_cap, B * (size_t)W);
-				good = hipMalloc((void **)&F.dk[s], cap * 8) == hipSuccess && hipMalloc((void **)&F.dc[s], cap / W * 4) == hipSuccess;
+				good = hipMalloc((void **)&F.dk[s], B * W * 8) == hipSuccess && hipMalloc((void **)&F.dc[s], B * 4) == hipSuccess;
 			}
 		}
 		if (good) { F.raw_cap = std::max(F.raw_cap, B * rb + 16); F.dk_cap = std::max(F.dk_cap, B * (size_t)W); }
@@ -1480,10 +1477,10 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 				cv.wait(lk, [&] { return alloc_done || stop; });
 				if (stop || !ok) return;
 			}
-			for (int s = 0; s < NS; s++) { slot[s].raw = F.raw[s]; slot[s].km = F.km[s]; slot[s].cnt = F.cnt[s]; }
+			for (int s = 0; s < 2; s++) { slot[s].raw = F.raw[s]; slot[s].km = F.km[s]; slot[s].cnt = F.cnt[s]; }
 			uint64_t rec = 0;
 			if (!raw) db.restart();                                          // kmodel.hpp:430
-			for (int s = 0;; s = (s + 1) % NS) {
+			for (int s = 0;; s ^= 1) {
 				{
 					std::unique_lock<std::mutex> lk(mu);
 					cv.wait(lk, [&] { return !slot[s].full || stop; });
@@ -1493,9 +1490,7 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 				const uint64_t rec0 = rec;
 				if (raw) {
 					got = (size_t)std::min<uint64_t>(B, db.records() > rec ? db.records() - rec : 0);
-					const auto t_fill = std::chrono::steady_clock::now();
 					if (got) db.copy_records(rec, got, slot[s].raw);
-					if (trace && got) fprintf(stderr, "[kmx] init(db) producer: %zu records into slot %d in %.2f ms\n", got, s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fill).count() * 1e3);
 					rec += got;
 				} else got = db.next_batch((uint64_t *)slot[s].km, slot[s].cnt, B);
 				{ std::lock_guard<std::mutex> lk(mu); slot[s].n = got; slot[s].rec0 = rec0; slot[s].last = got == 0; slot[s].full = true; }
@@ -1524,16 +1519,14 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 		{ std::lock_guard<std::mutex> lk(mu); stop = false; for (auto &sl : slot) sl = FeedSlot(); }
 		gpu_decode = false;
 	}
-	if (!gpu_decode) {                                               // host decoder: pinned k-mer / count slots
-		const size_t cap = std::max(F.km_cap, B * (size_t)W);
-		for (int s = 0; s < NS && !rc; s++) {
-			if (F.km_cap >= B * (size_t)W && F.km[s]) continue;
+	if (!gpu_decode && F.km_cap < B * (size_t)W) {                   // host decoder: pinned k-mer / count slots
+		for (int s = 0; s < 2 && !rc; s++) {
 			if (F.km[s]) hipHostFree(F.km[s]);
 			if (F.cnt[s]) hipHostFree(F.cnt[s]);
 			F.km[s] = nullptr; F.cnt[s] = nullptr;
-			if (hipHostMalloc((void **)&F.km[s], cap * 8) != hipSuccess || hipHostMalloc((void **)&F.cnt[s], cap / W * 4) != hipSuccess) rc = fail(KMX_E_NOMEM, "pinned buffers for the listing feed could not be allocated");
+			if (hipHostMalloc((void **)&F.km[s], B * W * 8) != hipSuccess || hipHostMalloc((void **)&F.cnt[s], B * 4) != hipSuccess) rc = fail(KMX_E_NOMEM, "pinned buffers for the listing feed could not be allocated");
 		}
-		F.km_cap = rc ? 0 : cap;
+		F.km_cap = rc ? 0 : B * (size_t)W;
 	}
 	if (!rc && !gpu_decode) start_producer(false);
 	if (!rc && db.io_failed()) rc = fail(KMX_E_IO, "reading %s.kmc_suf failed during pass 1", db_prefix);
@@ -1566,19 +1559,16 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 			{ std::lock_guard<std::mutex> lk(mu); slot[s].full = false; }
 			cv.notify_all();
 		};
-		for (int s = 0; s < NS; s++) hipEventRecord(F.ev_free[s], m->stream);
+		hipEventRecord(F.ev_free[0], m->stream);
+		hipEventRecord(F.ev_free[1], m->stream);
 		wait_full(0);
 		bool copied = !slot[0].last && enqueue_copy(0);
 		if (!slot[0].last && !copied) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
-		// Three slots: while batch b is inserted, b+1 is on the link and the producer fills b+2 -- with two, every iteration began
-		// by waiting for the producer to refill the slot released a moment before, the GPU idle beside it (1.1 ms per batch: trace
-		// in profiles/r04_init_kernel_trace.txt).
-		for (int s = 0; !slot[s].last; s = (s + 1) % NS) {
+		for (int s = 0; !slot[s].last; s ^= 1) {
 			const size_t n = slot[s].n;
-			const int nx = (s + 1) % NS;
 			// the next batch: produced meanwhile, copied under this batch's rounds
-			wait_full(nx);
-			if (!rc && !slot[nx].last && !enqueue_copy(nx)) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
+			wait_full(s ^ 1);
+			if (!rc && !slot[s ^ 1].last && !enqueue_copy(s ^ 1)) rc = fail(KMX_E_NODEVICE, "H2D copy failed");
 			if (!rc) {
 				if (hipStreamWaitEvent(m->stream, F.ev_copied[s], 0) != hipSuccess) rc = fail(KMX_E_NODEVICE, "stream wait failed");
 				else {
