@@ -434,10 +434,11 @@ def test_strings_the_packed_form_cannot_hold(name):
 
 @pytest.mark.parametrize("name,k", [("tiny_k31", 31), ("k55_nh9_nb6", 55)])
 def test_vector_of_strings_pipeline_over_many_chunks(name, k):
-    """kmer_to_occ(vector<string>) (kmodel.hpp:90-98) on a batch of several chunks of the three-slot pipeline (kmx_query_strings:
-    2^20 strings per chunk, packed by worker threads, answered under the next chunk's packing): as separate strings and as one
-    buffer, with chunks that must travel as bytes (a string the packed form cannot hold) between chunks that travel packed --
-    every answer equal to the packed query's, the dirty strings' answers equal to the oracle's."""
+    """kmer_to_occ(vector<string>) (kmodel.hpp:90-98) on a batch of more than 3 * 2^20 strings through the three-slot pipeline
+    (kmx_query_strings: tasks of 2^14 strings packed by worker threads, a chunk answered under the next one's packing): as
+    separate strings and as one buffer, with strings the packed form cannot hold scattered over the batch (they are answered
+    afterwards, one by one, through the byte-string kernel) -- every answer equal to the packed query's, the dirty strings'
+    answers equal to the oracle's."""
     _, kk, ci, cs, nh, nb, n = CASE[name]
     assert kk == k
     km, cnt = synth.make_stream(n, k, ci, cs)
@@ -455,7 +456,7 @@ def test_vector_of_strings_pipeline_over_many_chunks(name, k):
     rows[:, :k] = synth.to_ascii(q.reshape(-1), k)
     for separate in (True, False):
         assert np.array_equal(m.kmer_to_occ_rows(rows, k, separate), want), separate
-    # chunks 1 and 3 hold strings of other bytes: they travel as bytes, 0 and 2 stay packed
+    # strings of other bytes in the second and the last quarter of the batch
     dirty_at = [(1 << 20) + 5, (1 << 20) * 2 - 1, (1 << 20) * 3 + 7, nq - 1]
     r2 = rows.copy()
     for j, i in enumerate(dirty_at):
