@@ -239,7 +239,7 @@ def promote_single_model(line, single, world):
     line["steps"] = single["steps"]
     line["value_is"] = "k-mers/s encoded into ONE model by all ranks together (single_model); replica_value = N independent models"
     how = (f"ring of whole arrays (min({world}, nb) array owners)" if single.get("partition", "ring") == "ring" else
-           f"every array cut by position range over the {world} ranks, three all-to-alls per round (triples, verdicts, commits)")
+           f"every array cut by position range over the {world} ranks, two all-to-alls per round (commits + triples out, verdicts back)")
     line["config"]["parallelism"] = (f"one model over {world} ranks [--partition {single.get('partition', 'ring')}]: routing all-to-all + {how} + "
                                      f"OR-merged filters + replica queries; replica_value = {world} independent models")
     line["scaling"] = "weak (one model: the ordered chain runs once per round whatever N is -- sub-linear by construction; replica_value scales with N)"
@@ -276,7 +276,7 @@ def single_model_leg(a, m, km, cnt, q, out, rank, world, dev, rehearsal, distrib
                "ring_hops_per_build": info["blocks"] * a.nb * sum(1 for x in range(a.nb) if kd.owner_of_array(x, a.nb, world) != kd.owner_of_array((x + 1) % a.nb, a.nb, world))})
     return {"what": ("ONE model over all ranks' streams: routing all-to-all + ring of arrays (send/recv) + OR-merged filters + array broadcast; queries over replicas"
                      if a.partition == "ring" else
-                     "ONE model over all ranks' streams: routing all-to-all + arrays cut by position range (triples / verdicts / commits by all-to-all) + "
+                     "ONE model over all ranks' streams: routing all-to-all + arrays cut by position range (commits + triples out, verdicts back: two all-to-alls per round) + "
                      "OR-merged filters + all-gather of the ranges; queries over replicas"),
             **layout, "ranks_doing_ordered_work": working, "idle_ranks_in_the_ordered_rounds": world - working,
             "transport": "gloo, ranks sharing one GPU (rehearsal: rates are not xGMI rates)" if rehearsal else ("nccl (RCCL)" if world > 1 else "none (one rank)"),

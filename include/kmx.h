@@ -134,22 +134,27 @@ int kmx_shard_complete(kmx_model *m, const uint64_t *d_rest_kmers, const int32_t
 /* ---- the same model with every coupled array cut by POSITION RANGE over the ranks: rank q owns the cells
  * [cell_lo[q], cell_lo[q+1]) -- 16 positions each -- of every array; list i of a block lives on rank i % world for the whole
  * block and its k-mers never move.  A round of insert_array (kmodel.hpp:543-555, :560-565; check :604-610, set :611-618) is
- * three exchanges of 64-bit words that the CALLER moves between the ranks (all-to-all over RCCL): triples -> verdicts ->
- * commits.  kmx_count_classes_dev, kmx_shard_classify_dev, kmx_ring_stale_dup_dev, kmx_shard_local / _complete and
- * kmx_dev_view are shared with the ring.                                                                               */
+ * two exchanges of 64-bit words / bytes that the CALLER moves between the ranks (all-to-all over RCCL): triples out (behind the
+ * commits of the round before), verdicts back.  kmx_count_classes_dev, kmx_shard_classify_dev, kmx_ring_stale_dup_dev,
+ * kmx_shard_local / _complete and kmx_dev_view are shared with the ring.                                                */
 int kmx_range_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world);
 /* the send regions: region q (cap_words 64-bit words apart) holds what the last emit / resolve left for rank q         */
 int kmx_range_buffers(kmx_model *m, void **d_send, uint64_t *cap_words, uint64_t *cell_lo /* [world + 1] */);
-/* step 1, list rank: every position of every attempt of its lists as a triple, by owner rank; counts[world] on the host.
+/* step 1, list rank: every position of every attempt of its lists as a triple, by owner rank, appended behind the commits
+ * the last kmx_range_resolve_dev left there; counts[world] (commits + triples) on the host.
  * t == 0: `lists` = the fresh buffers of the block this rank holds (list, n_host, src_kmers, src_counts)              */
 int kmx_range_emit_dev(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists, uint64_t *counts);
-/* step 2, owner: conflict | untagged | wanted with both values this round -- one byte per received triple, same order   */
-int kmx_range_verdict_dev(kmx_model *m, int t, const uint64_t *d_triples, uint64_t n, uint8_t *d_verdict);
-/* step 3, list rank: verdicts in the order the triples left (regions concatenated in rank order) -> winners (the contended
- * ones decided in list order), their commits by owner rank in the send regions, reorder_buffer (:529-540), km_back, rest */
+/* step 2, owner: applies the commit words among what it received (the set loop :611-618 of the round before), then answers
+ * every word with one byte, same order: conflict | untagged | wanted with both values this round (0 for a commit word)   */
+int kmx_range_verdict_dev(kmx_model *m, int t, const uint64_t *d_words, uint64_t n, uint8_t *d_verdict);
+/* step 3, list rank: verdicts in the order the words left (regions concatenated in rank order) -> winners (the contended
+ * ones decided in list order); their commits stay in the send regions for the next emit; reorder_buffer (:529-540), km_back,
+ * rest.  counts[world]: the commits pending per owner rank (information: nothing is exchanged now)                      */
 int kmx_range_resolve_dev(kmx_model *m, int t, const uint8_t *d_verdict, uint64_t *counts);
-/* ... owner: the received commits set tag and value bits                                                                */
-int kmx_range_commit_dev(kmx_model *m, int t, const uint64_t *d_commits, uint64_t n);
+/* end of the build: what is still pending in the send regions (counts[world]) for a last exchange ...                  */
+int kmx_range_flush_dev(kmx_model *m, uint64_t *counts);
+/* ... and its application on the owner                                                                                  */
+int kmx_range_commit_dev(kmx_model *m, const uint64_t *d_commits, uint64_t n);
 
 /* device memory of filter / array storage for the caller's collectives: which 0 bf[i], 1 bf_back[i], 2 km_back
  * (bytes rounded up to 32-bit words), 3 the cells of coupled array i (value+tag interleaved, 8 bytes per 16 positions)  */

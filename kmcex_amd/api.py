@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "kmx_count_classes_dev", "kmx_shard_begin", "kmx_shard_classify_dev", "kmx_ring_msg_bytes", "kmx_ring_round_dev",
     "kmx_ring_stale_dup_dev", "kmx_shard_local", "kmx_shard_complete", "kmx_dev_view", "kmx_or_words_dev",
     "kmx_debug_pack_strings", "kmx_kernel_classes", "kmx_abi_version",
-    "kmx_create_on", "kmx_build_from_kmc_multi", "kmx_range_begin", "kmx_range_buffers", "kmx_range_emit_dev", "kmx_range_verdict_dev", "kmx_range_resolve_dev", "kmx_range_commit_dev",
+    "kmx_create_on", "kmx_build_from_kmc_multi", "kmx_range_begin", "kmx_range_buffers", "kmx_range_emit_dev", "kmx_range_verdict_dev", "kmx_range_resolve_dev", "kmx_range_commit_dev", "kmx_range_flush_dev",
 ]
 
 
@@ -136,7 +136,8 @@ def load_library():
     _sig(L, "kmx_range_emit_dev", [vp, i32, C.POINTER(RingList), i32, C.POINTER(u64)])
     _sig(L, "kmx_range_verdict_dev", [vp, i32, vp, u64, vp])
     _sig(L, "kmx_range_resolve_dev", [vp, i32, vp, C.POINTER(u64)])
-    _sig(L, "kmx_range_commit_dev", [vp, i32, vp, u64])
+    _sig(L, "kmx_range_commit_dev", [vp, vp, u64])
+    _sig(L, "kmx_range_flush_dev", [vp, C.POINTER(u64)])
     L.kmx_or_words_dev.argtypes = [vp, vp, vp, u64]
     _sig(L, "kmx_debug_pack_strings", [vp, vp, i32, i32, u64, vp, C.POINTER(i32)])
     _sig(L, "kmx_kernel_classes", [])
@@ -350,8 +351,13 @@ class KModel:
         _chk(self.L.kmx_range_resolve_dev(self.h, t, d_verdict_ptr, counts))
         return [int(x) for x in counts]
 
-    def range_commit_dev(self, t: int, d_commits_ptr: int, n: int) -> None:
-        _chk(self.L.kmx_range_commit_dev(self.h, t, d_commits_ptr, n))
+    def range_commit_dev(self, d_commits_ptr: int, n: int) -> None:
+        _chk(self.L.kmx_range_commit_dev(self.h, d_commits_ptr, n))
+
+    def range_flush_dev(self):
+        counts = (C.c_uint64 * self._range_world)()
+        _chk(self.L.kmx_range_flush_dev(self.h, counts))
+        return [int(x) for x in counts]
 
     def dev_view(self, which: str, index: int = 0):
         """(device pointer, bytes) of a filter ("bf", "bf_back", "km_back") or of the cells of coupled array `index` ("cells")"""

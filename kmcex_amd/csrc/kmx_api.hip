@@ -42,10 +42,10 @@ void bs_apply(const BitScatter &, hipStream_t);
 void ring_import(const ModelDev &, const BlockDev &, int, const RingLists &, u64 *, u32 *, hipStream_t);
 void ring_export(const ModelDev &, const BlockDev &, int, const RingLists &, hipStream_t);
 void or_words(u32 *, const u32 *, u64, hipStream_t);
-void range_emit(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, hipStream_t);
+void range_emit(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, bool, hipStream_t);
 void range_verdict(const ModelDev &, const BlockDev &, int, const u64 *, u64, unsigned char *, hipStream_t);
 void range_resolve(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, const unsigned char *, hipStream_t);
-void range_commit_apply(const ModelDev &, int, const u64 *, u64, hipStream_t);
+void range_commit_apply(const ModelDev &, const u64 *, u64, hipStream_t);
 void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *);
 void query_ascii(const ModelDev &, int, const unsigned char *, int, u64, int *, hipStream_t);
 void cells_from_disk(const unsigned char *, const unsigned char *, u64, cell_t *, u64, hipStream_t);
@@ -264,6 +264,7 @@ struct kmx_model {
 	// owner-side view of the block working set (scratch status + overflow flags for the detect kernel on received claims)
 	struct RangeState {
 		bool on = false;
+		bool pending = false;                                      // the send regions hold the last round's commits: the next emit appends to them
 		RangeDev rd = {};
 		RangePlan plan = {};
 		BlockDev obd = {};
@@ -2053,7 +2054,7 @@ static int kmx_range_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uin
 		HIPCHK(hipStreamSynchronize(m->stream));
 		free_range(m);
 		const u64 held = (u64)((nb + world - 1) / world), slots = (u64)nb * KMX_BUCKET;
-		R.rd.cap = held * KMX_BUCKET * (u64)nh;
+		R.rd.cap = 2 * held * KMX_BUCKET * (u64)nh;                  // a round's triples behind the previous round's commits
 		R.rd.rt_bits = nh <= 8 ? 22 : 23;
 		TRY(dalloc(&R.rd.send, (u64)world * R.rd.cap, false, m->stream));
 		TRY(dalloc(&R.rd.send_cnt, (u64)KMX_MAX_RANKS * KMX_CTR_STRIDE, true, m->stream));
@@ -2078,6 +2079,7 @@ static int kmx_range_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uin
 	R.obd.status[0] = R.obd.status[1] = R.d_ostatus;
 	R.obd.cl_ovf = R.d_oovf;
 	R.on = true;
+	R.pending = false;
 	return KMX_OK;
 }
 
@@ -2121,7 +2123,8 @@ static int kmx_range_emit_dev_impl(kmx_model *m, int t, const kmx_ring_list *lis
 		}
 		kmxk::ring_import(m->md, m->bd, m->pp, rl, m->d_stg_kmers, m->d_stg_counts, m->stream);
 	}
-	kmxk::range_emit(m->md, m->bd, R.rd, R.plan, t, m->pp, m->stream);
+	kmxk::range_emit(m->md, m->bd, R.rd, R.plan, t, m->pp, !R.pending, m->stream);
+	R.pending = false;                                             // the caller ships the regions now: commits of the last round + these triples
 	HIPCHK(hipGetLastError());
 	return range_counts(m, counts);
 }
@@ -2157,6 +2160,7 @@ static int kmx_range_resolve_dev_impl(kmx_model *m, int t, const uint8_t *d_verd
 	if (m->km_byte_size == 0) return KMX_OK;
 	const int nb = m->nb, pp = m->pp;
 	kmxk::range_resolve(m->md, m->bd, R.rd, R.plan, t, pp, d_verdict, m->stream);
+	R.pending = true;                                              // the winners' commits wait in the send regions for the next round's triples
 	HIPCHK(hipGetLastError());
 	TRY(range_counts(m, counts));
 	const int held = (nb + R.plan.world - 1 - R.plan.rank) / R.plan.world;
@@ -2175,14 +2179,25 @@ static int kmx_range_resolve_dev_impl(kmx_model *m, int t, const uint8_t *d_verd
 }
 
 // ... and on the owner: the winners' tag / value bits (kmodel.hpp:611-618)
-static int kmx_range_commit_dev_impl(kmx_model *m, int t, const uint64_t *d_commits, uint64_t n)
+static int kmx_range_commit_dev_impl(kmx_model *m, const uint64_t *d_commits, uint64_t n)
 {
-	TRY(range_check(m, t));
+	TRY(range_check(m, 0));
 	if (n && !d_commits) return fail(KMX_E_ARG, "null argument");
 	if (m->km_byte_size == 0) return KMX_OK;
-	kmxk::range_commit_apply(m->md, t, (const u64 *)d_commits, n, m->stream);
+	kmxk::range_commit_apply(m->md, (const u64 *)d_commits, n, m->stream);
 	HIPCHK(hipGetLastError());
 	return KMX_OK;
+}
+// what is pending in the send regions (the commits of the last round) for a last exchange at the end of the build
+static int kmx_range_flush_dev_impl(kmx_model *m, uint64_t *counts)
+{
+	TRY(range_check(m, 0));
+	if (!counts) return fail(KMX_E_ARG, "null argument");
+	auto &R = m->range;
+	for (int q = 0; q < R.plan.world; q++) counts[q] = 0;
+	if (!R.pending || m->km_byte_size == 0) return KMX_OK;
+	R.pending = false;
+	return range_counts(m, counts);
 }
 
 // device memory of one filter / array of this handle, for the collectives of the caller (which: as kmx_download; 3 = the
@@ -2907,7 +2922,8 @@ extern "C" int kmx_range_buffers(kmx_model *m, void **d_send, uint64_t *cap_word
 extern "C" int kmx_range_emit_dev(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists, uint64_t *counts) { return guarded([&] { return kmx_range_emit_dev_impl(m, t, lists, n_lists, counts); }); }
 extern "C" int kmx_range_verdict_dev(kmx_model *m, int t, const uint64_t *d_triples, uint64_t n, uint8_t *d_verdict) { return guarded([&] { return kmx_range_verdict_dev_impl(m, t, d_triples, n, d_verdict); }); }
 extern "C" int kmx_range_resolve_dev(kmx_model *m, int t, const uint8_t *d_verdict, uint64_t *counts) { return guarded([&] { return kmx_range_resolve_dev_impl(m, t, d_verdict, counts); }); }
-extern "C" int kmx_range_commit_dev(kmx_model *m, int t, const uint64_t *d_commits, uint64_t n) { return guarded([&] { return kmx_range_commit_dev_impl(m, t, d_commits, n); }); }
+extern "C" int kmx_range_commit_dev(kmx_model *m, const uint64_t *d_commits, uint64_t n) { return guarded([&] { return kmx_range_commit_dev_impl(m, d_commits, n); }); }
+extern "C" int kmx_range_flush_dev(kmx_model *m, uint64_t *counts) { return guarded([&] { return kmx_range_flush_dev_impl(m, counts); }); }
 extern "C" int kmx_dev_view(kmx_model *m, int which, int index, void **ptr, uint64_t *bytes) { return guarded([&] { return kmx_dev_view_impl(m, which, index, ptr, bytes); }); }
 extern "C" int kmx_or_words_dev(kmx_model *m, void *d_dst, const void *d_src, uint64_t n_words) { return guarded([&] { return kmx_or_words_dev_impl(m, d_dst, d_src, n_words); }); }
 extern "C" int kmx_kmc_info(const char *db_prefix, int *k, uint64_t *total_kmers) { return guarded([&] { return kmx_kmc_info_impl(db_prefix, k, total_kmers); }); }

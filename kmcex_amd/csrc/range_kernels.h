@@ -4,7 +4,8 @@
 //
 // Rank q owns the cells [cell_lo[q], cell_lo[q+1]) -- 16 positions each -- of EVERY array.  List i of a block lives on rank
 // i % P for the whole block: it hashes its k-mers, keeps the list order and reorders locally (kmodel.hpp:529-540); k-mers
-// never move.  A round (all lists at once, list i against array (i + t) % nb, kmodel.hpp:560-565) is three exchanges:
+// never move.  A round (all lists at once, list i against array (i + t) % nb, kmodel.hpp:560-565) is two all-to-alls (the
+// winners' commits of round t travel with the triples of round t + 1; a last exchange flushes them at the end of the build):
 //   1. k_range_emit        list rank: one TRIPLE (position, wanted value, list, slot, hash index) per position of every attempt,
 //                          binned by owner rank                                      -> all-to-all
 //   2. k_range_verdict     owner: reads the cell -- conflict with a set tag (kmodel.hpp:604-610) | untagged --, files every
@@ -15,7 +16,9 @@
 //      k_range_resolve     none of whose untagged positions is contended wins outright; the contended ones are decided in list
 //      k_range_commit_emit order from the verdicts alone (the only writers that can matter to them are earlier contended
 //                          winners): priority reservations on an exact position table, the smallest undecided slot always
-//                          wins its turn.  The winners' (position, value) pairs -> all-to-all -> k_range_commit_apply on the owners.
+//                          wins its turn.  The winners' (position, value, array) words stay in the send regions, IN FRONT of the
+//                          next round's triples (bit 63 marks them): the owner applies them (k_range_commit_apply) before it
+//                          reads a cell for that round's verdicts -- the order the sequential algorithm has.
 // Then k_reorder, the km_back emission of the round and, after the last round, k_rest_append -- the single-GPU kernels.
 #pragma once
 
@@ -26,6 +29,7 @@
 #define RT_X(tr) ((u32)((tr) >> 41) & (KMX_BUCKET - 1))
 #define RT_J(tr) ((u32)((tr) >> 59) & 15u)
 #define RT_MAKE(pos, want, i, x, j) ((u64)(pos) | ((u64)(want) << 36) | ((u64)(i) << 37) | ((u64)(x) << 41) | ((u64)(j) << 59))
+#define RT_COMMIT (1ULL << 63)      // a commit word: position | value << 36 | ARRAY << 37
 enum { RV_CONFLICT = 1, RV_UNTAGGED = 2, RV_BOTH = 4 };
 
 __device__ __forceinline__ int range_owner(const RangePlan &pl, u64 cell)
@@ -106,6 +110,7 @@ template <int NHM> __global__ __launch_bounds__(256) void k_range_verdict(ModelD
 	constexpr int NBIN = KMX_CL_BINS(NHM), CAP = KMX_CL_CAP_OF(NHM);
 	for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < n; q += (u64)gridDim.x * 256) {
 		const u64 tr = triples[q];
+		if (tr & RT_COMMIT) { verdict[q] = 0; continue; }              // a commit of the previous round (applied by the launch before this one)
 		const u64 pos = RT_POS(tr);
 		const u32 i = RT_LIST(tr), want = RT_WANT(tr);
 		const int a = (int)((i + (u32)t) % (u32)md.nb);
@@ -291,7 +296,7 @@ template <int NHM> __global__ __launch_bounds__(1024) void k_range_resolve(Model
 }
 
 // 3c. the winners' tag / value bits, by owner rank: one word per position they saw untagged (kmodel.hpp:611-618)
-template <int NHM> __global__ __launch_bounds__(256) void k_range_commit_emit(ModelDev md, BlockDev bd, RangeDev rd, RangePlan pl, int pp)
+template <int NHM> __global__ __launch_bounds__(256) void k_range_commit_emit(ModelDev md, BlockDev bd, RangeDev rd, RangePlan pl, int t, int pp)
 {
 	__shared__ int s_cnt[KMX_MAX_RANKS], s_base[KMX_MAX_RANKS];
 	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
@@ -311,22 +316,22 @@ template <int NHM> __global__ __launch_bounds__(256) void k_range_commit_emit(Mo
 #pragma unroll
 		for (int j = 0; j < NHM; j++)
 			if (j < md.nh && ((um >> j) & 1u)) {
-				word[j] = RT_MAKE(pos[j], value_at_position<NHM>(md, pos, um, want, j), i, 0, 0);
+				word[j] = RT_COMMIT | RT_MAKE(pos[j], value_at_position<NHM>(md, pos, um, want, j), (i + t) % md.nb, 0, 0);
 				dest[j] = range_owner(pl, pos[j] >> 4);
 				valid |= 1u << j;
 			}
 	}
 	range_block_append<NHM>(rd, pl.world, word, dest, valid, nullptr, s_cnt, s_base);
 }
-// ... and their application on the owner
-__global__ __launch_bounds__(256) void k_range_commit_apply(ModelDev md, int t, const u64 *commits, u64 n)
+// ... and their application on the owner: the commit words among what it received (the others are the round's triples)
+__global__ __launch_bounds__(256) void k_range_commit_apply(ModelDev md, const u64 *words, u64 n)
 {
 	for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < n; q += (u64)gridDim.x * 256) {
-		const u64 tr = commits[q];
+		const u64 tr = words[q];
+		if (!(tr & RT_COMMIT)) continue;
 		const u64 pos = RT_POS(tr);
-		const int a = (int)((RT_LIST(tr) + (u32)t) % (u32)md.nb);
 		const u32 b = bit_in_cell(pos);
-		atomicOr(md.cells[a] + (pos >> 4), CELL_TAG(b) | (RT_WANT(tr) ? CELL_VAL(b) : 0u));
+		atomicOr(md.cells[RT_LIST(tr)] + (pos >> 4), CELL_TAG(b) | (RT_WANT(tr) ? CELL_VAL(b) : 0u));
 	}
 }
 
@@ -334,9 +339,10 @@ namespace kmxk {
 
 static inline unsigned range_grid(u64 n) { return (unsigned)std::min<u64>((n + 255) / 256, 1u << 16); }
 
-void range_emit(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangePlan &pl, int t, int pp, hipStream_t st)
+// fresh: nothing is pending in the send regions (else the triples are appended behind the previous round's commits)
+void range_emit(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangePlan &pl, int t, int pp, bool fresh, hipStream_t st)
 {
-	hipMemsetAsync(rd.send_cnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, st);
+	if (fresh) hipMemsetAsync(rd.send_cnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, st);
 	hipMemsetAsync(rd.n_contended, 0, sizeof(int) * KMX_MAX_NB * KMX_CTR_STRIDE, st);
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_range_emit<W, NHM>), dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, md, bd, rd, pl, t, pp));
 }
@@ -344,6 +350,7 @@ void range_emit(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, cons
 void range_verdict(const ModelDev &md, const BlockDev &obd, int t, const u64 *triples, u64 n, unsigned char *verdict, hipStream_t st)
 {
 	if (!n) return;
+	hipLaunchKernelGGL(k_range_commit_apply, dim3(range_grid(n)), dim3(256), 0, st, md, triples, n);      // the previous round's winners first
 	if (md.nh <= 8) {
 		hipLaunchKernelGGL((k_range_verdict<8>), dim3(range_grid(n)), dim3(256), 0, st, md, obd, t, triples, n, verdict);
 		hipLaunchKernelGGL((k_round_detect<8, 1024, KMX_CL_TBITS(8)>), dim3(KMX_CL_BINS(8), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, 0);
@@ -362,18 +369,18 @@ void range_resolve(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, c
 		hipLaunchKernelGGL((k_range_apply<8>), grid, dim3(256), 0, st, md, bd, rd, pl.world, pp, verdict);
 		hipLaunchKernelGGL((k_range_resolve<8>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl.world, pp);
 		hipMemsetAsync(rd.send_cnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, st);
-		hipLaunchKernelGGL((k_range_commit_emit<8>), grid, dim3(256), 0, st, md, bd, rd, pl, pp);
+		hipLaunchKernelGGL((k_range_commit_emit<8>), grid, dim3(256), 0, st, md, bd, rd, pl, t, pp);
 	} else {
 		hipLaunchKernelGGL((k_range_apply<16>), grid, dim3(256), 0, st, md, bd, rd, pl.world, pp, verdict);
 		hipLaunchKernelGGL((k_range_resolve<16>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl.world, pp);
 		hipMemsetAsync(rd.send_cnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, st);
-		hipLaunchKernelGGL((k_range_commit_emit<16>), grid, dim3(256), 0, st, md, bd, rd, pl, pp);
+		hipLaunchKernelGGL((k_range_commit_emit<16>), grid, dim3(256), 0, st, md, bd, rd, pl, t, pp);
 	}
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, md.nb), dim3(256), 0, st, md, bd, t, pp, 0));   // (no REC_WON records here: Un stays 0)
 }
-void range_commit_apply(const ModelDev &md, int t, const u64 *commits, u64 n, hipStream_t st)
+void range_commit_apply(const ModelDev &md, const u64 *commits, u64 n, hipStream_t st)
 {
-	if (n) hipLaunchKernelGGL(k_range_commit_apply, dim3(range_grid(n)), dim3(256), 0, st, md, t, commits, n);
+	if (n) hipLaunchKernelGGL(k_range_commit_apply, dim3(range_grid(n)), dim3(256), 0, st, md, commits, n);
 }
 
 }   // namespace kmxk

@@ -348,12 +348,16 @@ class DeviceEngine:
         return ver
 
     def range_resolve(self, t, verdicts):
-        counts = self.m.range_resolve_dev(t, verdicts.data_ptr() if verdicts.numel() else 0)
+        """the winners' commits stay in the send regions, in front of the next round's triples"""
+        self.m.range_resolve_dev(t, verdicts.data_ptr() if verdicts.numel() else 0)
+
+    def range_flush(self):
+        counts = self.m.range_flush_dev()
         return self._regions(counts), counts
 
-    def range_commit(self, t, commits):
+    def range_commit(self, commits):
         if commits.numel():
-            self.m.range_commit_dev(t, commits.data_ptr(), commits.numel())
+            self.m.range_commit_dev(commits.data_ptr(), commits.numel())
 
     def array_ranges(self, a):
         return [(self.view("cells", a), self.cell_lo)]
@@ -481,10 +485,11 @@ def build_range_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: to
     """The north star's partition: "shard the bit arrays by hash-range across up to 8 GPUs with an RCCL all-to-all".  Rank q
     owns the cells [cell_lo[q], cell_lo[q+1]) of EVERY array; list i of a block lives on rank i % world, which hashes its
     k-mers, keeps the list order and reorders locally -- k-mers are routed once (the same all-to-all as the ring's, to the
-    list's rank) and never move again.  A round (list i against array (i + t) % nb, kmodel.hpp:560-565) is three all-to-alls
-    of 64-bit words / bytes: triples to the range owners, one verdict byte per triple back, the winners' commits
-    (`range_kernels.h` has the kernels and why the outcome is the sequential one).  Every rank works in every round, whatever
-    nb is; what the partition pays is three collectives inside every round of the ordered chain."""
+    list's rank) and never move again.  A round (list i against array (i + t) % nb, kmodel.hpp:560-565) is two all-to-alls:
+    64-bit words to the range owners -- the winners' commits of the round before, then this round's triples -- and one verdict
+    byte per word back (`range_kernels.h` has the kernels and why the outcome is the sequential one); the last round's commits
+    are flushed by one more exchange at the end.  Every rank works in every round, whatever nb is; what the partition pays is
+    two collectives (and a split-size exchange) inside every round of the ordered chain."""
     rank, world, dev = comm.rank, comm.world, counts.device
     sent0, coll0 = comm.bytes_sent, comm.collectives
     local_hist = eng.count_classes(counts)
@@ -519,14 +524,16 @@ def build_range_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: to
                     n_i = list_length(n_km, nb, b, i)
                     lists.append({"list": i, "n": n_i, "kmers": km_mine[pos:pos + n_i], "counts": cnt_mine[pos:pos + n_i]})
                     pos += n_i
-            triples, out_counts = eng.range_emit(t, lists)                              # 1. triples -> range owners
+            words, out_counts = eng.range_emit(t, lists)                                # 1. last round's commits + this round's triples -> range owners
             in_counts = comm.all_to_all_ints(out_counts, dev)
-            got = comm.all_to_all_v(triples, out_counts, in_counts)
-            ver = eng.range_verdict(t, got)                                             # 2. verdicts back, same order
+            got = comm.all_to_all_v(words, out_counts, in_counts)
+            ver = eng.range_verdict(t, got)                                             # 2. commits applied, one verdict byte per word back, same order
             back = comm.all_to_all_v(ver, in_counts, out_counts)
-            commits, c_out = eng.range_resolve(t, back)                                 # 3. the winners' commits -> range owners
-            c_in = comm.all_to_all_ints(c_out, dev)
-            eng.range_commit(t, comm.all_to_all_v(commits, c_out, c_in))
+            eng.range_resolve(t, back)                                                  # 3. winners decided; their commits wait for the next round's triples
+    if n_blocks:                                                                        # the last round's commits
+        commits, c_out = eng.range_flush()
+        c_in = comm.all_to_all_ints(c_out, dev)
+        eng.range_commit(comm.all_to_all_v(commits, c_out, c_in))
     st, rest_km, rest_cnt = eng.local()
     rest_counts = comm.all_gather_ints(int(st.rest_entries), dev)
     rest_km_all = comm.all_gather_v(rest_km, rest_counts)

@@ -33,6 +33,7 @@ class RangeOracleEngine(OracleEngine):
         self.seeds = [int(O.lib().kmo_hash_seed(i)) for i in range(128)]
         self.bin_of_occ, _ = O.occubin_table(self.cs + 1, self.nh)
         self.lists = {}                                             # list -> (kmers u64[n], counts u32[n]) in list order
+        self.pending_w, self.pending_p = np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)     # commits of the last round (words, positions)
         self.attempts = self.successes = self.n_contended = 0
         self.extra_attempts = 0
 
@@ -75,13 +76,20 @@ class RangeOracleEngine(OracleEngine):
             poss.append(pos.reshape(-1))
             self.meta.append((i, n, pos, want))
             self.attempts += n
-        w = np.concatenate(words) if words else np.zeros(0, dtype=np.int64)
-        p = np.concatenate(poss) if poss else np.zeros(0, dtype=np.int64)
+        # the commits of the round before travel in front of this round's triples (stable sort by destination keeps them there)
+        self.n_commits = len(self.pending_w)
+        w = np.concatenate([self.pending_w] + words)
+        p = np.concatenate([self.pending_p] + poss)
+        self.pending_w, self.pending_p = np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
         sent, self.order, counts = self._by_dest(w, p)
         return torch.from_numpy(sent.copy()), counts
 
-    def range_verdict(self, t, triples):
-        tr = _np(triples)
+    def range_verdict(self, t, words):
+        allw = _np(words)
+        is_commit = allw < 0                                        # bit 63
+        self.range_commit(torch.from_numpy(np.ascontiguousarray(allw[is_commit])))       # the previous round's winners first
+        ver_all = np.zeros(len(allw), dtype=np.uint8)
+        tr = allw[~is_commit]
         ver = np.zeros(len(tr), dtype=np.uint8)
         if len(tr):
             pos, want, i = tr & M36, (tr >> 36) & 1, (tr >> 37) & 15
@@ -101,12 +109,14 @@ class RangeOracleEngine(OracleEngine):
                 has1 = np.bincount(inv, weights=(want[u] == 1), minlength=len(ku)) > 0
                 both[u] = (has0 & has1)[inv]
             ver[:] = conflict.astype(np.uint8) | (untag.astype(np.uint8) << 1) | (both.astype(np.uint8) << 2)
-        return torch.from_numpy(ver)
+        ver_all[~is_commit] = ver
+        return torch.from_numpy(ver_all)
 
     def range_resolve(self, t, verdicts):
         back = _np(verdicts)
         verdict = np.empty(len(back), dtype=np.uint8)
-        verdict[self.order] = back                                  # the order the triples were generated in
+        verdict[self.order] = back                                  # the order the words were generated in: commits, then the triples
+        verdict = verdict[self.n_commits:]
         cw, cp, off = [], [], 0
         for i, n, pos, want in self.meta:
             v = verdict[off: off + n * self.nh].reshape(n, self.nh)
@@ -144,7 +154,8 @@ class RangeOracleEngine(OracleEngine):
                     key = rows.astype(np.int64) * np.int64(1 << 40) + p
                     ku, inv = np.unique(key, return_inverse=True)
                     val = (np.bincount(inv, weights=val, minlength=len(ku)) > 0)[inv].astype(np.int64)
-                cw.append(_word(p, val, i, np.zeros(len(p), dtype=np.int64), np.zeros(len(p), dtype=np.int64)))
+                a = (i + t) % self.nb                               # a commit word names its ARRAY and carries bit 63
+                cw.append(_word(p, val, a, np.zeros(len(p), dtype=np.int64), np.zeros(len(p), dtype=np.int64)) | np.int64(-(1 << 63)))
                 cp.append(p)
             km, cn = self.lists[i]
             keep = reorder(np.arange(n, dtype=np.int64), failed)
@@ -154,19 +165,22 @@ class RangeOracleEngine(OracleEngine):
                 self.rest_k.append(km2.copy())
                 self.rest_c.append(cn2.copy())
                 self.stale[i] = (km2[:1].copy(), int(cn2[0])) if len(cn2) else None
-        w = np.concatenate(cw) if cw else np.zeros(0, dtype=np.int64)
-        p = np.concatenate(cp) if cp else np.zeros(0, dtype=np.int64)
-        sent, _, counts = self._by_dest(w, p)
+        self.pending_w = np.concatenate(cw) if cw else np.zeros(0, dtype=np.int64)
+        self.pending_p = np.concatenate(cp) if cp else np.zeros(0, dtype=np.int64)
+
+    def range_flush(self):
+        sent, _, counts = self._by_dest(self.pending_w, self.pending_p)
+        self.pending_w, self.pending_p = np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
         return torch.from_numpy(sent.copy()), counts
 
-    def range_commit(self, t, commits):
+    def range_commit(self, commits):
         tr = _np(commits)
         if not len(tr):
             return
         pos, v, i = tr & M36, (tr >> 36) & 1, (tr >> 37) & 15
         for li in np.unique(i):
             msk = i == li
-            tag, val = self._bits(int((li + t) % self.nb))
+            tag, val = self._bits(int(li))
             p = pos[msk]
             np.bitwise_or.at(tag, p >> 3, (np.uint8(0x80) >> (p & 7).astype(np.uint8)))
             pv = p[v[msk] == 1]

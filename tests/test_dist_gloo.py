@@ -140,7 +140,7 @@ def test_range_partition_protocol_with_numpy_engine(spec, world, golden, tmp_pat
     for r in res:
         assert r["sha"] == {f: g["sha256"][f] for f in ("header", "km.bin", "rest.bin")}, f"rank {r['rank']} holds a different model"
         assert r["stats"][2:5] == (g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
-        assert r["info"]["partition"] == "range" and r["info"]["collectives"] >= 3 * r["info"]["blocks"]
+        assert r["info"]["partition"] == "range" and r["info"]["collectives"] >= 2 * r["info"]["blocks"]
     assert res[0]["occ_sha"] == g["occ_sha256"]
 
 

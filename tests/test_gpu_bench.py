@@ -30,7 +30,7 @@ def test_bench_two_ranks_one_line(partition):
     assert sm["partition"] == partition and sm["kmers"] == 2 * d["config"]["kmers_per_gpu"] and f"--partition {partition}" in d["config"]["parallelism"]
     assert d["scaling"].startswith("weak") and sm["bytes_exchanged_per_build"] > 0
     if partition == "range":
-        assert sm["all_to_alls_per_build"] >= 3 * sm["blocks"] * d["config"]["nb"] and sm["idle_ranks_in_the_ordered_rounds"] == 0
+        assert sm["all_to_alls_per_build"] >= 2 * sm["blocks"] * d["config"]["nb"] and sm["idle_ranks_in_the_ordered_rounds"] == 0
     else:
         assert sm["array_owners"] == 2 and sm["ring_hops_per_build"] > 0
     # one model = the sequential build of the concatenated streams: what all ranks inserted and what went to the rest table add up
