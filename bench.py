@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--single-model-steps", type=int, default=0, help="0: --steps when N > 1 (it is the headline there), 2 at N = 1")
     ap.add_argument("--partition", choices=("ring", "range"), default="ring",
                     help="how ONE model is spread over the ranks: ring = arrays owned whole, lists travel (send/recv); range = every array cut by "
-                         "position range, triples / verdicts / commits by all-to-all (the north star's partition, SURVEY.md 8e(1))")
+                         "position range, commits + triples out and verdicts back by all-to-all (the north star's partition, SURVEY.md 8e(1))")
     return ap.parse_args()
 
 

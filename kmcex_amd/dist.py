@@ -391,7 +391,7 @@ def build_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: torch.Te
     """KModel::init (kmodel.hpp:57-86) of ONE model by `comm.world` ranks.  `kmers` / `counts`: this rank's contiguous slice
     of the listing (slices in rank order = listing order).  On return every rank holds the whole model.
     `partition`: "ring" -- arrays owned whole, lists travel (module docstring); "range" -- every array cut by position
-    range, k-mers stay, triples / verdicts / commits travel by all-to-all (`build_range_sharded`).
+    range, k-mers stay, commits + triples out and verdicts back travel by all-to-all (`build_range_sharded`).
 
     Returns a dict of figures (n_km, blocks, bytes this rank sent)."""
     if partition == "range":
