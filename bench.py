@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--no-query-strings", action="store_true", help="skip the kmer_to_occ(vector<string>) leg")
     ap.add_argument("--no-single-model", action="store_true", help="skip the one-model-over-all-ranks leg")
     ap.add_argument("--single-model-steps", type=int, default=0, help="0: --steps when N > 1 (it is the headline there), 2 at N = 1")
+    ap.add_argument("--no-other-partition", action="store_true", help="N > 1: do not also time the partition that was not selected")
     ap.add_argument("--partition", choices=("ring", "range"), default="ring",
                     help="how ONE model is spread over the ranks: ring = arrays owned whole, lists travel (send/recv); range = every array cut by "
                          "position range, commits + triples out and verdicts back by all-to-all (the north star's partition, SURVEY.md 8e(1))")
@@ -477,13 +478,24 @@ def main():
         partial = {}
         if rank == 0:
             partial = headline(a, world, n, q, n_all, nq_all, t_ins, t_q, st, roof, None, extra, init_db)
-        wd = threading.Timer(300.0 + 30.0 * (a.single_model_steps + a.warmup), give_up)
+        wd = threading.Timer(400.0 + 40.0 * (a.single_model_steps + a.warmup), give_up)
         wd.daemon = True
         wd.start()
         try:
             single = single_model_leg(a, m, km, cnt, q, out, rank, world, dev, rehearsal, distributed)
         except Exception as e:  # noqa: BLE001
             single = {"error": repr(e)}
+        # N > 1: the OTHER partition too, a few builds, beside the headline (not in it): the first run on a node times both
+        if world > 1 and "value" in single and not a.no_other_partition:
+            import copy
+            b = copy.copy(a)
+            b.partition = "range" if a.partition == "ring" else "ring"
+            b.single_model_steps, b.warmup = min(a.single_model_steps, 3), 1
+            try:
+                o = single_model_leg(b, m, km, cnt, q, out, rank, world, dev, rehearsal, distributed)
+                single["other_partition"] = {k: o[k] for k in o if k not in ("what", "stats")}
+            except Exception as e:  # noqa: BLE001
+                single["other_partition"] = {"partition": b.partition, "error": repr(e)}
         done.set()
         wd.cancel()
     cpu = None

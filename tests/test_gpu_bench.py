@@ -33,6 +33,8 @@ def test_bench_two_ranks_one_line(partition):
         assert sm["all_to_alls_per_build"] >= 2 * sm["blocks"] * d["config"]["nb"] and sm["idle_ranks_in_the_ordered_rounds"] == 0
     else:
         assert sm["array_owners"] == 2 and sm["ring_hops_per_build"] > 0
+    other = sm["other_partition"]                                    # the partition that was not selected is timed beside the headline
+    assert other["partition"] != partition and other["value"] > 0 and other["kmers"] == sm["kmers"]
     # one model = the sequential build of the concatenated streams: what all ranks inserted and what went to the rest table add up
     st = sm["stats"]
     assert st["successes"] + st["rest_entries"] >= st["n_km"] and st["attempts"] >= st["n_km"]
