@@ -149,7 +149,7 @@ int kmx_range_emit_dev(kmx_model *m, int t, const kmx_ring_list *lists, int n_li
 int kmx_range_verdict_dev(kmx_model *m, int t, const uint64_t *d_words, uint64_t n, uint8_t *d_verdict);
 /* step 3, list rank: verdicts in the order the words left (regions concatenated in rank order) -> winners (the contended
  * ones decided in list order); their commits stay in the send regions for the next emit; reorder_buffer (:529-540), km_back,
- * rest.  counts[world]: the commits pending per owner rank (information: nothing is exchanged now)                      */
+ * rest.  counts[world] comes back zeroed: nothing is exchanged now, and no host wait is spent on it                    */
 int kmx_range_resolve_dev(kmx_model *m, int t, const uint8_t *d_verdict, uint64_t *counts);
 /* end of the build: what is still pending in the send regions (counts[world]) for a last exchange ...                  */
 int kmx_range_flush_dev(kmx_model *m, uint64_t *counts);

@@ -43,7 +43,7 @@ void ring_import(const ModelDev &, const BlockDev &, int, const RingLists &, u64
 void ring_export(const ModelDev &, const BlockDev &, int, const RingLists &, hipStream_t);
 void or_words(u32 *, const u32 *, u64, hipStream_t);
 void range_emit(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, bool, hipStream_t);
-void range_verdict(const ModelDev &, const BlockDev &, int, const u64 *, u64, unsigned char *, hipStream_t);
+void range_verdict(const ModelDev &, const BlockDev &, int *, int, const u64 *, u64, unsigned char *, hipStream_t);
 void range_resolve(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, const unsigned char *, hipStream_t);
 void range_commit_apply(const ModelDev &, const u64 *, u64, hipStream_t);
 void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *);
@@ -270,6 +270,7 @@ struct kmx_model {
 		BlockDev obd = {};
 		unsigned char *d_ostatus = nullptr;
 		int *d_oovf = nullptr, *h_cnt = nullptr;                   // h_cnt: pinned copy of rd.send_cnt
+		int *d_opcnt = nullptr;                                    // the owner's claim-bin counters, one per 128-byte line (k_range_verdict)
 		u64 alloc_key = 0;                                         // nb, nh, world the buffers were sized for
 	} range;
 	bool ring = false;                                         // built by several GPUs (kmx_shard_begin): this handle holds ONE rank's share
@@ -482,7 +483,7 @@ static void free_range(kmx_model *m)
 	auto &R = m->range;
 	hipFree(R.rd.send); hipFree(R.rd.send_cnt); hipFree(R.rd.tidx); hipFree(R.rd.contended); hipFree(R.rd.n_contended);
 	hipFree(R.rd.rt_key); hipFree(R.rd.rt_resv); hipFree(R.rd.rt_mark); hipFree(R.rd.rt_eidx); hipFree(R.rd.rt_um);
-	hipFree(R.d_ostatus); hipFree(R.d_oovf);
+	hipFree(R.d_ostatus); hipFree(R.d_oovf); hipFree(R.d_opcnt);
 	if (R.h_cnt) hipHostFree(R.h_cnt);
 	R = kmx_model::RangeState();
 }
@@ -2068,11 +2069,13 @@ static int kmx_range_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uin
 		TRY(dalloc(&R.rd.rt_um, slots, false, m->stream));
 		TRY(dalloc(&R.d_ostatus, slots, true, m->stream));
 		TRY(dalloc(&R.d_oovf, (u64)KMX_MAX_NB, true, m->stream));
+		TRY(dalloc(&R.d_opcnt, (u64)KMX_MAX_NB * KMX_CL_MAXBINS * KMX_CTR_STRIDE, true, m->stream));
 		HIPCHK(hipHostMalloc((void **)&R.h_cnt, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE));
 		R.alloc_key = key;
 	}
 	HIPCHK(hipMemsetAsync(R.d_ostatus, 0, (u64)nb * KMX_BUCKET, m->stream));
 	HIPCHK(hipMemsetAsync(R.d_oovf, 0, sizeof(int) * KMX_MAX_NB, m->stream));
+	HIPCHK(hipMemsetAsync(R.d_opcnt, 0, sizeof(int) * (u64)KMX_MAX_NB * KMX_CL_MAXBINS * KMX_CTR_STRIDE, m->stream));
 	R.plan.rank = rank; R.plan.world = world;
 	for (int q = 0; q <= world; q++) R.plan.cell_lo[q] = (u64)(((unsigned __int128)m->ncells * (unsigned)q) / (unsigned)world);
 	R.obd = m->bd;                                                  // (kmx_begin carved it; the claim bins are the owner's here)
@@ -2144,7 +2147,7 @@ static int kmx_range_verdict_dev_impl(kmx_model *m, int t, const uint64_t *d_tri
 	TRY(range_check(m, t));
 	if (n && (!d_triples || !d_verdict)) return fail(KMX_E_ARG, "null argument");
 	if (m->km_byte_size == 0) return KMX_OK;
-	kmxk::range_verdict(m->md, m->range.obd, t, (const u64 *)d_triples, n, d_verdict, m->stream);
+	kmxk::range_verdict(m->md, m->range.obd, m->range.d_opcnt, t, (const u64 *)d_triples, n, d_verdict, m->stream);
 	HIPCHK(hipGetLastError());
 	return KMX_OK;
 }
@@ -2161,8 +2164,7 @@ static int kmx_range_resolve_dev_impl(kmx_model *m, int t, const uint8_t *d_verd
 	const int nb = m->nb, pp = m->pp;
 	kmxk::range_resolve(m->md, m->bd, R.rd, R.plan, t, pp, d_verdict, m->stream);
 	R.pending = true;                                              // the winners' commits wait in the send regions for the next round's triples
-	HIPCHK(hipGetLastError());
-	TRY(range_counts(m, counts));
+	HIPCHK(hipGetLastError());                                     // (their counts are read with the next emit's: no host wait here)
 	const int held = (nb + R.plan.world - 1 - R.plan.rank) / R.plan.world;
 	if (held > 0) TRY(kmback_emit(m, t, pp, -1, (u64)held * KMX_BUCKET));
 	m->pp ^= 1;

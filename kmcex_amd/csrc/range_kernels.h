@@ -105,7 +105,11 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_range_emit(Mo
 }
 
 // 2a. owner: the state of every claimed position; untagged claims go to the detect bins of their list
-template <int NHM> __global__ __launch_bounds__(256) void k_range_verdict(ModelDev md, BlockDev obd, int t, const u64 *triples, u64 n, unsigned char *verdict)
+// (The bin counters of this kernel are PADDED, one per 128-byte line (pcnt[(list * bins + bin) * KMX_CTR_STRIDE]): every lane's
+// returning atomic goes to a counter of its own choosing, and with the 1280 counters of the claim bins packed into 80 lines the
+// lines serialised them -- 761 us per launch against 150 for the gathers; k_range_pack_counts hands the packed form to
+// k_round_detect.)
+template <int NHM> __global__ __launch_bounds__(256) void k_range_verdict(ModelDev md, BlockDev obd, int *pcnt, int t, const u64 *triples, u64 n, unsigned char *verdict)
 {
 	constexpr int NBIN = KMX_CL_BINS(NHM), CAP = KMX_CL_CAP_OF(NHM);
 	for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < n; q += (u64)gridDim.x * 256) {
@@ -123,12 +127,17 @@ template <int NHM> __global__ __launch_bounds__(256) void k_range_verdict(ModelD
 			v = RV_UNTAGGED;
 			const u64 mx = cl_mix(pos);
 			const u32 bin = cl_bin(mx);
-			const int g = atomicAdd(obd.cl_cnt[0] + i * KMX_CL_MAXBINS + bin, 1);
+			const int g = atomicAdd(pcnt + (i * KMX_CL_MAXBINS + bin) * KMX_CTR_STRIDE, 1);
 			if (g < CAP) obd.cl_tup[0][((u64)i * NBIN + bin) * CAP + g] = CL_TUPLE(mx, want, RT_X(tr));
 			else obd.cl_ovf[i] = 1;                                     // tuples lost: every untagged claim of the list counts as contended
 		}
 		verdict[q] = v;
 	}
+}
+__global__ __launch_bounds__(256) void k_range_pack_counts(BlockDev obd, int *pcnt, int n)
+{
+	const int q = blockIdx.x * 256 + threadIdx.x;
+	if (q < n) { obd.cl_cnt[0][q] = pcnt[q * KMX_CTR_STRIDE]; pcnt[q * KMX_CTR_STRIDE] = 0; }
 }
 // 2b. after k_round_detect on the owner's bins: a slot it marked holds a position that is wanted with both values
 __global__ __launch_bounds__(256) void k_range_verdict2(BlockDev obd, const u64 *triples, u64 n, unsigned char *verdict)
@@ -347,15 +356,17 @@ void range_emit(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, cons
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_range_emit<W, NHM>), dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, md, bd, rd, pl, t, pp));
 }
 // obd: the owner's view (scratch status, its own overflow flags; the claim bins of the handle, unused by the list side here)
-void range_verdict(const ModelDev &md, const BlockDev &obd, int t, const u64 *triples, u64 n, unsigned char *verdict, hipStream_t st)
+void range_verdict(const ModelDev &md, const BlockDev &obd, int *pcnt, int t, const u64 *triples, u64 n, unsigned char *verdict, hipStream_t st)
 {
 	if (!n) return;
 	hipLaunchKernelGGL(k_range_commit_apply, dim3(range_grid(n)), dim3(256), 0, st, md, triples, n);      // the previous round's winners first
 	if (md.nh <= 8) {
-		hipLaunchKernelGGL((k_range_verdict<8>), dim3(range_grid(n)), dim3(256), 0, st, md, obd, t, triples, n, verdict);
+		hipLaunchKernelGGL((k_range_verdict<8>), dim3(range_grid(n)), dim3(256), 0, st, md, obd, pcnt, t, triples, n, verdict);
+		hipLaunchKernelGGL(k_range_pack_counts, dim3((md.nb * KMX_CL_MAXBINS + 255) / 256), dim3(256), 0, st, obd, pcnt, md.nb * KMX_CL_MAXBINS);
 		hipLaunchKernelGGL((k_round_detect<8, 1024, KMX_CL_TBITS(8)>), dim3(KMX_CL_BINS(8), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, 0);
 	} else {
-		hipLaunchKernelGGL((k_range_verdict<16>), dim3(range_grid(n)), dim3(256), 0, st, md, obd, t, triples, n, verdict);
+		hipLaunchKernelGGL((k_range_verdict<16>), dim3(range_grid(n)), dim3(256), 0, st, md, obd, pcnt, t, triples, n, verdict);
+		hipLaunchKernelGGL(k_range_pack_counts, dim3((md.nb * KMX_CL_MAXBINS + 255) / 256), dim3(256), 0, st, obd, pcnt, md.nb * KMX_CL_MAXBINS);
 		hipLaunchKernelGGL((k_round_detect<16, 1024, KMX_CL_TBITS(16)>), dim3(KMX_CL_BINS(16), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, 0);
 	}
 	hipLaunchKernelGGL(k_range_verdict2, dim3(range_grid(n)), dim3(256), 0, st, obd, triples, n, verdict);
