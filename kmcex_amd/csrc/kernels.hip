@@ -501,6 +501,11 @@ __global__ __launch_bounds__(256) void k_block_init(BlockDev bd, int nb, int pp,
 #define CL_WANT(tp) ((u32)((tp) >> CL_POS_BITS) & 1u)
 #define CL_X(tp) ((u32)((tp) >> (CL_POS_BITS + 1)) & (KMX_BUCKET - 1))
 #define CL_MIX_BITS KMX_CL_MIX_BITS
+// position-range partition (range_kernels.h): a claim names the received triple it came from instead of a list slot -- 27 bits, 8 above
+// the 36 mixed bits and 19 above the wanted value (k_round_detect<..., RANGE> answers in that triple's verdict byte)
+#define CL_RANGE_TUPLE(mixed, want, q) ((u64)(mixed) | ((u64)((q) & 0xFFu) << CL_MIX_BITS) | ((u64)(want) << CL_POS_BITS) | ((u64)((q) >> 8) << (CL_POS_BITS + 1)))
+#define CL_RQ(tp) (((u32)((tp) >> CL_MIX_BITS) & 0xFFu) | ((u32)((tp) >> (CL_POS_BITS + 1)) << 8))
+static_assert(KMX_RANGE_QBITS == 8 + 19 && CL_MIX_BITS + 8 <= CL_POS_BITS, "8 bits above the mixed position + the 19 bits above the wanted value");
 #define CL_FP_BITS (CL_MIX_BITS - 8)
 static_assert(KMX_CL_BINS_LOG2(8) == 8 && KMX_CL_BINS_LOG2(16) == 8 && CL_FP_BITS + 4 == 32, "bin (8 bits) + fingerprint (28 bits) = the mixed position; an entry = fingerprint + 4 flags");
 // multiply by an odd constant and xor-shift right are bijections on 36-bit integers: distinct positions below 2^36 get
@@ -716,12 +721,17 @@ __device__ __forceinline__ void dt_settle(u32 *s_t, u32 tmask, u64 d, const unsi
 	const int slot = dt_find(s_t, tmask, cl_fp(CL_MIXED(d)));
 	if (slot >= 0 && dstatus[CL_X(d)] == SLOT_UNDECIDED) atomicOr(&s_t[slot], DT_SETTLED(CL_WANT(d)));
 }
-__device__ __forceinline__ void dt_lookup(const u32 *s_t, u32 tmask, u64 e, unsigned char *status, unsigned char *dfail)
+// RANGE (the owner of a position range, range_kernels.h): no settled positions there, and the contention is reported per CLAIM --
+// in the verdict byte of the triple the claim came from (it was 2 = untagged; 2 | 4 = untagged, wanted with both values) --
+// because the list rank orders its contended candidates on the both-wanted positions alone
+template <bool RANGE = false>
+__device__ __forceinline__ void dt_lookup(const u32 *s_t, u32 tmask, u64 e, unsigned char *status, unsigned char *dfail, unsigned char *rverdict = nullptr)
 {
 	const u32 fp = cl_fp(CL_MIXED(e));
 	u32 slot = fp & tmask, cur;
 	while (((cur = s_t[slot]) >> 4) != fp) slot = (slot + 1) & tmask;  // (it was inserted in phase 1)
 	const u32 w = CL_WANT(e);
+	if (RANGE) { if ((cur >> (w ^ 1u)) & 1u) rverdict[CL_RQ(e)] = 2 | 4; return; }
 	if (cur & 12u) { if (w != ((cur >> 3) & 1u)) dfail[CL_X(e)] = 1; }             // tagged meanwhile with the other value (two winners never settle
 	else if ((cur >> (w ^ 1u)) & 1u) status[CL_X(e)] = SLOT_CONTENDED;             // different values; one that hits it twice leaves the OR: 1)
 }
@@ -732,7 +742,7 @@ __device__ __forceinline__ void dt_lookup(const u32 *s_t, u32 tmask, u64 e, unsi
 // for the late rounds, whose bins hold a few hundred tuples: a launch of it is one generation of workgroups instead of three.
 // A bin that does not fit a small table raises cl_ovf[i] -- the whole list takes the ordered path, exact like any other
 // overflow -- and reports its fill (`late`: ST_MAX_LATE_BIN), from which the host decides which form the late rounds get.
-template <int NHM, int BT, int TBITS> __global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(NHM <= 8 ? 8 : 4)))
+template <int NHM, int BT, int TBITS, bool RANGE = false> __global__ __launch_bounds__(BT) __attribute__((amdgpu_waves_per_eu(NHM <= 8 ? 8 : 4)))
 void k_round_detect(BlockDev bd, int nb, int pp, int use_delta, int keep_own, int late)
 {
 	constexpr int NBIN = KMX_CL_BINS(NHM), T = 1 << TBITS, CAP = KMX_CL_CAP_OF(NHM), TCAP = T / 4 * 3;
@@ -740,9 +750,9 @@ void k_round_detect(BlockDev bd, int nb, int pp, int use_delta, int keep_own, in
 	__shared__ u32 s_t[T];                                           // exactly 64 KB at nh <= 8 (full size): two workgroups per CU
 	const int i = (int)blockIdx.y, b = blockIdx.x;
 	const int id = (i + 1) % nb;                                     // list that visited this array one round earlier
-	int *gc = bd.cl_cnt[pp] + i * KMX_CL_MAXBINS + b;
+	int *gc = bd.cl_cnt[pp] + (i * KMX_CL_MAXBINS + b) * (RANGE ? KMX_CTR_STRIDE : 1);   // (RANGE: one counter per 128-byte line, k_range_verdict)
 	int *gd = bd.cl_cnt[pp ^ 1] + id * KMX_CL_MAXBINS + b;
-	int cnt = *gc, dcnt = *gd;
+	int cnt = *gc, dcnt = RANGE ? 0 : *gd;
 	if (late && threadIdx.x == 0 && cnt > 1024) atomicMax(bd.stats + ST_MAX_LATE_BIN, (u64)cnt);
 	if (cnt > CAP) cnt = CAP;                                        // check_emit has raised cl_ovf[i]
 	if (cnt > TCAP) {                                                // (small form only) the bin does not fit: the list takes the ordered path
@@ -756,6 +766,7 @@ void k_round_detect(BlockDev bd, int nb, int pp, int use_delta, int keep_own, in
 		const u64 *dp = bd.cl_tup[pp ^ 1] + ((u64)id * NBIN + b) * CAP;
 		const unsigned char *dstatus = bd.status[pp ^ 1] + (u64)id * KMX_BUCKET;
 		unsigned char *status = bd.status[pp] + (u64)i * KMX_BUCKET, *dfail = bd.dfail + (u64)i * KMX_BUCKET;
+		unsigned char *rverdict = RANGE ? bd.rverdict : nullptr;
 		int tb = TBITS < 10 ? TBITS : 10;
 		while ((1 << tb) < 4 * cnt && tb < TBITS) tb++;              // load <= 1/4 (<= 3/4 for a full bin): short probe chains
 		const u32 tmask = (1u << tb) - 1;
@@ -777,19 +788,19 @@ void k_round_detect(BlockDev bd, int nb, int pp, int use_delta, int keep_own, in
 				__syncthreads();
 			}
 #pragma unroll
-			for (int u = 0; u < U; u++) if (e[u] != ~0ULL) dt_lookup(s_t, tmask, e[u], status, dfail);
+			for (int u = 0; u < U; u++) if (e[u] != ~0ULL) dt_lookup<RANGE>(s_t, tmask, e[u], status, dfail, rverdict);
 		} else {
 			__syncthreads();
 			for (int q = threadIdx.x; q < cnt; q += BT) { const u64 e = tp[q]; dt_insert(s_t, tmask, cl_fp(CL_MIXED(e)), 1u << CL_WANT(e)); }
 			__syncthreads();
 			for (int q = threadIdx.x; q < dcnt; q += BT) dt_settle(s_t, tmask, dp[q], dstatus);
 			__syncthreads();
-			for (int q = threadIdx.x; q < cnt; q += BT) dt_lookup(s_t, tmask, tp[q], status, dfail);
+			for (int q = threadIdx.x; q < cnt; q += BT) dt_lookup<RANGE>(s_t, tmask, tp[q], status, dfail, rverdict);
 		}
 	}
 	// (every thread has read the counters: barriers above, or nothing else happened)
 	if (threadIdx.x == 0) {
-		*gd = 0;                                                     // last reader of the previous round's bin: ready for round r+1
+		if (!RANGE) *gd = 0;                                         // last reader of the previous round's bin: ready for round r+1
 		if (!keep_own) *gc = 0;                                      // nobody will read this round's tuples again
 	}
 }
@@ -1863,6 +1874,7 @@ template <int W> __global__ __launch_bounds__(256) void k_ring_import(BlockDev b
 			stg_counts[row + x] = src_c[x];
 		}
 		bd.list[pp][row + x] = (u32)x;
+		bd.surv[row + x] = 0;                                     // (the range partition emits km_back once per block, from the survivor flags)
 	}
 	if (x < (int)KMX_NTILES) { bd.tile_cnt[0][i * KMX_NTILES + x] = 0; bd.tile_cnt[1][i * KMX_NTILES + x] = 0; }
 	if (x == 0) {

@@ -261,17 +261,17 @@ struct kmx_model {
 		hipEvent_t ev_in[S] = {nullptr, nullptr, nullptr}, ev_k[S] = {nullptr, nullptr, nullptr}, ev_out[S] = {nullptr, nullptr, nullptr};
 	} qfeed;
 	// position-range partition over several GPUs (kmx_range_*): this rank's exchange buffers, its resolver tables, and the
-	// owner-side view of the block working set (scratch status + overflow flags for the detect kernel on received claims)
+	// owner-side view of the block working set (overflow flags + padded bin counters for the detect kernel on received claims)
 	struct RangeState {
 		bool on = false;
 		bool pending = false;                                      // the send regions hold the last round's commits: the next emit appends to them
 		RangeDev rd = {};
 		RangePlan plan = {};
 		BlockDev obd = {};
-		unsigned char *d_ostatus = nullptr;
 		int *d_oovf = nullptr, *h_cnt = nullptr;                   // h_cnt: pinned copy of rd.send_cnt
 		int *d_opcnt = nullptr;                                    // the owner's claim-bin counters, one per 128-byte line (k_range_verdict)
 		u64 alloc_key = 0;                                         // nb, nh, world the buffers were sized for
+		int n0[KMX_MAX_NB] = {};                                   // entries of the held lists when the block came in (km_back is emitted once per block)
 	} range;
 	bool ring = false;                                         // built by several GPUs (kmx_shard_begin): this handle holds ONE rank's share
 	int ring_rank = 0, ring_world = 1;
@@ -483,7 +483,7 @@ static void free_range(kmx_model *m)
 	auto &R = m->range;
 	hipFree(R.rd.send); hipFree(R.rd.send_cnt); hipFree(R.rd.tidx); hipFree(R.rd.contended); hipFree(R.rd.n_contended);
 	hipFree(R.rd.rt_key); hipFree(R.rd.rt_resv); hipFree(R.rd.rt_mark); hipFree(R.rd.rt_eidx); hipFree(R.rd.rt_um);
-	hipFree(R.d_ostatus); hipFree(R.d_oovf); hipFree(R.d_opcnt);
+	hipFree(R.d_oovf); hipFree(R.d_opcnt);
 	if (R.h_cnt) hipHostFree(R.h_cnt);
 	R = kmx_model::RangeState();
 }
@@ -2067,19 +2067,18 @@ static int kmx_range_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uin
 		TRY(dalloc(&R.rd.rt_mark, held << R.rd.rt_bits, false, m->stream));
 		TRY(dalloc(&R.rd.rt_eidx, slots * nh, false, m->stream));
 		TRY(dalloc(&R.rd.rt_um, slots, false, m->stream));
-		TRY(dalloc(&R.d_ostatus, slots, true, m->stream));
 		TRY(dalloc(&R.d_oovf, (u64)KMX_MAX_NB, true, m->stream));
 		TRY(dalloc(&R.d_opcnt, (u64)KMX_MAX_NB * KMX_CL_MAXBINS * KMX_CTR_STRIDE, true, m->stream));
 		HIPCHK(hipHostMalloc((void **)&R.h_cnt, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE));
 		R.alloc_key = key;
 	}
-	HIPCHK(hipMemsetAsync(R.d_ostatus, 0, (u64)nb * KMX_BUCKET, m->stream));
 	HIPCHK(hipMemsetAsync(R.d_oovf, 0, sizeof(int) * KMX_MAX_NB, m->stream));
+	HIPCHK(hipMemsetAsync(R.rd.n_contended, 0, sizeof(int) * KMX_MAX_NB * KMX_CTR_STRIDE, m->stream));   // (k_range_resolve leaves them zero round by round)
 	HIPCHK(hipMemsetAsync(R.d_opcnt, 0, sizeof(int) * (u64)KMX_MAX_NB * KMX_CL_MAXBINS * KMX_CTR_STRIDE, m->stream));
 	R.plan.rank = rank; R.plan.world = world;
 	for (int q = 0; q <= world; q++) R.plan.cell_lo[q] = (u64)(((unsigned __int128)m->ncells * (unsigned)q) / (unsigned)world);
 	R.obd = m->bd;                                                  // (kmx_begin carved it; the claim bins are the owner's here)
-	R.obd.status[0] = R.obd.status[1] = R.d_ostatus;
+	R.obd.cl_cnt[0] = R.obd.cl_cnt[1] = R.d_opcnt;                  // (its detect reads the padded counters and reports per claim, in the verdict bytes)
 	R.obd.cl_ovf = R.d_oovf;
 	R.on = true;
 	R.pending = false;
@@ -2124,6 +2123,7 @@ static int kmx_range_emit_dev_impl(kmx_model *m, int t, const kmx_ring_list *lis
 			r.active = 1; r.n_host = l.n_host;
 			r.src_kmers = (const u64 *)l.src_kmers; r.src_counts = (const u32 *)l.src_counts;
 		}
+		for (int i = 0; i < m->nb; i++) R.n0[i] = rl.e[i].active ? rl.e[i].n_host : 0;
 		kmxk::ring_import(m->md, m->bd, m->pp, rl, m->d_stg_kmers, m->d_stg_counts, m->stream);
 	}
 	kmxk::range_emit(m->md, m->bd, R.rd, R.plan, t, m->pp, !R.pending, m->stream);
@@ -2146,6 +2146,7 @@ static int kmx_range_verdict_dev_impl(kmx_model *m, int t, const uint64_t *d_tri
 {
 	TRY(range_check(m, t));
 	if (n && (!d_triples || !d_verdict)) return fail(KMX_E_ARG, "null argument");
+	if (n >> KMX_RANGE_QBITS) return fail(KMX_E_ARG, "a round's exchange holds up to 2^%d words", KMX_RANGE_QBITS);   // (a claim tuple names its triple in that many bits)
 	if (m->km_byte_size == 0) return KMX_OK;
 	kmxk::range_verdict(m->md, m->range.obd, m->range.d_opcnt, t, (const u64 *)d_triples, n, d_verdict, m->stream);
 	HIPCHK(hipGetLastError());
@@ -2165,14 +2166,18 @@ static int kmx_range_resolve_dev_impl(kmx_model *m, int t, const uint8_t *d_verd
 	kmxk::range_resolve(m->md, m->bd, R.rd, R.plan, t, pp, d_verdict, m->stream);
 	R.pending = true;                                              // the winners' commits wait in the send regions for the next round's triples
 	HIPCHK(hipGetLastError());                                     // (their counts are read with the next emit's: no host wait here)
-	const int held = (nb + R.plan.world - 1 - R.plan.rank) / R.plan.world;
-	if (held > 0) TRY(kmback_emit(m, t, pp, -1, (u64)held * KMX_BUCKET));
 	m->pp ^= 1;
 	m->rounds++;
 	if (t == nb - 1) {
+		// the lists never leave their rank: survivors -> rest table, then km_back ONCE for the block -- every k-mer of a held list
+		// that is not a survivor was inserted in one of the rounds (kmodel.hpp:548-550), as in the single-GPU build
 		for (int i = R.plan.rank; i < nb; i += R.plan.world) {
 			TRY(ensure_rest_capacity(m, (u64)KMX_BUCKET + (u64)nb));
 			kmxk::rest_append(m->md, m->bd, m->pp, i, 1, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream);
+			if (R.n0[i] > 0) {
+				if (m->kmb_deferred) TRY(kmback_reserve(m, (u64)R.n0[i]));
+				kmxk::kmback_emit(m->md, m->bd, m->bd.kmers, m->bd.surv, i, 1, 0, m->pp, i * (int)KMX_BUCKET + R.n0[i], m->kmb, m->stream);
+			}
 		}
 		m->blocks++;
 	}

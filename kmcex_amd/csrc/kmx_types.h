@@ -127,6 +127,8 @@ struct BlockDev {
 	int *cl_cnt[2];          // [nb][KMX_CL_MAXBINS] tuples per bin; a round's counts are reset by the NEXT round's k_round_detect, which reads
 	                         // the tuples once more as the delta of the still-uncommitted winners
 	int *cl_ovf;             // [nb] a bin of the list overflowed: every candidate of the round takes the ordered path (reset by k_reorder)
+	unsigned char *rverdict; // position-range partition, owner's view only: the verdict bytes of the triples it received this round -- a claim
+	                         // on a position wanted with both values is reported there (k_round_detect<..., RANGE>); null elsewhere
 };
 
 // claim partition: bins per list and slots of the LDS table of one bin (kernels.hip, "claims as a partitioned stream")
@@ -163,6 +165,7 @@ struct RingLists { RingList e[KMX_MAX_NB]; };
 
 // ---- the position-range partition of the coupled arrays over several GPUs (range_kernels.h)
 #define KMX_MAX_RANKS 16
+#define KMX_RANGE_QBITS 27                     // a claim tuple on the owner names the received triple it came from in this many bits (kernels.hip CL_RANGE_TUPLE)
 struct RangePlan {
 	int rank, world;
 	u64 cell_lo[KMX_MAX_RANKS + 1];   // rank q owns the cells [cell_lo[q], cell_lo[q+1]) -- 16 positions each -- of every array
@@ -178,7 +181,7 @@ struct RangeDev {
 	u64 *rt_key;
 	u32 *rt_resv, *rt_mark;
 	u32 *rt_eidx;            // [nb*BUCKET][nh]
-	u32 *rt_um;              // [nb*BUCKET]
+	u32 *rt_um;              // [nb*BUCKET] per contended record (same index as `contended`): its positions wanted with both values
 	u32 rt_bits;
 };
 

@@ -107,8 +107,8 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_range_emit(Mo
 // 2a. owner: the state of every claimed position; untagged claims go to the detect bins of their list
 // (The bin counters of this kernel are PADDED, one per 128-byte line (pcnt[(list * bins + bin) * KMX_CTR_STRIDE]): every lane's
 // returning atomic goes to a counter of its own choosing, and with the 1280 counters of the claim bins packed into 80 lines the
-// lines serialised them -- 761 us per launch against 150 for the gathers; k_range_pack_counts hands the packed form to
-// k_round_detect.)
+// lines serialised them -- 761 us per launch against 150 for the gathers; k_round_detect<..., RANGE> reads and resets the padded
+// form.  A claim tuple names the triple it came from, so that detect answers in that triple's verdict byte.)
 template <int NHM> __global__ __launch_bounds__(256) void k_range_verdict(ModelDev md, BlockDev obd, int *pcnt, int t, const u64 *triples, u64 n, unsigned char *verdict)
 {
 	constexpr int NBIN = KMX_CL_BINS(NHM), CAP = KMX_CL_CAP_OF(NHM);
@@ -128,26 +128,23 @@ template <int NHM> __global__ __launch_bounds__(256) void k_range_verdict(ModelD
 			const u64 mx = cl_mix(pos);
 			const u32 bin = cl_bin(mx);
 			const int g = atomicAdd(pcnt + (i * KMX_CL_MAXBINS + bin) * KMX_CTR_STRIDE, 1);
-			if (g < CAP) obd.cl_tup[0][((u64)i * NBIN + bin) * CAP + g] = CL_TUPLE(mx, want, RT_X(tr));
+			if (g < CAP) obd.cl_tup[0][((u64)i * NBIN + bin) * CAP + g] = CL_RANGE_TUPLE(mx, want, q);
 			else obd.cl_ovf[i] = 1;                                     // tuples lost: every untagged claim of the list counts as contended
 		}
 		verdict[q] = v;
 	}
 }
-__global__ __launch_bounds__(256) void k_range_pack_counts(BlockDev obd, int *pcnt, int n)
+// 2b. k_round_detect<..., RANGE> on the owner's bins has marked the claims that sit on positions wanted with both values.  What
+// is left for this kernel is the rare overflow: a bin lost tuples (or does not fit its table), so every untagged claim of that
+// list counts as contended.
+__global__ __launch_bounds__(256) void k_range_verdict2(BlockDev obd, int nb, const u64 *triples, u64 n, unsigned char *verdict)
 {
-	const int q = blockIdx.x * 256 + threadIdx.x;
-	if (q < n) { obd.cl_cnt[0][q] = pcnt[q * KMX_CTR_STRIDE]; pcnt[q * KMX_CTR_STRIDE] = 0; }
-}
-// 2b. after k_round_detect on the owner's bins: a slot it marked holds a position that is wanted with both values
-__global__ __launch_bounds__(256) void k_range_verdict2(BlockDev obd, const u64 *triples, u64 n, unsigned char *verdict)
-{
+	bool any = false;
+	for (int i = 0; i < nb; i++) any |= obd.cl_ovf[i] != 0;             // uniform
+	if (!any) return;
 	for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < n; q += (u64)gridDim.x * 256) {
 		const unsigned char v = verdict[q];
-		if (!(v & RV_UNTAGGED)) continue;
-		const u64 tr = triples[q];
-		const u32 i = RT_LIST(tr);
-		if (obd.status[0][(u64)i * KMX_BUCKET + RT_X(tr)] == SLOT_CONTENDED || obd.cl_ovf[i]) verdict[q] = v | RV_BOTH;
+		if ((v & RV_UNTAGGED) && obd.cl_ovf[RT_LIST(triples[q])]) verdict[q] = v | RV_BOTH;
 	}
 }
 
@@ -167,6 +164,7 @@ template <int NHM> __global__ __launch_bounds__(256) void k_range_apply(ModelDev
 	__syncthreads();
 	const u64 row = (u64)i * KMX_BUCKET;
 	bool failed = false, contended = false;
+	u32 both_of_slot = 0;
 	if (x < n) {
 		u32 um = 0, both = 0;
 #pragma unroll
@@ -179,128 +177,243 @@ template <int NHM> __global__ __launch_bounds__(256) void k_range_apply(ModelDev
 				both |= (v & RV_BOTH) ? 1u << j : 0u;
 			}
 		contended = !failed && both != 0;
+		both_of_slot = both;
 		bd.uw[pp][row + x] |= um;
 		if (failed) bd.status[pp][row + x] = SLOT_FAILED;
 	}
 	const u64 fm = __ballot(failed);
 	if ((threadIdx.x & 63) == 0 && fm) atomicAdd(&s_fail, (int)__popcll(fm));
 	const int slot = block_append_slot(rd.n_contended + i * KMX_CTR_STRIDE, contended, &s_cnt, &s_base);
-	if (contended) rd.contended[row + slot] = (u32)x;
+	if (contended) { rd.contended[row + slot] = (u32)x; rd.rt_um[row + slot] = both_of_slot; }
 	if (threadIdx.x == 0 && s_fail) atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (int)(blockIdx.x >> 2), s_fail);   // survivors per 1024-slot tile (k_reorder)
 }
 
-// 3b. the contended candidates of a list, in list order, from the verdicts alone.  ONE workgroup per list; an exact
-// position table in global memory (open addressing on the position itself): a record reserves every position it still
-// believes untagged with its priority (smaller slot first); whoever holds all of its positions has no earlier undecided
-// record on any of them -- it wins and MARKS them with the value it commits (a k-mer that hits a position twice leaves the
-// OR, kmodel.hpp:611-618); a record that meets a mark with the other value has failed, with its own value the position
-// leaves its mask.  The smallest undecided slot wins every iteration, and a later record can never win a position an
-// earlier undecided one still wants, so the outcome is the sequential one (the scheme of finish_lds, without its size limit).
+// 3b. the contended candidates of a list, in list order, from the verdicts alone.  ONE workgroup per list.  Only the
+// positions the owners reported as wanted with BOTH values take part (rt_um: bit j of a record): on any other untagged
+// position every claim of the round wants the same value, so whoever wins it leaves what the others want there -- it can
+// neither fail a record nor be lost by one.  An exact position table (open addressing on the position itself): a record
+// reserves every both-wanted position it still believes untagged with its priority (smaller slot first); whoever holds all
+// of its positions has no earlier undecided record on any of them -- it wins and MARKS them with the value it commits (a
+// k-mer that hits a position twice leaves the OR, kmodel.hpp:611-618); a record that meets a mark with the other value has
+// failed, with its own value the position leaves its mask.  The smallest undecided slot wins every iteration, and a later
+// record can never win a position an earlier undecided one still wants, so the outcome is the sequential one (the scheme
+// of finish_lds).  Up to 2048 records on 2048 positions are decided in LDS with their state in registers (the usual case:
+// a few hundred records per list and round); larger sets use the table in global memory, without a size limit.
 __device__ __forceinline__ u32 rt_hash(u64 pos) { return (u32)((pos * 0x9E3779B97F4A7C15ULL) >> 32); }
-template <int NHM> __global__ __launch_bounds__(1024) void k_range_resolve(ModelDev md, BlockDev bd, RangeDev rd, int world, int pp)
+constexpr int RT_LDS_BITS = 12, RT_LDS = 1 << RT_LDS_BITS, RT_RPT = 2;        // 4096 entries: key | mark in one u64 (32 KB) + reservations (16 KB)
+#define RT_LDS_MARK(v) (1ULL << (62 + (v)))
+template <int NHM> __device__ __forceinline__ u64 range_resolve_lds(const ModelDev &md, const BlockDev &bd, int pp, int i, u64 row, int nc, const u32 *cont, const u32 *bothm,
+                                                                    u64 *s_key, u32 *s_resv, int *s_pending, int *s_succ)
 {
-	__shared__ int s_pending, s_succ;
-	const int i = blockIdx.x, tab = i / world;                          // the lists a rank holds are i = rank, rank + world, ...: one table each
-	const int nc = rd.n_contended[i * KMX_CTR_STRIDE];
-	if (nc == 0) return;
-	const u64 row = (u64)i * KMX_BUCKET;
-	int tb = 10;
-	while ((1u << tb) < 4u * (u32)nc * (u32)md.nh && tb < (int)rd.rt_bits) tb++;
-	const u32 tmask = (1u << tb) - 1;
-	u64 *key = rd.rt_key + ((u64)tab << rd.rt_bits);
-	u32 *resv = rd.rt_resv + ((u64)tab << rd.rt_bits), *mark = rd.rt_mark + ((u64)tab << rd.rt_bits);
-	u32 *eidx = rd.rt_eidx + row * (u64)md.nh, *cur = rd.rt_um + row;     // per record: table entry of each position / mask still believed untagged | live
-	const u32 *cont = rd.contended + row;
-	constexpr u32 LIVE = 1u << 31;
-	for (u32 q = threadIdx.x; q <= tmask; q += 1024) { key[q] = 0; resv[q] = 0; mark[q] = 0; }
-	if (threadIdx.x == 0) { s_succ = 0; atomicAdd(bd.stats + ST_CONTENDED, (u64)nc); atomicMax(bd.stats + ST_MAX_U0, (u64)nc); }
-	drain_vmem();
+	constexpr u32 TM = RT_LDS - 1;
+	for (int q = threadIdx.x; q < RT_LDS; q += 1024) { s_key[q] = 0; s_resv[q] = 0; }
 	__syncthreads();
-	for (int r = threadIdx.x; r < nc; r += 1024) {
-		const u32 x = cont[r];
-		const u32 um = bd.uw[pp][row + x] & 0xFFFFu;
-		const CRec<NHM> cr = crec_load<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh);
+	u32 x[RT_RPT], c[RT_RPT], want[RT_RPT];
+	bool live[RT_RPT];
+	unsigned short e[RT_RPT][NHM];
+#pragma unroll
+	for (int k = 0; k < RT_RPT; k++) {
+		const int r = (int)threadIdx.x + k * 1024;
+		live[k] = r < nc;
+		x[k] = c[k] = want[k] = 0;
+#pragma unroll
+		for (int j = 0; j < NHM; j++) e[k][j] = 0;
+		if (!live[k]) continue;
+		x[k] = cont[r];
+		c[k] = bothm[r] & 0xFFFFu;
+		want[k] = bd.uw[pp][row + x[k]] >> 16;
+		const CRec<NHM> cr = crec_load<NHM>(bd.crec[pp] + (row + x[k]) * (u64)crec_words(md.nh), md.nh);
 #pragma unroll
 		for (int j = 0; j < NHM; j++)
-			if (j < md.nh && ((um >> j) & 1u)) {
+			if (j < md.nh && ((c[k] >> j) & 1u)) {
 				const u64 pos = ((u64)crec_cell<NHM>(cr, j) << 4) | crec_nib<NHM>(cr, md.nh, j);
-				u32 e = rt_hash(pos) & tmask;
-				for (;;) {
-					const u64 old = atomicCAS(&key[e], 0ULL, pos + 1);
+				u32 q = rt_hash(pos) & TM;
+				for (;;) {                                               // (at most 2048 positions in 4096 entries: a free one always exists)
+					const u64 old = atomicCAS(&s_key[q], 0ULL, pos + 1);
 					if (old == 0 || old == pos + 1) break;
-					e = (e + 1) & tmask;
+					q = (q + 1) & TM;
 				}
-				eidx[(u64)r * md.nh + j] = e;
+				e[k][j] = (unsigned short)q;
 			}
-		cur[r] = um | LIVE;
 	}
-	drain_vmem();
 	__syncthreads();
 	u64 iters = 0;
 	for (;; iters++) {
-		if (threadIdx.x == 0) s_pending = 0;
-		for (int r = threadIdx.x; r < nc; r += 1024) {                 // 1: reserve
-			const u32 c = cur[r];
-			if (!(c & LIVE)) continue;
-			const u32 prio = 0x40000u - cont[r];
+		if (threadIdx.x == 0) *s_pending = 0;
 #pragma unroll
-			for (int j = 0; j < NHM; j++)
-				if (j < md.nh && ((c >> j) & 1u)) atomicMax(&resv[eidx[(u64)r * md.nh + j]], prio);
-		}
-		drain_vmem();
+		for (int k = 0; k < RT_RPT; k++)                                 // 1: reserve
+			if (live[k]) {
+				const u32 prio = 0x40000u - x[k];
+#pragma unroll
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh && ((c[k] >> j) & 1u)) atomicMax(&s_resv[e[k][j]], prio);
+			}
 		__syncthreads();
 		int succ = 0;
-		for (int r = threadIdx.x; r < nc; r += 1024) {                 // 2: whoever holds everything wins and marks
-			const u32 c = cur[r];
-			if (!(c & LIVE)) continue;
-			const u32 x = cont[r], prio = 0x40000u - x, want = bd.uw[pp][row + x] >> 16;
-			bool mine = true;
 #pragma unroll
-			for (int j = 0; j < NHM; j++)
-				if (j < md.nh && ((c >> j) & 1u)) mine &= cell_load_coherent(&resv[eidx[(u64)r * md.nh + j]]) == prio;
-			if (!mine) continue;
+		for (int k = 0; k < RT_RPT; k++)                                 // 2: whoever holds everything wins and marks
+			if (live[k]) {
+				const u32 prio = 0x40000u - x[k];
+				bool mine = true;
 #pragma unroll
-			for (int j = 0; j < NHM; j++)
-				if (j < md.nh && ((c >> j) & 1u)) {
-					const u32 e = eidx[(u64)r * md.nh + j];
-					u32 v = (want >> j) & 1u;
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh && ((c[k] >> j) & 1u)) mine &= s_resv[e[k][j]] == prio;
+				if (!mine) continue;
 #pragma unroll
-					for (int j2 = 0; j2 < NHM; j2++)
-						if (j2 < md.nh && j2 != j && ((c >> j2) & 1u) && eidx[(u64)r * md.nh + j2] == e) v |= (want >> j2) & 1u;
-					atomicOr(&mark[e], 1u << v);
-				}
-			bd.status[pp][row + x] = SLOT_INSERTED;
-			cur[r] = 0;
-			succ++;
-		}
-		if (succ) atomicAdd(&s_succ, succ);
-		drain_vmem();
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh && ((c[k] >> j) & 1u)) {
+						u32 v = (want[k] >> j) & 1u;
+#pragma unroll
+						for (int j2 = 0; j2 < NHM; j2++)
+							if (j2 < md.nh && j2 != j && ((c[k] >> j2) & 1u) && e[k][j2] == e[k][j]) v |= (want[k] >> j2) & 1u;
+						atomicOr(&s_key[e[k][j]], RT_LDS_MARK(v));
+					}
+				bd.status[pp][row + x[k]] = SLOT_INSERTED;
+				live[k] = false;
+				succ++;
+			}
+		if (succ) atomicAdd(s_succ, succ);
 		__syncthreads();
-		for (int r = threadIdx.x; r < nc; r += 1024) {                 // 3: what the winners marked
-			u32 c = cur[r];
-			if (!(c & LIVE)) continue;
-			const u32 x = cont[r], want = bd.uw[pp][row + x] >> 16;
-			bool conflict = false;
 #pragma unroll
-			for (int j = 0; j < NHM; j++)
-				if (j < md.nh && ((c >> j) & 1u)) {
-					const u32 e = eidx[(u64)r * md.nh + j];
-					const u32 mk = cell_load_coherent(&mark[e]);
-					if (mk) { conflict |= ((mk >> 1) & 1u) != ((want >> j) & 1u); c &= ~(1u << j); }
-					else resv[e] = 0;                                    // everybody who still wants it reserves it again
-				}
-			if (conflict) { mark_failed(bd, pp, i, row, x); cur[r] = 0; }
-			else { cur[r] = c; s_pending = 1; }
-		}
-		drain_vmem();
+		for (int k = 0; k < RT_RPT; k++)                                 // 3: what the winners marked
+			if (live[k]) {
+				bool conflict = false;
+#pragma unroll
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh && ((c[k] >> j) & 1u)) {
+						const u32 mk = (u32)(s_key[e[k][j]] >> 62);
+						if (mk) { conflict |= ((mk >> 1) & 1u) != ((want[k] >> j) & 1u); c[k] &= ~(1u << j); }
+						else s_resv[e[k][j]] = 0;                        // everybody who still wants it reserves it again
+					}
+				if (conflict) { mark_failed(bd, pp, i, row, x[k]); live[k] = false; }
+				else *s_pending = 1;
+			}
 		__syncthreads();
-		const int pending = s_pending;
+		const int pending = *s_pending;
 		__syncthreads();
 		if (!pending) break;
+	}
+	return iters;
+}
+template <int NHM> __global__ __launch_bounds__(1024) void k_range_resolve(ModelDev md, BlockDev bd, RangeDev rd, int world, int pp)
+{
+	__shared__ int s_pending, s_succ, s_ent;
+	__shared__ u64 s_key[RT_LDS];
+	__shared__ u32 s_resv[RT_LDS];
+	const int i = blockIdx.x, tab = i / world;                          // the lists a rank holds are i = rank, rank + world, ...: one table each
+	const int nc = rd.n_contended[i * KMX_CTR_STRIDE];
+	if (blockIdx.x == 0 && (int)threadIdx.x < world) rd.send_cnt[threadIdx.x * KMX_CTR_STRIDE] = 0;   // k_range_apply has read where the triples went: the regions now take the winners' commits
+	if (nc == 0) return;
+	const u64 row = (u64)i * KMX_BUCKET;
+	const u32 *cont = rd.contended + row;
+	u32 *cur = rd.rt_um + row;                                          // per record: mask of both-wanted positions still believed untagged (| live)
+	if (threadIdx.x == 0) { s_succ = 0; s_ent = 0; atomicAdd(bd.stats + ST_CONTENDED, (u64)nc); atomicMax(bd.stats + ST_MAX_U0, (u64)nc); }
+	__syncthreads();
+	{
+		int ent = 0;
+		for (int r = threadIdx.x; r < nc; r += 1024) ent += __popc(cur[r] & 0xFFFFu);
+		if (ent) atomicAdd(&s_ent, ent);
+	}
+	__syncthreads();
+	u64 iters = 0;
+	if (nc <= 1024 * RT_RPT && s_ent * 2 <= RT_LDS) iters = range_resolve_lds<NHM>(md, bd, pp, i, row, nc, cont, cur, s_key, s_resv, &s_pending, &s_succ);
+	else {
+		int tb = 10;
+		while ((1u << tb) < 4u * (u32)nc * (u32)md.nh && tb < (int)rd.rt_bits) tb++;
+		const u32 tmask = (1u << tb) - 1;
+		u64 *key = rd.rt_key + ((u64)tab << rd.rt_bits);
+		u32 *resv = rd.rt_resv + ((u64)tab << rd.rt_bits), *mark = rd.rt_mark + ((u64)tab << rd.rt_bits);
+		u32 *eidx = rd.rt_eidx + row * (u64)md.nh;                      // per record: table entry of each position
+		constexpr u32 LIVE = 1u << 31;
+		for (u32 q = threadIdx.x; q <= tmask; q += 1024) { key[q] = 0; resv[q] = 0; mark[q] = 0; }
+		drain_vmem();
+		__syncthreads();
+		for (int r = threadIdx.x; r < nc; r += 1024) {
+			const u32 x = cont[r];
+			const u32 c0 = cur[r] & 0xFFFFu;
+			const CRec<NHM> cr = crec_load<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh);
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((c0 >> j) & 1u)) {
+					const u64 pos = ((u64)crec_cell<NHM>(cr, j) << 4) | crec_nib<NHM>(cr, md.nh, j);
+					u32 e = rt_hash(pos) & tmask;
+					for (;;) {
+						const u64 old = atomicCAS(&key[e], 0ULL, pos + 1);
+						if (old == 0 || old == pos + 1) break;
+						e = (e + 1) & tmask;
+					}
+					eidx[(u64)r * md.nh + j] = e;
+				}
+			cur[r] = c0 | LIVE;
+		}
+		drain_vmem();
+		__syncthreads();
+		for (;; iters++) {
+			if (threadIdx.x == 0) s_pending = 0;
+			for (int r = threadIdx.x; r < nc; r += 1024) {                 // 1: reserve
+				const u32 c = cur[r];
+				if (!(c & LIVE)) continue;
+				const u32 prio = 0x40000u - cont[r];
+#pragma unroll
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh && ((c >> j) & 1u)) atomicMax(&resv[eidx[(u64)r * md.nh + j]], prio);
+			}
+			drain_vmem();
+			__syncthreads();
+			int succ = 0;
+			for (int r = threadIdx.x; r < nc; r += 1024) {                 // 2: whoever holds everything wins and marks
+				const u32 c = cur[r];
+				if (!(c & LIVE)) continue;
+				const u32 x = cont[r], prio = 0x40000u - x, want = bd.uw[pp][row + x] >> 16;
+				bool mine = true;
+#pragma unroll
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh && ((c >> j) & 1u)) mine &= cell_load_coherent(&resv[eidx[(u64)r * md.nh + j]]) == prio;
+				if (!mine) continue;
+#pragma unroll
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh && ((c >> j) & 1u)) {
+						const u32 e = eidx[(u64)r * md.nh + j];
+						u32 v = (want >> j) & 1u;
+#pragma unroll
+						for (int j2 = 0; j2 < NHM; j2++)
+							if (j2 < md.nh && j2 != j && ((c >> j2) & 1u) && eidx[(u64)r * md.nh + j2] == e) v |= (want >> j2) & 1u;
+						atomicOr(&mark[e], 1u << v);
+					}
+				bd.status[pp][row + x] = SLOT_INSERTED;
+				cur[r] = 0;
+				succ++;
+			}
+			if (succ) atomicAdd(&s_succ, succ);
+			drain_vmem();
+			__syncthreads();
+			for (int r = threadIdx.x; r < nc; r += 1024) {                 // 3: what the winners marked
+				u32 c = cur[r];
+				if (!(c & LIVE)) continue;
+				const u32 x = cont[r], want = bd.uw[pp][row + x] >> 16;
+				bool conflict = false;
+#pragma unroll
+				for (int j = 0; j < NHM; j++)
+					if (j < md.nh && ((c >> j) & 1u)) {
+						const u32 e = eidx[(u64)r * md.nh + j];
+						const u32 mk = cell_load_coherent(&mark[e]);
+						if (mk) { conflict |= ((mk >> 1) & 1u) != ((want >> j) & 1u); c &= ~(1u << j); }
+						else resv[e] = 0;                                    // everybody who still wants it reserves it again
+					}
+				if (conflict) { mark_failed(bd, pp, i, row, x); cur[r] = 0; }
+				else { cur[r] = c; s_pending = 1; }
+			}
+			drain_vmem();
+			__syncthreads();
+			const int pending = s_pending;
+			__syncthreads();
+			if (!pending) break;
+		}
 	}
 	if (threadIdx.x == 0) {
 		atomicAdd(bd.stats + ST_FIN_ITERS, iters + 1);
 		if (s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)s_succ);
+		rd.n_contended[i * KMX_CTR_STRIDE] = 0;                      // (every thread read it before the first barrier) ready for the next round's k_range_apply
 	}
 }
 
@@ -333,8 +446,10 @@ template <int NHM> __global__ __launch_bounds__(256) void k_range_commit_emit(Mo
 	range_block_append<NHM>(rd, pl.world, word, dest, valid, nullptr, s_cnt, s_base);
 }
 // ... and their application on the owner: the commit words among what it received (the others are the round's triples)
-__global__ __launch_bounds__(256) void k_range_commit_apply(ModelDev md, const u64 *words, u64 n)
+// (ovf: the owner's overflow flags of the round before -- k_range_verdict2 has read them -- are reset here, ahead of this round's k_range_verdict)
+__global__ __launch_bounds__(256) void k_range_commit_apply(ModelDev md, const u64 *words, u64 n, int *ovf)
 {
+	if (ovf && blockIdx.x == 0 && (int)threadIdx.x < md.nb) ovf[threadIdx.x] = 0;
 	for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < n; q += (u64)gridDim.x * 256) {
 		const u64 tr = words[q];
 		if (!(tr & RT_COMMIT)) continue;
@@ -352,46 +467,41 @@ static inline unsigned range_grid(u64 n) { return (unsigned)std::min<u64>((n + 2
 void range_emit(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangePlan &pl, int t, int pp, bool fresh, hipStream_t st)
 {
 	if (fresh) hipMemsetAsync(rd.send_cnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, st);
-	hipMemsetAsync(rd.n_contended, 0, sizeof(int) * KMX_MAX_NB * KMX_CTR_STRIDE, st);
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_range_emit<W, NHM>), dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, md, bd, rd, pl, t, pp));
 }
-// obd: the owner's view (scratch status, its own overflow flags; the claim bins of the handle, unused by the list side here)
-void range_verdict(const ModelDev &md, const BlockDev &obd, int *pcnt, int t, const u64 *triples, u64 n, unsigned char *verdict, hipStream_t st)
+// obd: the owner's view (its own overflow flags and padded bin counters; the claim bins of the handle, unused by the list side here)
+void range_verdict(const ModelDev &md, const BlockDev &obd_, int *pcnt, int t, const u64 *triples, u64 n, unsigned char *verdict, hipStream_t st)
 {
 	if (!n) return;
-	hipLaunchKernelGGL(k_range_commit_apply, dim3(range_grid(n)), dim3(256), 0, st, md, triples, n);      // the previous round's winners first
+	BlockDev obd = obd_;
+	obd.rverdict = verdict;
+	hipLaunchKernelGGL(k_range_commit_apply, dim3(range_grid(n)), dim3(256), 0, st, md, triples, n, obd.cl_ovf);      // the previous round's winners first
 	if (md.nh <= 8) {
 		hipLaunchKernelGGL((k_range_verdict<8>), dim3(range_grid(n)), dim3(256), 0, st, md, obd, pcnt, t, triples, n, verdict);
-		hipLaunchKernelGGL(k_range_pack_counts, dim3((md.nb * KMX_CL_MAXBINS + 255) / 256), dim3(256), 0, st, obd, pcnt, md.nb * KMX_CL_MAXBINS);
-		hipLaunchKernelGGL((k_round_detect<8, 1024, KMX_CL_TBITS(8)>), dim3(KMX_CL_BINS(8), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, 0);
+		hipLaunchKernelGGL((k_round_detect<8, 1024, KMX_CL_TBITS(8), true>), dim3(KMX_CL_BINS(8), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, 0);
 	} else {
 		hipLaunchKernelGGL((k_range_verdict<16>), dim3(range_grid(n)), dim3(256), 0, st, md, obd, pcnt, t, triples, n, verdict);
-		hipLaunchKernelGGL(k_range_pack_counts, dim3((md.nb * KMX_CL_MAXBINS + 255) / 256), dim3(256), 0, st, obd, pcnt, md.nb * KMX_CL_MAXBINS);
-		hipLaunchKernelGGL((k_round_detect<16, 1024, KMX_CL_TBITS(16)>), dim3(KMX_CL_BINS(16), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, 0);
+		hipLaunchKernelGGL((k_round_detect<16, 1024, KMX_CL_TBITS(16), true>), dim3(KMX_CL_BINS(16), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, 0);
 	}
-	hipLaunchKernelGGL(k_range_verdict2, dim3(range_grid(n)), dim3(256), 0, st, obd, triples, n, verdict);
-	hipMemsetAsync(obd.status[0], 0, (u64)md.nb * KMX_BUCKET, st);
-	hipMemsetAsync(obd.cl_ovf, 0, sizeof(int) * md.nb, st);
+	hipLaunchKernelGGL(k_range_verdict2, dim3(std::min(range_grid(n), 2048u)), dim3(256), 0, st, obd, md.nb, triples, n, verdict);   // (grid-stride; nearly always it only reads the flags)
 }
 void range_resolve(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangePlan &pl, int t, int pp, const unsigned char *verdict, hipStream_t st)
 {
 	const dim3 grid(KMX_BUCKET / 256, md.nb);
 	if (md.nh <= 8) {
 		hipLaunchKernelGGL((k_range_apply<8>), grid, dim3(256), 0, st, md, bd, rd, pl.world, pp, verdict);
-		hipLaunchKernelGGL((k_range_resolve<8>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl.world, pp);
-		hipMemsetAsync(rd.send_cnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, st);
+		hipLaunchKernelGGL((k_range_resolve<8>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl.world, pp);      // (its first workgroup resets send_cnt)
 		hipLaunchKernelGGL((k_range_commit_emit<8>), grid, dim3(256), 0, st, md, bd, rd, pl, t, pp);
 	} else {
 		hipLaunchKernelGGL((k_range_apply<16>), grid, dim3(256), 0, st, md, bd, rd, pl.world, pp, verdict);
-		hipLaunchKernelGGL((k_range_resolve<16>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl.world, pp);
-		hipMemsetAsync(rd.send_cnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, st);
+		hipLaunchKernelGGL((k_range_resolve<16>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl.world, pp);      // (its first workgroup resets send_cnt)
 		hipLaunchKernelGGL((k_range_commit_emit<16>), grid, dim3(256), 0, st, md, bd, rd, pl, t, pp);
 	}
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, md.nb), dim3(256), 0, st, md, bd, t, pp, 0));   // (no REC_WON records here: Un stays 0)
 }
 void range_commit_apply(const ModelDev &md, const u64 *commits, u64 n, hipStream_t st)
 {
-	if (n) hipLaunchKernelGGL(k_range_commit_apply, dim3(range_grid(n)), dim3(256), 0, st, md, commits, n);
+	if (n) hipLaunchKernelGGL(k_range_commit_apply, dim3(range_grid(n)), dim3(256), 0, st, md, commits, n, (int *)nullptr);
 }
 
 }   // namespace kmxk

@@ -335,6 +335,8 @@ class DeviceEngine:
     def _regions(self, counts):
         """what the last emit / resolve left for every rank, concatenated in rank order (the order the verdicts come back in)"""
         parts = [self._send[q * self._cap: q * self._cap + c] for q, c in enumerate(counts) if c]
+        if len(parts) == 1:
+            return parts[0]                                     # one destination (one rank, or nothing for the others): the region itself, no copy
         return torch.cat(parts) if parts else self._send[:0]
 
     def range_emit(self, t, lists):
