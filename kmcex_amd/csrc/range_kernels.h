@@ -63,10 +63,59 @@ template <int NHM> __device__ __forceinline__ void range_block_append(const Rang
 	__syncthreads();
 }
 
+// The same for a round's triples, SORTED by (destination, claim bin of the position) inside the workgroup's run: the owner files
+// untagged claims in the position-hashed bins of its list, and with the triples of one bin next to each other a wave there
+// reserves a run of tuples with ONE atomic instead of one per lane (k_range_verdict).  s_key: KMX_MAX_RANKS * 256 + 1 counters.
+template <int NHM> __device__ __forceinline__ void range_block_append_sorted(const RangeDev &rd, int world, const u64 *word, const int *dest, u32 valid, u32 *where, int *s_key, int *s_base, int *s_wsum)
+{
+	const int K = world * KMX_CL_MAXBINS;
+	for (int q = threadIdx.x; q <= K; q += 256) s_key[q] = 0;
+	__syncthreads();
+	int rank[NHM], key[NHM];
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if ((valid >> j) & 1u) {
+			key[j] = dest[j] * KMX_CL_MAXBINS + (int)cl_bin(cl_mix(RT_POS(word[j])));
+			rank[j] = atomicAdd(&s_key[key[j]], 1);
+		}
+	__syncthreads();
+	// exclusive scan of the K counters in place: thread t owns the `world` consecutive keys [t * world, (t + 1) * world)
+	int loc[KMX_MAX_RANKS], sum = 0;
+#pragma unroll
+	for (int e = 0; e < KMX_MAX_RANKS; e++)
+		if (e < world) { loc[e] = sum; sum += s_key[(int)threadIdx.x * world + e]; }
+	int incl = sum;                                                       // inclusive scan over the 256 threads: wave scan + wave totals
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+	if (lane == 63) s_wsum[wv] = incl;
+	__syncthreads();
+	int before = incl - sum;
+	for (int w2 = 0; w2 < wv; w2++) before += s_wsum[w2];
+#pragma unroll
+	for (int e = 0; e < KMX_MAX_RANKS; e++)
+		if (e < world) s_key[(int)threadIdx.x * world + e] = before + loc[e];
+	if (threadIdx.x == 255) s_key[K] = before + sum;                      // the grand total closes the last destination
+	__syncthreads();
+	if ((int)threadIdx.x < world) {
+		const int tot = s_key[((int)threadIdx.x + 1) * KMX_CL_MAXBINS] - s_key[(int)threadIdx.x * KMX_CL_MAXBINS];
+		s_base[threadIdx.x] = tot ? atomicAdd(rd.send_cnt + (int)threadIdx.x * KMX_CTR_STRIDE, tot) : 0;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if ((valid >> j) & 1u) {
+			const u64 off = (u64)(s_base[dest[j]] + (s_key[key[j]] - s_key[dest[j] * KMX_CL_MAXBINS]) + rank[j]);
+			rd.send[(u64)dest[j] * rd.cap + off] = word[j];
+			where[j] = ((u32)dest[j] << 28) | (u32)off;
+		}
+	__syncthreads();
+}
+
 // 1. every attempt of the lists this rank holds -> triples by owner rank; positions kept per slot (crec) for steps 3
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_range_emit(ModelDev md, BlockDev bd, RangeDev rd, RangePlan pl, int t, int pp)
 {
-	__shared__ int s_cnt[KMX_MAX_RANKS], s_base[KMX_MAX_RANKS];
+	__shared__ int s_key[KMX_MAX_RANKS * KMX_CL_MAXBINS + 1], s_base[KMX_MAX_RANKS], s_wsum[4];
 	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
 	const int n = bd.n[pp][i];
 	if ((int)blockIdx.x * 256 >= n) return;                             // uniform
@@ -97,7 +146,7 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_range_emit(Mo
 		bd.uw[pp][row + x] = bin << 16;                                  // the untagged mask arrives with the verdicts
 		bd.status[pp][row + x] = SLOT_UNDECIDED;
 	}
-	range_block_append<NHM>(rd, pl.world, word, dest, valid, where, s_cnt, s_base);
+	range_block_append_sorted<NHM>(rd, pl.world, word, dest, valid, where, s_key, s_base, s_wsum);
 	if (x < n)
 #pragma unroll
 		for (int j = 0; j < NHM; j++)
@@ -109,29 +158,51 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_range_emit(Mo
 // returning atomic goes to a counter of its own choosing, and with the 1280 counters of the claim bins packed into 80 lines the
 // lines serialised them -- 761 us per launch against 150 for the gathers; k_round_detect<..., RANGE> reads and resets the padded
 // form.  A claim tuple names the triple it came from, so that detect answers in that triple's verdict byte.)
+// (The triples of a sender's workgroup arrive sorted by claim bin -- range_block_append_sorted --, so neighbouring lanes mostly file
+// into the same bin: the lanes of a wave that follow each other with the same (list, bin) reserve their tuples with ONE atomic.)
 template <int NHM> __global__ __launch_bounds__(256) void k_range_verdict(ModelDev md, BlockDev obd, int *pcnt, int t, const u64 *triples, u64 n, unsigned char *verdict)
 {
 	constexpr int NBIN = KMX_CL_BINS(NHM), CAP = KMX_CL_CAP_OF(NHM);
-	for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < n; q += (u64)gridDim.x * 256) {
-		const u64 tr = triples[q];
-		if (tr & RT_COMMIT) { verdict[q] = 0; continue; }              // a commit of the previous round (applied by the launch before this one)
+	const int lane = threadIdx.x & 63;
+	for (u64 base = (u64)blockIdx.x * 256; base < n; base += (u64)gridDim.x * 256) {   // (uniform trip count: the wave votes below)
+		const u64 q = base + threadIdx.x;
+		const bool act = q < n;
+		const u64 tr = act ? triples[q] : RT_COMMIT;
+		const bool claim = !(tr & RT_COMMIT);                           // (a commit of the previous round was applied by the launch before this one)
 		const u64 pos = RT_POS(tr);
 		const u32 i = RT_LIST(tr), want = RT_WANT(tr);
-		const int a = (int)((i + (u32)t) % (u32)md.nb);
-		const cell_t c = md.cells[a][pos >> 4];
-		const u32 b = bit_in_cell(pos);
-		const u32 tag = (c >> (16 + b)) & 1u, val = (c >> b) & 1u;
 		unsigned char v = 0;
-		if (tag) v = val != want ? RV_CONFLICT : 0;
-		else {
-			v = RV_UNTAGGED;
-			const u64 mx = cl_mix(pos);
-			const u32 bin = cl_bin(mx);
-			const int g = atomicAdd(pcnt + (i * KMX_CL_MAXBINS + bin) * KMX_CTR_STRIDE, 1);
-			if (g < CAP) obd.cl_tup[0][((u64)i * NBIN + bin) * CAP + g] = CL_RANGE_TUPLE(mx, want, q);
+		u64 mx = 0;
+		u32 key = 0x80000000u | (u32)lane;                              // lanes without a claim: a key of their own
+		bool untagged = false;
+		if (claim) {
+			const int a = (int)((i + (u32)t) % (u32)md.nb);
+			const cell_t c = md.cells[a][pos >> 4];
+			const u32 b = bit_in_cell(pos);
+			const u32 tag = (c >> (16 + b)) & 1u, val = (c >> b) & 1u;
+			mx = cl_mix(pos);
+			key = i * KMX_CL_MAXBINS + cl_bin(mx);
+			if (tag) v = val != want ? RV_CONFLICT : 0;
+			else { v = RV_UNTAGGED; untagged = true; }
+		}
+		// runs of equal keys among the lanes: heads, this lane's run [start, end)
+		const u32 prev = __shfl_up(key, 1, 64);
+		const u64 heads = __ballot(lane == 0 || key != prev), um = __ballot(untagged);
+		const u64 upto = lane == 63 ? ~0ULL : ((2ULL << lane) - 1);     // lanes 0..lane
+		const int start = 63 - __clzll((long long)(heads & upto));
+		const u64 after = heads & ~upto;
+		const int end = after ? __ffsll((long long)after) - 1 : 64;
+		const u64 run = (end == 64 ? ~0ULL : ((1ULL << end) - 1)) & ~((1ULL << start) - 1);
+		const int cnt = (int)__popcll(um & run), rk = (int)__popcll(um & run & ((1ULL << lane) - 1));
+		int g0 = 0;
+		if (lane == start && cnt) g0 = atomicAdd(pcnt + (int)key * KMX_CTR_STRIDE, cnt);
+		g0 = __shfl(g0, start, 64);
+		if (untagged) {
+			const int g = g0 + rk;
+			if (g < CAP) obd.cl_tup[0][((u64)i * NBIN + (key & (KMX_CL_MAXBINS - 1))) * CAP + g] = CL_RANGE_TUPLE(mx, want, q);
 			else obd.cl_ovf[i] = 1;                                     // tuples lost: every untagged claim of the list counts as contended
 		}
-		verdict[q] = v;
+		if (act) verdict[q] = v;
 	}
 }
 // 2b. k_round_detect<..., RANGE> on the owner's bins has marked the claims that sit on positions wanted with both values.  What
