@@ -208,7 +208,7 @@ int kmx_occubin(int cs, int nh, uint32_t *bin_of_occ, uint32_t *mean_of_bin);
 int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds);
 
 /* Per-kernel-class timing with HIP events recorded on the model's stream around each launch (off by default).
- * classes: 0 classify(+Bloom insert) 1 check (+ claim emission) 2 commit 3 ordered slow path 4 reorder 5 rest append 6 query
+ * classes: 0 classify(+Bloom insert) 1 check (+ claim emission) 2 commit 3 ordered slow path 4 reorder 5 rest table (sort + index) 6 query
  * 7 detect (opposite claims) 8 commit of the previous round beside the check of the next (k_round_commit_check)
  * 9 file (k_round_file).  seconds[KMX_KERNEL_CLASSES], launches[KMX_KERNEL_CLASSES] accumulate until reset: a caller
  * must size both arrays with the macro of the header it was compiled against and check kmx_kernel_classes() == it.  */

@@ -440,7 +440,7 @@ class KModel:
         _chk(self.L.kmx_download(self.h, self.DL[which], index, buf.ctypes.data, cap, C.byref(w)))
         return buf[:w.value].copy()
 
-    KERNEL_CLASSES = ["classify", "check", "commit", "slow_path", "reorder", "rest_append", "query", "detect", "commit_check", "file"]
+    KERNEL_CLASSES = ["classify", "check", "commit", "slow_path", "reorder", "rest_table", "query", "detect", "commit_check", "file"]
 
     def set_profile(self, on) -> None:
         """True / 1: time the kernel classes; 2: the next builds run the fused launches' accounting variant (stats().piped_*)"""

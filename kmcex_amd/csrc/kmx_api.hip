@@ -1197,8 +1197,10 @@ static int build_rest(kmx_model *m, u64 n)
 	HIPCHK(hipMalloc((void **)&r.d_h2i, (u64)r.map_size * 4));
 	HIPCHK(hipMalloc((void **)&r.d_pre, ((u64)r.map_size + 2) * 4));
 	HIPCHK(hipMemsetAsync(r.d_h2i, 0xFF, (u64)r.map_size * 4, m->stream));
+	KPROF_BEGIN(&m->prof, KC_REST, m->stream);                        // class 5: the rest table -- radix sort + index kernels (the accelerators follow)
 	HIPCHK(kmxk::rest_sort(m->d_rest_kmers, m->d_rest_counts, n, W, k, r.d_sorted, r.d_cnt, m->stream));
 	HIPCHK(kmxk::rest_index(r.d_sorted, n, W, k, r.pre_len, r.d_h2i, r.d_pre, r.d_suf, m->d_total, m->stream));
+	KPROF_END(&m->prof, m->stream);
 	HIPCHK(hipMemcpyAsync(m->h_total, m->d_total, 4, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipStreamSynchronize(m->stream));
 	r.pre_buffer_size = *m->h_total + 1;
