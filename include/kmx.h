@@ -145,7 +145,8 @@ int kmx_range_buffers(kmx_model *m, void **d_send, uint64_t *cap_words, uint64_t
  * t == 0: `lists` = the fresh buffers of the block this rank holds (list, n_host, src_kmers, src_counts)              */
 int kmx_range_emit_dev(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists, uint64_t *counts);
 /* step 2, owner: applies the commit words among what it received (the set loop :611-618 of the round before), then answers
- * every word with one byte, same order: conflict | untagged | wanted with both values this round (0 for a commit word)   */
+ * every word with one byte, same order: conflict | untagged | wanted with both values this round (0 for a commit word);
+ * n < 2^27 words per call (KMX_E_ARG beyond: a round of nb = nh = 16 on one rank stays below it)                          */
 int kmx_range_verdict_dev(kmx_model *m, int t, const uint64_t *d_words, uint64_t n, uint8_t *d_verdict);
 /* step 3, list rank: verdicts in the order the words left (regions concatenated in rank order) -> winners (the contended
  * ones decided in list order); their commits stay in the send regions for the next emit; reorder_buffer (:529-540), km_back,

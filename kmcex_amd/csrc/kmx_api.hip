@@ -2044,7 +2044,7 @@ static int kmx_create_on_impl(int device, int ci, int cs, int nh, int nb, kmx_mo
 
 // ------------------------------------------------------------------------------------------ position-range partition (range_kernels.h)
 // Every coupled array cut by position range over the ranks (the north star's partition); the caller moves
-// the words between the ranks (three all-to-alls per round: kmcex_amd/dist.py build_sharded(partition="range")).
+// the words between the ranks (two all-to-alls per round + a split-size exchange: kmcex_amd/dist.py build_sharded(partition="range")).
 static int kmx_range_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world)
 {
 	if (world > KMX_MAX_RANKS) return fail(KMX_E_ARG, "the range partition takes up to %d ranks", KMX_MAX_RANKS);

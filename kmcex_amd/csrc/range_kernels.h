@@ -7,19 +7,22 @@
 // never move.  A round (all lists at once, list i against array (i + t) % nb, kmodel.hpp:560-565) is two all-to-alls (the
 // winners' commits of round t travel with the triples of round t + 1; a last exchange flushes them at the end of the build):
 //   1. k_range_emit        list rank: one TRIPLE (position, wanted value, list, slot, hash index) per position of every attempt,
-//                          binned by owner rank                                      -> all-to-all
+//                          binned by owner rank and, inside a workgroup's run, sorted by claim bin          -> all-to-all
 //   2. k_range_verdict     owner: reads the cell -- conflict with a set tag (kmodel.hpp:604-610) | untagged --, files every
-//      k_round_detect      untagged claim in the position-hashed bins of the single-GPU path and lets ITS detect kernel find
-//      k_range_verdict2    the positions wanted with both values by claims of this round: the owner sees every claim on its
-//                          positions, so contention is found where the bits live.  One verdict byte per triple -> all-to-all back
+//      k_round_detect      untagged claim in the position-hashed bins of the single-GPU path (one atomic per wave and bin) and
+//      <..., RANGE>        lets ITS detect kernel find the positions wanted with both values by claims of this round: the owner
+//      k_range_verdict2    sees every claim on its positions, so contention is found where the bits live; detect answers in the
+//                          verdict byte of the triple a claim came from (verdict2: bin overflow only).  One byte per triple
+//                                                                                                          -> all-to-all back
 //   3. k_range_apply       list rank: a slot with a conflict anywhere has failed (final: bits are never cleared); a candidate
-//      k_range_resolve     none of whose untagged positions is contended wins outright; the contended ones are decided in list
-//      k_range_commit_emit order from the verdicts alone (the only writers that can matter to them are earlier contended
-//                          winners): priority reservations on an exact position table, the smallest undecided slot always
-//                          wins its turn.  The winners' (position, value, array) words stay in the send regions, IN FRONT of the
-//                          next round's triples (bit 63 marks them): the owner applies them (k_range_commit_apply) before it
-//                          reads a cell for that round's verdicts -- the order the sequential algorithm has.
-// Then k_reorder, the km_back emission of the round and, after the last round, k_rest_append -- the single-GPU kernels.
+//      k_range_resolve     none of whose untagged positions is wanted with both values wins outright; the others are decided
+//      k_range_commit_emit in list order from the verdicts alone, on their both-wanted positions (the only writers that can
+//                          matter to them are earlier contended winners): priority reservations on an exact position table,
+//                          the smallest undecided slot always wins its turn.  The winners' (position, value, array) words stay
+//                          in the send regions, IN FRONT of the next round's triples (bit 63 marks them): the owner applies
+//                          them (k_range_commit_apply) before it reads a cell for that round's verdicts -- the order the
+//                          sequential algorithm has.
+// Then k_reorder and, after the last round, k_rest_append and the block's km_back emission -- the single-GPU kernels.
 #pragma once
 
 // triple: position (36 bits) | want << 36 | list << 37 | slot << 41 | hash index << 59
