@@ -70,6 +70,60 @@ def test_range_partition_over_ranks_is_bit_exact(spec, world, golden, tmp_path):
     assert cells[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cells, cells[1:]))       # the ranges tile every array
 
 
+# The world size the driver's 8-GPU node starts with (and the 16 the range partition is sized for): more ranks than the box
+# lets share the card as processes, so here they are THREADS of one process (tests/thread_comm.py) on the UNSTAGED path of the
+# orchestration -- device tensors straight to the transport, whole ring messages -- which is the code "nccl" runs.
+@pytest.mark.parametrize("spec,world,partition", [
+    (("synth", "k31_multiblock_ci1"), 8, "ring"),  # 5 array owners, 3 ranks that only list, classify and merge
+    (("synth", "k31_multiblock_ci1"), 8, "range"), # 5 list holders, 8 range owners
+    (("synth", "k55_multiblock"), 8, "range"),     # two-word k-mers, nh 9, nb 6
+    (("synth", "k55_multiblock"), 8, "ring"),
+    (("synth", "k31_multiblock_ci2"), 16, "range"),  # KMX_MAX_RANKS owners, three Bloom classes
+    (("kmc2", "k31_kmc2_6bins"), 7, "range"),      # a world that divides nothing
+], ids=lambda v: v[1] if isinstance(v, tuple) else str(v))
+def test_many_ranks_in_one_process_are_bit_exact(spec, world, partition, golden, tmp_path):
+    import torch
+    from common import sha_file, sha_occ
+    from dist_workers import _to_torch, listing_of, queries_of
+    from kmcex_amd import KModel
+    from kmcex_amd import dist as kd
+    from thread_comm import run_threads
+    g = _golden_of(golden, spec)
+    dev = torch.device("cuda", 0)
+    k, ci, cs, nh, nb, km, cnt, base = listing_of(spec)
+    qk = queries_of(spec, base, k)
+    tq = torch.from_numpy(np.ascontiguousarray(qk, dtype=np.uint64).view(np.int64).reshape(-1)).to(dev)
+
+    def rank_body(rank, comm):
+        lo, hi = kd.split_batch(len(cnt), world, rank)
+        tk, tc = _to_torch(km[lo:hi], cnt[lo:hi], k, dev)
+        m = KModel(ci, cs, nh, nb)
+        try:
+            info = kd.build_sharded(kd.DeviceEngine(m, dev), comm, k, nb, 1 if ci == 1 else 3, tk, tc, partition=partition)
+            st = m.stats()
+            occ = kd.query_replicas(m, comm, tq, k).cpu().numpy()
+            d = os.path.join(str(tmp_path), f"rank{rank}")
+            os.makedirs(d, exist_ok=True)
+            m.save(d)
+            return {"info": info, "stats": (st.attempts, st.successes, st.rest_entries), "occ_sha": sha_occ(occ),
+                    "sha": {f: sha_file(os.path.join(d, f)) for f in ("header", "km.bin", "rest.bin")}}
+        finally:
+            m.close()
+
+    res = run_threads(world, rank_body)
+    for rank, r in enumerate(res):
+        assert r["sha"] == {f: g["sha256"][f] for f in ("header", "km.bin", "rest.bin")}, f"rank {rank} holds a different model"
+        assert r["occ_sha"] == g["occ_sha256"]
+        if "stats" in g:
+            assert r["stats"] == (g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
+    if partition == "ring":
+        owned = sorted(a for r in res for a in r["info"]["arrays_owned"])
+        assert owned == list(range(nb))
+    else:
+        cells = sorted(tuple(r["info"]["cells_owned"]) for r in res)
+        assert cells[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cells, cells[1:]))
+
+
 def test_replica_query_of_reference_files():
     """2 ranks load the model the REFERENCE wrote (tests/golden/tiny) and answer the batch by slices."""
     d = os.path.join(ROOT, "tests", "golden", "tiny")
