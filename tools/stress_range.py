@@ -2,7 +2,10 @@
 list and owns every range (each exchange is a word "sent" to itself), so the emit / verdict + detect / apply / ordered resolve /
 commit kernels run alone on configurations biased to heavy contention -- tiny arrays where nearly every candidate is contended
 (the resolver iterates many times), claim bins that overflow on the owner, several blocks with a partial last one.
-usage: python tools/stress_range.py [seconds] [seed] [big]"""
+With `world=N` (or `world=rand`) the N ranks are threads of this process (tests/thread_comm.py) that share the GPU: the lists are spread
+over the ranks, every rank owns a range of every array, the words really travel between the handles, and EVERY rank's model is
+compared with the oracle.
+usage: python tools/stress_range.py [seconds] [seed] [big] [world=N|world=rand] [part=range|ring]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,6 +15,9 @@ import oracle_lib as O
 from kmcex_amd import KModel, synth
 from kmcex_amd import dist as kd
 
+from thread_comm import run_threads
+world_arg = next((a.split("=")[1] for a in sys.argv if a.startswith("world=")), None)
+part = next((a.split("=")[1] for a in sys.argv if a.startswith("part=")), "range")      # part=ring: the ring of whole arrays through the same harness
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4321)
 SIZES = [600000, 1500000, 3000000] if "big" in sys.argv else [40, 300, 3000, 30000, 120000, 300000, 700000]
@@ -35,10 +41,27 @@ while time.time() - t0 < budget:
     W = (k + 31) // 32
     tk = torch.from_numpy(np.ascontiguousarray(km, dtype=np.uint64).view(np.int64).reshape(-1, W) if W > 1 else np.ascontiguousarray(km, dtype=np.uint64).view(np.int64)).to(dev)
     tc = torch.from_numpy(np.ascontiguousarray(cnt, dtype=np.uint32).view(np.int32)).to(dev)
-    m = KModel(ci, cs, nh, nb)
-    kd.build_sharded(kd.DeviceEngine(m, dev), kd.Comm(), k, nb, 1 if ci == 1 else 3, tk, tc, partition="range")
+    world = 1 if world_arg is None else (int(rng.integers(2, 17)) if world_arg == "rand" else int(world_arg))
+    tag = (k, ci, cs, nh, nb, n, seed, world)
+    if world > 1:
+        def rank_body(rank, comm):
+            lo, hi = kd.split_batch(len(cnt), world, rank)
+            mr = KModel(ci, cs, nh, nb)
+            kd.build_sharded(kd.DeviceEngine(mr, dev), comm, k, nb, 1 if ci == 1 else 3, tk[lo:hi].contiguous(), tc[lo:hi].contiguous(), partition=part)
+            return mr
+        models = run_threads(world, rank_body)
+        m = models[0]
+        for r, mr in enumerate(models[1:], 1):                  # every rank must hold the model rank 0 holds (compared with the oracle below)
+            for a in range(nb):
+                assert np.array_equal(mr.download("tag", a), m.download("tag", a)) and np.array_equal(mr.download("value", a), m.download("value", a)), ("rank", r, "array", a, tag)
+            assert np.array_equal(mr.download("km_back"), m.download("km_back")), ("rank", r, "km_back", tag)
+            sr, s0 = mr.stats(), m.stats()
+            assert (sr.attempts, sr.successes, sr.rest_entries) == (s0.attempts, s0.successes, s0.rest_entries), ("rank", r, "stats", tag)
+            mr.close()
+    else:
+        m = KModel(ci, cs, nh, nb)
+        kd.build_sharded(kd.DeviceEngine(m, dev), kd.Comm(), k, nb, 1 if ci == 1 else 3, tk, tc, partition=part)
     st = m.stats()
-    tag = (k, ci, cs, nh, nb, n, seed)
     for a in range(nb):
         assert np.array_equal(m.download("tag", a), o.array_bytes("tag", a)), ("tag", a, tag)
         assert np.array_equal(m.download("value", a), o.array_bytes("value", a)), ("value", a, tag)
@@ -52,4 +75,4 @@ while time.time() - t0 < budget:
     m.close(); del m
     done += 1
     if done % (5 if "big" in sys.argv else 20) == 0: print(f"[{time.time()-t0:.0f}s] {done} configurations, {contended} contended k-mers decided in list order, all bit-exact", flush=True)
-print(f"RANGE STRESS OK: {done} configurations, {contended} contended k-mers, {time.time()-t0:.0f}s")
+print(f"{part.upper()} STRESS OK (world {world_arg or 1}): {done} configurations, {contended} contended k-mers, {time.time()-t0:.0f}s")
