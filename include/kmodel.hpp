@@ -76,8 +76,11 @@ public:
 
 	// kmodel.hpp:57 -- two passes over the KMC listing, rest-table build
 	// kmodel.hpp:57-86.  KMX_DEVICES=0,1,2,... (HIP device numbers, repeats allowed): the model is built by those GPUs
-	// together -- one host thread per device inside libkmx.so, the ring of whole arrays with peer copies
-	// (kmx_build_from_kmc_multi) -- and this object keeps the replica of the first one.  Unset: the current device alone.
+	// together, one host thread per device inside libkmx.so, and this object keeps the replica of the first one.
+	// KMX_PARTITION=range: every coupled array cut by position range over the devices, the words of a round written
+	// straight into the owners' memory through peer mappings (kmx_build_from_kmc_multi_ex, KMX_PARTITION_RANGE);
+	// KMX_PARTITION=ring (the default): arrays owned whole, lists travel with peer copies.  Unset: the current device alone.
+	// A value that does not parse is an error, like a bad argument of the reference's own command line.
 	void init(std::string db_file)
 	{
 		std::vector<int> devs;
@@ -85,17 +88,30 @@ public:
 			for (const char *p = e; *p;) {
 				char *end = nullptr;
 				const long v = std::strtol(p, &end, 10);
-				if (end == p) break;
+				if (end == p || v < 0 || (*end != ',' && *end != 0) || (*end == ',' && end[1] == 0)) {
+					std::cout << "KMX_DEVICES=" << e << ": a comma-separated list of HIP device numbers is expected" << std::endl;
+					exit(1);
+				}
 				devs.push_back((int)v);
 				p = *end == ',' ? end + 1 : end;
 			}
 		}
-		if (devs.size() < 2) { check(kmx_build_from_kmc(h_, db_file.c_str())); return; }
+		int partition = KMX_PARTITION_RING;
+		if (const char *e = std::getenv("KMX_PARTITION")) {
+			const std::string v(e);
+			if (v == "range") partition = KMX_PARTITION_RANGE;
+			else if (v != "ring" && !v.empty()) { std::cout << "KMX_PARTITION=" << v << ": ring or range" << std::endl; exit(1); }
+		}
+		if (devs.empty()) { check(kmx_build_from_kmc(h_, db_file.c_str())); return; }
 		kmx_stats st;
 		check(kmx_get_stats(h_, &st));
 		std::vector<kmx_model *> hs(devs.size(), nullptr);
-		for (size_t d = 0; d < devs.size(); d++) check(kmx_create_on(devs[d], st.ci, st.cs, st.nh, st.nb, &hs[d]));
-		check(kmx_build_from_kmc_multi(hs.data(), (int)hs.size(), db_file.c_str()));
+		for (size_t d = 0; d < devs.size(); d++) {
+			const int rc = kmx_create_on(devs[d], st.ci, st.cs, st.nh, st.nb, &hs[d]);
+			if (rc) { for (size_t e2 = 0; e2 < d; e2++) kmx_destroy(hs[e2]); check(rc); }
+		}
+		const int rc = kmx_build_from_kmc_multi_ex(hs.data(), (int)hs.size(), db_file.c_str(), partition);
+		if (rc) { for (kmx_model *h : hs) kmx_destroy(h); check(rc); }
 		kmx_destroy(h_);
 		h_ = hs[0];
 		for (size_t d = 1; d < hs.size(); d++) kmx_destroy(hs[d]);

@@ -62,7 +62,7 @@ int kmx_device_count(void);
 /* Layout version of the structs and array sizes this header declares (kmx_stats, KMX_KERNEL_CLASSES ...): a caller built
  * against an older header must not hand its smaller structs to a newer library -- compare before the first call that
  * takes one (include/kmodel.hpp does, and exits like the reference does on a bad model directory).                    */
-#define KMX_ABI_VERSION 4
+#define KMX_ABI_VERSION 5
 int kmx_abi_version(void);
 
 /* get_model(ci, cs, num_hash, num_bit)                                     kmodel.hpp:674-677 */
@@ -72,12 +72,23 @@ int kmx_destroy(kmx_model *m);
 /* stream (hipStream_t) used by every later call on this model; NULL = the default stream       */
 int kmx_set_stream(kmx_model *m, void *hip_stream);
 
-/* a handle on a given HIP device (kmx_create uses the calling thread's current device)                                  */
+/* a handle on a given HIP device (kmx_create uses the calling thread's current device, which this call leaves as it was) */
 int kmx_create_on(int device, int ci, int cs, int nh, int nb, kmx_model **out);
 /* KModel::init(db_file) by several GPUs from ONE process (kmodel.hpp:57-86; main.cpp:143-149 is the caller): models[d] was
  * created on the device it is to use (devices may repeat), all with the same parameters.  One host thread per handle
  * drives the ring of whole arrays (below) with hipMemcpyPeerAsync hand-offs; on return EVERY handle holds the whole model. */
 int kmx_build_from_kmc_multi(kmx_model **models, int n_models, const char *db_prefix);
+/* The same with the partition chosen.  KMX_PARTITION_RANGE is the north star's: every coupled array cut by POSITION RANGE over
+ * the handles (handle q owns the cells [q n/P, (q+1) n/P) of every array; list i of a block lives on handle i % P and its k-mers
+ * never move).  A round of the rotation (kmodel.hpp:560-565; check :604-610, set :611-618) is words written by the list
+ * handle's kernels STRAIGHT INTO the owner's inbox through a peer mapping (hipDeviceEnablePeerAccess) -- the winners' commits of
+ * the round before, then one triple per position of every attempt, with the counts in a header beside them -- and one verdict
+ * byte per triple written straight back into the sender's box; two events per handle order the three steps of a round and the
+ * host threads only enqueue: no host wait inside a round.  Up to 16 handles; one handle is allowed (the partition's kernels
+ * alone).  On return every handle holds the whole model.                                                                       */
+#define KMX_PARTITION_RING  0
+#define KMX_PARTITION_RANGE 1
+int kmx_build_from_kmc_multi_ex(kmx_model **models, int n_models, const char *db_prefix, int partition);
 /* KModel::init(db_file): two passes over the KMC listing + rest build      kmodel.hpp:57-86   */
 int kmx_build_from_kmc(kmx_model *m, const char *db_prefix);
 
@@ -138,22 +149,24 @@ int kmx_shard_complete(kmx_model *m, const uint64_t *d_rest_kmers, const int32_t
  * commits of the round before), verdicts back.  kmx_count_classes_dev, kmx_shard_classify_dev, kmx_ring_stale_dup_dev,
  * kmx_shard_local / _complete and kmx_dev_view are shared with the ring.                                                */
 int kmx_range_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world);
-/* the send regions: region q (cap_words 64-bit words apart) holds what the last emit / resolve left for rank q         */
+/* the regions: region q (cap_words 64-bit words apart) holds what the last emit left for rank q -- commits in front, triples behind  */
 int kmx_range_buffers(kmx_model *m, void **d_send, uint64_t *cap_words, uint64_t *cell_lo /* [world + 1] */);
 /* step 1, list rank: every position of every attempt of its lists as a triple, by owner rank, appended behind the commits
- * the last kmx_range_resolve_dev left there; counts[world] (commits + triples) on the host.
+ * the last kmx_range_resolve_dev left in front of the regions; on the host counts[q] = words for rank q, counts[world + q] =
+ * the commit words among them (the header of the region: the owner needs both).
  * t == 0: `lists` = the fresh buffers of the block this rank holds (list, n_host, src_kmers, src_counts)              */
-int kmx_range_emit_dev(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists, uint64_t *counts);
-/* step 2, owner: applies the commit words among what it received (the set loop :611-618 of the round before), then answers
- * every word with one byte, same order: conflict | untagged | wanted with both values this round (0 for a commit word);
- * n < 2^27 words per call (KMX_E_ARG beyond: a round of nb = nh = 16 on one rank stays below it)                          */
-int kmx_range_verdict_dev(kmx_model *m, int t, const uint64_t *d_words, uint64_t n, uint8_t *d_verdict);
-/* step 3, list rank: verdicts in the order the words left (regions concatenated in rank order) -> winners (the contended
- * ones decided in list order); their commits stay in the send regions for the next emit; reorder_buffer (:529-540), km_back,
- * rest.  counts[world] comes back zeroed: nothing is exchanged now, and no host wait is spent on it                    */
-int kmx_range_resolve_dev(kmx_model *m, int t, const uint8_t *d_verdict, uint64_t *counts);
-/* end of the build: what is still pending in the send regions (counts[world]) for a last exchange ...                  */
-int kmx_range_flush_dev(kmx_model *m, uint64_t *counts);
+int kmx_range_emit_dev(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists, uint64_t *counts /* [2 world] */);
+/* step 2, owner: d_words = the regions of the n_src senders back to back (totals[s] words, the first commits[s] of them commit
+ * words).  Applies the commit words (the set loop :611-618 of the round before), then answers every triple with one byte at the
+ * same index of d_verdict: conflict | untagged | wanted with both values this round (the bytes of commit words stay unwritten);
+ * fewer than 2^27 triples per call (KMX_E_ARG beyond: a round of nb = nh = 16 holds 2^26)                                  */
+int kmx_range_verdict_dev(kmx_model *m, int t, const uint64_t *d_words, const uint64_t *totals, const uint64_t *commits, int n_src, uint8_t *d_verdict);
+/* step 3, list rank: verdicts in the order the words left (regions back to back, in rank order) -> winners (the contended
+ * ones decided in list order); their commits go to the front of the regions for the next emit; reorder_buffer (:529-540),
+ * km_back, rest.  Nothing is exchanged now, and no host wait is spent                                                   */
+int kmx_range_resolve_dev(kmx_model *m, int t, const uint8_t *d_verdict);
+/* end of the build: what is still pending in front of the regions (counts[q] = counts[world + q] = commit words) for a last exchange ... */
+int kmx_range_flush_dev(kmx_model *m, uint64_t *counts /* [2 world] */);
 /* ... and its application on the owner                                                                                  */
 int kmx_range_commit_dev(kmx_model *m, const uint64_t *d_commits, uint64_t n);
 

@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "kmx_count_classes_dev", "kmx_shard_begin", "kmx_shard_classify_dev", "kmx_ring_msg_bytes", "kmx_ring_round_dev",
     "kmx_ring_stale_dup_dev", "kmx_shard_local", "kmx_shard_complete", "kmx_dev_view", "kmx_or_words_dev",
     "kmx_debug_pack_strings", "kmx_kernel_classes", "kmx_abi_version",
-    "kmx_create_on", "kmx_build_from_kmc_multi", "kmx_range_begin", "kmx_range_buffers", "kmx_range_emit_dev", "kmx_range_verdict_dev", "kmx_range_resolve_dev", "kmx_range_commit_dev", "kmx_range_flush_dev",
+    "kmx_create_on", "kmx_build_from_kmc_multi", "kmx_build_from_kmc_multi_ex", "kmx_range_begin", "kmx_range_buffers", "kmx_range_emit_dev", "kmx_range_verdict_dev", "kmx_range_resolve_dev", "kmx_range_commit_dev", "kmx_range_flush_dev",
 ]
 
 
@@ -131,11 +131,12 @@ def load_library():
     L.kmx_dev_view.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(u64)]
     _sig(L, "kmx_create_on", [i32, i32, i32, i32, i32, C.POINTER(vp)])
     _sig(L, "kmx_build_from_kmc_multi", [C.POINTER(vp), i32, C.c_char_p])
+    _sig(L, "kmx_build_from_kmc_multi_ex", [C.POINTER(vp), i32, C.c_char_p, i32])
     _sig(L, "kmx_range_begin", [vp, i32, C.POINTER(u64), u64, i32, i32])
     _sig(L, "kmx_range_buffers", [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)])
     _sig(L, "kmx_range_emit_dev", [vp, i32, C.POINTER(RingList), i32, C.POINTER(u64)])
-    _sig(L, "kmx_range_verdict_dev", [vp, i32, vp, u64, vp])
-    _sig(L, "kmx_range_resolve_dev", [vp, i32, vp, C.POINTER(u64)])
+    _sig(L, "kmx_range_verdict_dev", [vp, i32, vp, C.POINTER(u64), C.POINTER(u64), i32, vp])
+    _sig(L, "kmx_range_resolve_dev", [vp, i32, vp])
     _sig(L, "kmx_range_commit_dev", [vp, vp, u64])
     _sig(L, "kmx_range_flush_dev", [vp, C.POINTER(u64)])
     L.kmx_or_words_dev.argtypes = [vp, vp, vp, u64]
@@ -336,28 +337,30 @@ class KModel:
         return p.value or 0, int(cap.value), [int(x) for x in lo]
 
     def range_emit_dev(self, t: int, lists):
+        """-> (words per destination rank, commit words among them): the headers of the regions"""
         arr = (RingList * max(len(lists), 1))()
         for j, (i, n, pk, pc) in enumerate(lists):
             arr[j] = RingList(i, n, pk or None, pc or None, None, None)
-        counts = (C.c_uint64 * self._range_world)()
+        w = self._range_world
+        counts = (C.c_uint64 * (2 * w))()
         _chk(self.L.kmx_range_emit_dev(self.h, t, arr, len(lists), counts))
-        return [int(x) for x in counts]
+        return [int(x) for x in counts[:w]], [int(x) for x in counts[w:]]
 
-    def range_verdict_dev(self, t: int, d_triples_ptr: int, n: int, d_verdict_ptr: int) -> None:
-        _chk(self.L.kmx_range_verdict_dev(self.h, t, d_triples_ptr, n, d_verdict_ptr))
+    def range_verdict_dev(self, t: int, d_words_ptr: int, totals, commits, d_verdict_ptr: int) -> None:
+        n = len(totals)
+        _chk(self.L.kmx_range_verdict_dev(self.h, t, d_words_ptr or None, (C.c_uint64 * n)(*totals), (C.c_uint64 * n)(*commits), n, d_verdict_ptr or None))
 
-    def range_resolve_dev(self, t: int, d_verdict_ptr: int):
-        counts = (C.c_uint64 * self._range_world)()
-        _chk(self.L.kmx_range_resolve_dev(self.h, t, d_verdict_ptr, counts))
-        return [int(x) for x in counts]
+    def range_resolve_dev(self, t: int, d_verdict_ptr: int) -> None:
+        _chk(self.L.kmx_range_resolve_dev(self.h, t, d_verdict_ptr or None))
 
     def range_commit_dev(self, d_commits_ptr: int, n: int) -> None:
         _chk(self.L.kmx_range_commit_dev(self.h, d_commits_ptr, n))
 
     def range_flush_dev(self):
-        counts = (C.c_uint64 * self._range_world)()
+        w = self._range_world
+        counts = (C.c_uint64 * (2 * w))()
         _chk(self.L.kmx_range_flush_dev(self.h, counts))
-        return [int(x) for x in counts]
+        return [int(x) for x in counts[:w]]
 
     def dev_view(self, which: str, index: int = 0):
         """(device pointer, bytes) of a filter ("bf", "bf_back", "km_back") or of the cells of coupled array `index` ("cells")"""
@@ -469,12 +472,17 @@ class KModel:
             pass
 
 
-def init_multi(models, db_file: str) -> None:
-    """KModel::init(db_file) (kmodel.hpp:57-86) by several handles together, from inside libkmx.so (kmx_build_from_kmc_multi:
-    one host thread per handle, ring of whole arrays, hipMemcpyPeerAsync hand-offs): every handle ends with the whole model."""
+PARTITIONS = {"ring": 0, "range": 1}                                # KMX_PARTITION_* of include/kmx.h
+
+
+def init_multi(models, db_file: str, partition: str = "ring") -> None:
+    """KModel::init(db_file) (kmodel.hpp:57-86) by several handles together, from inside libkmx.so (kmx_build_from_kmc_multi_ex:
+    one host thread per handle).  partition "ring": arrays owned whole, hipMemcpyPeerAsync hand-offs; "range": every array cut
+    by position range, the words of a round written into the owners' inboxes through peer mappings, no host wait in a round.
+    Every handle ends with the whole model."""
     L = load_library()
     arr = (C.c_void_p * len(models))(*[m.h for m in models])
-    _chk(L.kmx_build_from_kmc_multi(arr, len(models), db_file.encode()))
+    _chk(L.kmx_build_from_kmc_multi_ex(arr, len(models), db_file.encode(), PARTITIONS[partition]))
 
 
 def get_model(ci_or_dir=1, cs: int = 1023, num_hash: int = 7, num_bit: int = 5) -> KModel:

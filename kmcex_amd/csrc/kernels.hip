@@ -1806,16 +1806,17 @@ __device__ __forceinline__ void kmback_emit_body(const ModelDev &md, const Block
 		if (!md.kmb_direct) bs_block_emit<K, BT>(bs, v, valid, s_bs_cnt, s_bs_off, s_bs_base, s_bs_tmp, s_bs_stage);   // (uniform)
 	}
 }
-template <int W, int NHM, int KPT> __global__ __launch_bounds__(256) void k_kmback_emit(ModelDev md, BlockDev bd, const u64 *kmers, const unsigned char *surv, int i0, int pp, int n_in_block, BitScatter bs)
+template <int W, int NHM, int KPT> __global__ __launch_bounds__(256) void k_kmback_emit(ModelDev md, BlockDev bd, const u64 *kmers, const unsigned char *surv, int i0, int istride, int pp, int n_in_block, BitScatter bs)
 {
 	__shared__ __align__(16) unsigned char lds[BS_LDS_BYTES(KPT * (NHM - 2), 256)];
-	kmback_emit_body<W, NHM, KPT>(md, bd, kmers, surv, pp, n_in_block, bs, i0 + (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, lds);
+	kmback_emit_body<W, NHM, KPT>(md, bd, kmers, surv, pp, n_in_block, bs, i0 + (int)blockIdx.y * istride, (int)blockIdx.x, (int)gridDim.x, lds);
 }
 
 // survivors of the block go to the rest table (kmodel.hpp:567-571); slot 0 is remembered for the
 // stale-slot duplicate of the final block (quirk Q1)
-// (i0: first list of the launch -- the whole block with grid.y = nb, or ONE list that a rank of the multi-GPU ring retires)
-template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev bd, int pp, int i0, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, u64 *feedback)
+// (i0: first list of the launch -- the whole block with grid.y = nb, ONE list that a rank of the multi-GPU ring retires, or the
+// lists i0, i0 + istride, ... a rank of the range partition holds)
+template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev bd, int pp, int i0, int istride, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, u64 *feedback)
 {
 	__shared__ int s_cnt;
 	__shared__ unsigned long long s_base;
@@ -1825,7 +1826,7 @@ template <int W> __global__ __launch_bounds__(256) void k_rest_append(BlockDev b
 	}
 	if (threadIdx.x == 0) s_cnt = 0;
 	__syncthreads();
-	const int i = i0 + blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	const int i = i0 + (int)blockIdx.y * istride, x = blockIdx.x * 256 + threadIdx.x;
 	const int n = bd.n[pp][i];
 	if (x == 0 && n == 0) stale_counts[i] = 0;
 	const bool act = x < n;
@@ -2618,24 +2619,24 @@ void commit_flush(const ModelDev &md, const BlockDev &bd, int t, int pp, hipStre
 }
 
 // lists [i0, i0 + n_lists) of the block go to the rest table
-void rest_append(const ModelDev &md, const BlockDev &bd, int pp, int i0, int n_lists, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, u64 *feedback, hipStream_t st)
+void rest_append(const ModelDev &md, const BlockDev &bd, int pp, int i0, int n_lists, u64 *rest_kmers, int *rest_counts, unsigned long long *rest_n, u64 *stale_kmers, int *stale_counts, u64 *feedback, hipStream_t st, int istride)
 {
-	DISPATCH_W(words(md), hipLaunchKernelGGL(k_rest_append<W>, dim3(KMX_BUCKET / 256, n_lists), dim3(256), 0, st, bd, pp, i0, rest_kmers, rest_counts, rest_n, stale_kmers, stale_counts, feedback));
+	DISPATCH_W(words(md), hipLaunchKernelGGL(k_rest_append<W>, dim3(KMX_BUCKET / 256, n_lists), dim3(256), 0, st, bd, pp, i0, istride, rest_kmers, rest_counts, rest_n, stale_kmers, stale_counts, feedback));
 }
 
 // n_in_block < 0: the slots round t inserted (list[pp], status); >= 0: every k-mer of the block that is not a survivor.
 // Lists [i0, i0 + n_lists) of the block whose k-mers / survivor flags are given (the current block's: bd.kmers, bd.surv).
-void kmback_emit(const ModelDev &md, const BlockDev &bd, const u64 *kmers, const unsigned char *surv, int i0, int n_lists, int t, int pp, int n_in_block, const BitScatter &bs, hipStream_t st)
+void kmback_emit(const ModelDev &md, const BlockDev &bd, const u64 *kmers, const unsigned char *surv, int i0, int n_lists, int t, int pp, int n_in_block, const BitScatter &bs, hipStream_t st, int istride)
 {
 	if (!md.km_back_mod.d || n_lists <= 0) return;
 	const int gx = n_in_block >= 0 ? KMX_BUCKET / 1024 : (KMX_BUCKET / 1024) >> (t < 4 ? t : 4);   // 4 (2) slots per thread; lists shrink round by round
 	const dim3 grid(gx, n_lists), blk(256);
 	if (words(md) == 1) {
-		if (md.nh <= 8) hipLaunchKernelGGL((k_kmback_emit<1, 8, 4>), grid, blk, 0, st, md, bd, kmers, surv, i0, pp, n_in_block, bs);
-		else hipLaunchKernelGGL((k_kmback_emit<1, 16, 2>), grid, blk, 0, st, md, bd, kmers, surv, i0, pp, n_in_block, bs);
+		if (md.nh <= 8) hipLaunchKernelGGL((k_kmback_emit<1, 8, 4>), grid, blk, 0, st, md, bd, kmers, surv, i0, istride, pp, n_in_block, bs);
+		else hipLaunchKernelGGL((k_kmback_emit<1, 16, 2>), grid, blk, 0, st, md, bd, kmers, surv, i0, istride, pp, n_in_block, bs);
 	} else {
-		if (md.nh <= 8) hipLaunchKernelGGL((k_kmback_emit<2, 8, 4>), grid, blk, 0, st, md, bd, kmers, surv, i0, pp, n_in_block, bs);
-		else hipLaunchKernelGGL((k_kmback_emit<2, 16, 2>), grid, blk, 0, st, md, bd, kmers, surv, i0, pp, n_in_block, bs);
+		if (md.nh <= 8) hipLaunchKernelGGL((k_kmback_emit<2, 8, 4>), grid, blk, 0, st, md, bd, kmers, surv, i0, istride, pp, n_in_block, bs);
+		else hipLaunchKernelGGL((k_kmback_emit<2, 16, 2>), grid, blk, 0, st, md, bd, kmers, surv, i0, istride, pp, n_in_block, bs);
 	}
 }
 void bs_apply(const BitScatter &bs, hipStream_t st)

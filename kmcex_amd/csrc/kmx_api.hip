@@ -36,16 +36,17 @@ void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int
 void block_init(const BlockDev &, int, int, int, hipStream_t);
 void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *, const KmbackJob *, const BitScatter *);
 void commit_flush(const ModelDev &, const BlockDev &, int, int, hipStream_t, KernelProf *);
-void rest_append(const ModelDev &, const BlockDev &, int, int, int, u64 *, int *, unsigned long long *, u64 *, int *, u64 *, hipStream_t);
-void kmback_emit(const ModelDev &, const BlockDev &, const u64 *, const unsigned char *, int, int, int, int, int, const BitScatter &, hipStream_t);
+void rest_append(const ModelDev &, const BlockDev &, int, int, int, u64 *, int *, unsigned long long *, u64 *, int *, u64 *, hipStream_t, int istride = 1);
+void kmback_emit(const ModelDev &, const BlockDev &, const u64 *, const unsigned char *, int, int, int, int, int, const BitScatter &, hipStream_t, int istride = 1);
 void bs_apply(const BitScatter &, hipStream_t);
 void ring_import(const ModelDev &, const BlockDev &, int, const RingLists &, u64 *, u32 *, hipStream_t);
 void ring_export(const ModelDev &, const BlockDev &, int, const RingLists &, hipStream_t);
 void or_words(u32 *, const u32 *, u64, hipStream_t);
 void range_emit(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, bool, hipStream_t);
-void range_verdict(const ModelDev &, const BlockDev &, int *, int, const u64 *, u64, unsigned char *, hipStream_t);
-void range_resolve(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, const unsigned char *, hipStream_t);
-void range_commit_apply(const ModelDev &, const u64 *, u64, hipStream_t);
+void range_seal(const RangeDev &, const RangePlan &, hipStream_t);
+void range_verdict(const ModelDev &, const BlockDev &, int *, int, const RangeIn &, unsigned char *, hipStream_t);
+void range_resolve(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, hipStream_t);
+void range_commit_apply(const ModelDev &, const RangeIn &, hipStream_t);
 void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *);
 void query_ascii(const ModelDev &, int, const unsigned char *, int, u64, int *, hipStream_t);
 void cells_from_disk(const unsigned char *, const unsigned char *, u64, cell_t *, u64, hipStream_t);
@@ -264,13 +265,24 @@ struct kmx_model {
 	// owner-side view of the block working set (overflow flags + padded bin counters for the detect kernel on received claims)
 	struct RangeState {
 		bool on = false;
-		bool pending = false;                                      // the send regions hold the last round's commits: the next emit appends to them
+		bool pending = false;                                      // a round was resolved since the last seal: its winners' commits sit in front of the regions
+		bool mailbox = false;                                      // the regions live in the owners' inboxes (kmx_build_from_kmc_multi_ex), not in d_send
 		RangeDev rd = {};
 		RangePlan plan = {};
+		RangeIn in = {};                                           // mailbox transport: this rank's inbox as its owner-side kernels see it
 		BlockDev obd = {};
-		int *d_oovf = nullptr, *h_cnt = nullptr;                   // h_cnt: pinned copy of rd.send_cnt
+		int *d_oovf = nullptr;
 		int *d_opcnt = nullptr;                                    // the owner's claim-bin counters, one per 128-byte line (k_range_verdict)
-		u64 alloc_key = 0;                                         // nb, nh, world the buffers were sized for
+		unsigned char *d_lver = nullptr;                           // one verdict byte per triple received in a round (detect answers there, k_range_ship sends it on)
+		// caller-moved transport (kmx_range_*_dev): the regions and their headers in this rank's memory
+		u64 *d_send = nullptr;
+		u32 *d_hdr = nullptr, *h_hdr = nullptr;                    // [KMX_MAX_RANKS][2]; h_: pinned copy
+		u64 sent_tot[KMX_MAX_RANKS] = {};                          // words per destination of the last emit (where each region's verdicts start in what comes back)
+		// mailbox transport: what the other ranks write into (through peer mappings when they sit on other devices)
+		u64 *d_inbox = nullptr;                                    // [world][cap] region of sender s
+		u32 *d_in_hdr = nullptr;                                   // [world][2]
+		unsigned char *d_vbox = nullptr;                           // [world][cap] verdict bytes of the words this rank sent to owner q
+		u64 alloc_key = 0;                                         // nb, nh, world, transport the buffers were sized for
 		int n0[KMX_MAX_NB] = {};                                   // entries of the held lists when the block came in (km_back is emitted once per block)
 	} range;
 	bool ring = false;                                         // built by several GPUs (kmx_shard_begin): this handle holds ONE rank's share
@@ -481,10 +493,10 @@ static void free_feed(kmx_model *m)
 static void free_range(kmx_model *m)
 {
 	auto &R = m->range;
-	hipFree(R.rd.send); hipFree(R.rd.send_cnt); hipFree(R.rd.tidx); hipFree(R.rd.contended); hipFree(R.rd.n_contended);
+	hipFree(R.d_send); hipFree(R.d_hdr); hipFree(R.rd.ccnt); hipFree(R.rd.tcnt); hipFree(R.rd.tidx); hipFree(R.rd.contended); hipFree(R.rd.n_contended);
 	hipFree(R.rd.rt_key); hipFree(R.rd.rt_resv); hipFree(R.rd.rt_mark); hipFree(R.rd.rt_eidx); hipFree(R.rd.rt_um);
-	hipFree(R.d_oovf); hipFree(R.d_opcnt);
-	if (R.h_cnt) hipHostFree(R.h_cnt);
+	hipFree(R.d_oovf); hipFree(R.d_opcnt); hipFree(R.d_lver); hipFree(R.d_inbox); hipFree(R.d_in_hdr); hipFree(R.d_vbox);
+	if (R.h_hdr) hipHostFree(R.h_hdr);
 	R = kmx_model::RangeState();
 }
 
@@ -1786,25 +1798,42 @@ static int kmx_shard_complete_impl(kmx_model *m, const uint64_t *d_rest_kmers, c
 // EVERY handle holds the whole model (replicas, as after dist.build_sharded).  Devices may repeat (several handles on one
 // GPU: how the one-GPU pool tests the protocol).
 namespace {
+// The host threads only ENQUEUE (nobody waits for a device between two barriers of a round), so a barrier is crossed within
+// microseconds: spin, and give the core away only when there are more threads than cores.
 struct HostBarrier {
-	std::mutex mu; std::condition_variable cv; int n, waiting = 0; unsigned long gen = 0;
+	std::atomic<int> waiting{0};
+	std::atomic<unsigned> gen{0};
+	int n;
 	explicit HostBarrier(int n_) : n(n_) {}
-	void wait() { std::unique_lock<std::mutex> lk(mu); const unsigned long g = gen; if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); } else cv.wait(lk, [&] { return gen != g; }); }
+	void wait()
+	{
+		const unsigned g = gen.load(std::memory_order_acquire);
+		if (waiting.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { waiting.store(0, std::memory_order_relaxed); gen.fetch_add(1, std::memory_order_release); return; }
+		for (int spins = 0; gen.load(std::memory_order_acquire) == g; spins++) { if (spins > 4000) std::this_thread::yield(); else __builtin_ia32_pause(); }
+	}
 };
 }   // namespace
 
 static int kmx_dev_view_impl(kmx_model *m, int which, int index, void **ptr, uint64_t *bytes);
 static int owner_of_array_ring(int a, int nb, int world) { return a * std::min(world, nb) / nb; }   // kmcex_amd/dist.py owner_of_array
 
-static int kmx_build_from_kmc_multi_impl(kmx_model **hs, int P, const char *db_prefix)
+static int range_begin_common(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world, bool mailbox);
+static int range_link(kmx_model **hs, int P, int d);
+static int range_list_emit(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists);
+static int range_owner_round(kmx_model *m, int t, const RangeIn &in);
+static int range_list_finish(kmx_model *m, int t);
+static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *db_prefix, int partition)
 {
 	if (!hs || !db_prefix || P < 1) return fail(KMX_E_ARG, "null argument");
+	if (partition != KMX_PARTITION_RING && partition != KMX_PARTITION_RANGE) return fail(KMX_E_ARG, "partition %d: KMX_PARTITION_RING or KMX_PARTITION_RANGE", partition);
+	const bool by_range = partition == KMX_PARTITION_RANGE;
+	if (by_range && P > KMX_MAX_RANKS) return fail(KMX_E_ARG, "the range partition takes up to %d handles", KMX_MAX_RANKS);
 	for (int d = 0; d < P; d++) {
 		if (!hs[d]) return fail(KMX_E_ARG, "null model");
 		if (hs[d]->ci != hs[0]->ci || hs[d]->cs != hs[0]->cs || hs[d]->nh != hs[0]->nh || hs[d]->nb != hs[0]->nb) return fail(KMX_E_ARG, "the handles of one model must share ci, cs, nh, nb");
 		for (int e = 0; e < d; e++) if (hs[e] == hs[d]) return fail(KMX_E_ARG, "a handle appears twice");
 	}
-	if (P == 1) return kmx_build_from_kmc_impl(hs[0], db_prefix);
+	if (P == 1 && !by_range) return kmx_build_from_kmc_impl(hs[0], db_prefix);      // (one handle, by range: the partition's kernels alone, every word "sent" to itself)
 	kmx::KmcListing db;
 	if (!db.open(db_prefix)) return fail(KMX_E_IO, "can't open the kmer_data_base %s: %s", db_prefix, db.error().c_str());
 	const int k = (int)db.kmer_length(), W = db.words(), nb = hs[0]->nb;
@@ -1825,13 +1854,13 @@ static int kmx_build_from_kmc_multi_impl(kmx_model **hs, int P, const char *db_p
 		u64 n = 0, n_c = 0, n_r = 0, rec_lo = 0;
 		uint64_t nbf[3] = {0, 0, 0};
 		std::vector<u64 *> msg;                                    // [nb * 2] list i, parity
-		hipEvent_t ev_round = nullptr, ev_copied = nullptr;
+		hipEvent_t ev_round = nullptr, ev_copied = nullptr;     // ring: the round is enqueued / the hand-offs are; range: the regions are sealed / the verdicts shipped
 		kmx_stats st;
 		void *rest_k = nullptr, *rest_c = nullptr;
 	};
 	std::vector<Rank> R((size_t)P);
 	std::vector<int> own((size_t)nb);
-	for (int a = 0; a < nb; a++) own[(size_t)a] = owner_of_array_ring(a, nb, P);
+	for (int a = 0; a < nb; a++) own[(size_t)a] = by_range ? a % P : owner_of_array_ring(a, nb, P);   // ring: who owns array a = who meets list a first; range: who holds list a
 	const u64 msg_words = ring_msg_bytes(k) / 8, blk = (u64)nb * KMX_BUCKET;
 	std::atomic<int> err{0};
 	std::mutex err_mu;
@@ -1879,7 +1908,7 @@ static int kmx_build_from_kmc_multi_impl(kmx_model **hs, int P, const char *db_p
 		if (d == 0) for (int q = 0; q < P; q++) for (int c = 0; c < 3; c++) nbf_all[c] += R[(size_t)q].nbf[c];
 		bar.wait();
 		// ---- sizes from the whole database (kmodel.hpp:402-456), front end on the slice (partial Bloom filters), the coupled class in order
-		if (!err) note(kmx_shard_begin_impl(m, k, nbf_all, db.kmer_count(), d, P));
+		if (!err) note(by_range ? range_begin_common(m, k, nbf_all, db.kmer_count(), d, P, true) : kmx_shard_begin_impl(m, k, nbf_all, db.kmer_count(), d, P));
 		if (!err) { uint64_t nc = 0; if (!note(kmx_shard_classify_dev_impl(m, (const uint64_t *)r.d_km, r.d_cnt, r.n, (uint64_t *)r.d_ck, r.d_cc, &nc))) r.n_c = nc; }
 		if (!err) hip_ok(hipStreamSynchronize(st), "classify");
 		bar.wait();
@@ -1907,13 +1936,57 @@ static int kmx_build_from_kmc_multi_impl(kmx_model **hs, int P, const char *db_p
 					}
 					at += g1 - g0;
 				}
-			r.msg.assign((size_t)nb * 2, nullptr);
-			for (auto &p : r.msg) if (ok) { ok = hip_ok(hipMalloc((void **)&p, msg_words * 8), "hipMalloc") && hip_ok(hipMemsetAsync(p, 0, msg_words * 8, st), "memset"); }
+			if (by_range) { if (ok) note(range_link(hs, P, d)); }          // (every handle allocated its inbox in range_begin, two barriers ago)
+			else {
+				try { r.msg.assign((size_t)nb * 2, nullptr); } catch (...) { fail(KMX_E_NOMEM, "out of memory"); note(KMX_E_NOMEM); ok = false; }
+				for (auto &p : r.msg) if (ok) { ok = hip_ok(hipMalloc((void **)&p, msg_words * 8), "hipMalloc") && hip_ok(hipMemsetAsync(p, 0, msg_words * 8, st), "memset"); }
+			}
 			if (ok) hip_ok(hipStreamSynchronize(st), "routing");
 		}
 		bar.wait();
-		// ---- the rounds (kmodel.hpp:560-565): this rank attempts the lists whose array it owns; survivors travel as messages
+		// ---- the rounds (kmodel.hpp:560-565), by range: this rank holds the lists i = d, d + P, ... for the whole block and owns a
+		// cell range of every array; the words of a round are written straight into the owners' inboxes (peer mappings), the
+		// verdict bytes straight into the senders' boxes, and two events per rank order the three steps -- the host threads
+		// only enqueue, nothing here waits for a device
 		u64 pos = 0;
+		if (by_range) {
+			auto wait_all = [&](bool emitted) {
+				for (int q = 0; q < P; q++)
+					if (q != d) hip_ok(hipStreamWaitEvent(st, emitted ? R[(size_t)q].ev_round : R[(size_t)q].ev_copied, 0), "wait");
+			};
+			for (u64 b = 0; b < n_blocks; b++) {
+				const u64 n_in_block = std::min<u64>(blk, n_km - b * blk);
+				if (!err && n_in_block < blk && b > 0) {                     // quirk Q1 (kmodel.hpp:520-527), on the rank that holds the list
+					const int row = (int)((n_in_block - 1) / KMX_BUCKET);
+					if (row + 1 < nb) note(kmx_ring_stale_dup_dev_impl(m, row + 1));
+				}
+				for (int t = 0; t < nb; t++) {
+					kmx_ring_list lists[KMX_MAX_NB];
+					int n_lists = 0;
+					if (t == 0)
+						for (int i = d; i < nb; i += P) {
+							kmx_ring_list &l = lists[n_lists++];
+							memset(&l, 0, sizeof l);
+							l.list = i; l.n_host = list_len(b, i);
+							l.src_kmers = r.d_rk + pos * W; l.src_counts = r.d_rc + pos;
+							pos += (u64)l.n_host;
+						}
+					if (!err) { hip_ok(hipSetDevice(m->device), "hipSetDevice"); note(range_list_emit(m, t, lists, n_lists)); }   // 1. commits of the round before + this round's triples -> the owners' inboxes
+					if (!err) hip_ok(hipEventRecord(r.ev_round, st), "event");
+					bar.wait();
+					if (!err) { wait_all(true); note(range_owner_round(m, t, m->range.in)); }     // 2. commits applied, one verdict byte per triple -> the senders' boxes
+					if (!err) hip_ok(hipEventRecord(r.ev_copied, st), "event");
+					bar.wait();
+					if (!err) { wait_all(false); note(range_list_finish(m, t)); }                  // 3. winners decided; their commits go to the front of the regions
+				}
+			}
+			if (n_blocks) {                                                   // the last round's commits
+				if (!err) { kmxk::range_seal(m->range.rd, m->range.plan, st); m->range.pending = false; hip_ok(hipEventRecord(r.ev_round, st), "event"); }
+				bar.wait();
+				if (!err) { wait_all(true); kmxk::range_commit_apply(m->md, m->range.in, st); hip_ok(hipGetLastError(), "commit"); }
+			}
+		} else
+		// ---- the rounds, ring: this rank attempts the lists whose array it owns; survivors travel as messages
 		for (u64 b = 0; b < n_blocks; b++) {
 			const u64 n_in_block = std::min<u64>(blk, n_km - b * blk);
 			if (!err && n_in_block < blk && b > 0) {                         // quirk Q1 (kmodel.hpp:520-527)
@@ -1921,8 +1994,9 @@ static int kmx_build_from_kmc_multi_impl(kmx_model **hs, int P, const char *db_p
 				if (row + 1 < nb) note(kmx_ring_stale_dup_dev_impl(m, row + 1));
 			}
 			for (int t = 0; t < nb; t++) {
-				std::vector<kmx_ring_list> lists;
-				std::vector<std::pair<int, int>> recvs, sends;             // (list, peer rank)
+				kmx_ring_list lists[KMX_MAX_NB];                             // (fixed arrays: nothing in a body may throw between two barriers)
+				std::pair<int, int> recvs[KMX_MAX_NB], sends[KMX_MAX_NB];   // (list, peer rank)
+				int n_lists = 0, n_recvs = 0, n_sends = 0;
 				for (int i = 0; i < nb; i++) {
 					const int n_i = list_len(b, i), a = (i + t) % nb;
 					if (n_i == 0) continue;
@@ -1933,15 +2007,16 @@ static int kmx_build_from_kmc_multi_impl(kmx_model **hs, int P, const char *db_p
 						l.dst_msg = t + 1 < nb ? r.msg[(size_t)i * 2 + ((t + 1) & 1)] : nullptr;
 						if (t == 0) { l.n_host = n_i; l.src_kmers = r.d_rk + pos * W; l.src_counts = r.d_rc + pos; pos += (u64)n_i; }
 						else { l.n_host = -1; l.src_msg = r.msg[(size_t)i * 2 + (t & 1)]; }
-						lists.push_back(l);
-						if (t + 1 < nb && own[(size_t)((a + 1) % nb)] != d) sends.push_back({i, own[(size_t)((a + 1) % nb)]});
-					} else if (t + 1 < nb && own[(size_t)((a + 1) % nb)] == d) recvs.push_back({i, own[(size_t)a]});
+						lists[n_lists++] = l;
+						if (t + 1 < nb && own[(size_t)((a + 1) % nb)] != d) sends[n_sends++] = {i, own[(size_t)((a + 1) % nb)]};
+					} else if (t + 1 < nb && own[(size_t)((a + 1) % nb)] == d) recvs[n_recvs++] = {i, own[(size_t)a]};
 				}
-				if (!err && !lists.empty()) note(kmx_ring_round_dev_impl(m, t, lists.data(), (int)lists.size()));
+				if (!err && n_lists) note(kmx_ring_round_dev_impl(m, t, lists, n_lists));
 				if (!err) hip_ok(hipEventRecord(r.ev_round, st), "event");
 				bar.wait();
 				if (!err) {
-					for (auto &rv : recvs) {                                 // the survivors of list rv.first, from the rank that just attempted it
+					for (int e = 0; e < n_recvs; e++) {                      // the survivors of list rv.first, from the rank that just attempted it
+						const std::pair<int, int> &rv = recvs[e];
 						const Rank &sr = R[(size_t)rv.second];
 						hip_ok(hipStreamWaitEvent(st, sr.ev_round, 0), "wait");
 						hip_ok(hipMemcpyPeerAsync(r.msg[(size_t)rv.first * 2 + ((t + 1) & 1)], m->device, sr.msg[(size_t)rv.first * 2 + ((t + 1) & 1)], hs[rv.second]->device, msg_words * 8, st), "hand-off");
@@ -1949,7 +2024,7 @@ static int kmx_build_from_kmc_multi_impl(kmx_model **hs, int P, const char *db_p
 					hip_ok(hipEventRecord(r.ev_copied, st), "event");
 				}
 				bar.wait();
-				if (!err) for (auto &sd : sends) hip_ok(hipStreamWaitEvent(st, R[(size_t)sd.second].ev_copied, 0), "wait");   // before this buffer is written again
+				if (!err) for (int e = 0; e < n_sends; e++) hip_ok(hipStreamWaitEvent(st, R[(size_t)sends[e].second].ev_copied, 0), "wait");   // before this buffer is written again
 				bar.wait();                                                 // (ev_round / ev_copied are recorded again only after everybody has enqueued its waits)
 			}
 		}
@@ -2010,6 +2085,13 @@ static int kmx_build_from_kmc_multi_impl(kmx_model **hs, int P, const char *db_p
 					filter(hs[0], which, idx, &theirs, &w2);
 					if (w) hip_ok(hipMemcpyPeerAsync(mine, m->device, theirs, hs[0]->device, w * 4, st), "filter copy");
 				}
+			if (by_range) {                                                   // every rank's cell range of every array
+				for (int a = 0; a < nb; a++)
+					for (int q = 0; q < P; q++) {
+						const u64 lo = m->range.plan.cell_lo[q], hi = m->range.plan.cell_lo[q + 1];
+						if (q != d && hi > lo) hip_ok(hipMemcpyPeerAsync(m->d_cells[a] + lo, m->device, hs[q]->d_cells[a] + lo, hs[q]->device, (hi - lo) * sizeof(cell_t), st), "array copy");
+					}
+			} else
 			for (int a = 0; a < nb; a++)
 				if (own[(size_t)a] != d) hip_ok(hipMemcpyPeerAsync(m->d_cells[a], m->device, hs[own[(size_t)a]]->d_cells[a], hs[own[(size_t)a]]->device, m->ncells * sizeof(cell_t), st), "array copy");
 			hip_ok(hipStreamSynchronize(st), "merge");
@@ -2025,8 +2107,24 @@ static int kmx_build_from_kmc_multi_impl(kmx_model **hs, int P, const char *db_p
 		if (r.ev_round) hipEventDestroy(r.ev_round);
 		if (r.ev_copied) hipEventDestroy(r.ev_copied);
 	};
+	// (a body must reach every barrier whatever happens to it: an exception -- bad_alloc in one of its vectors -- is noted like
+	// any other error and the walk goes on with empty steps; a thread that cannot be created leaves the build with an error
+	// before anybody waits for it)
 	std::vector<std::thread> th;
-	for (int d = 1; d < P; d++) th.emplace_back(body, d);
+	std::atomic<int> started{1};
+	try { th.reserve((size_t)P); } catch (...) { return fail(KMX_E_NOMEM, "out of memory"); }
+	bool spawned = true;
+	std::atomic<bool> go{false};
+	std::atomic<bool> cancel{false};
+	auto guarded_body = [&](int d) {
+		while (!go.load(std::memory_order_acquire)) { if (cancel.load(std::memory_order_acquire)) return; std::this_thread::yield(); }
+		body(d);
+	};
+	for (int d = 1; d < P && spawned; d++) {
+		try { th.emplace_back(guarded_body, d); started++; } catch (...) { spawned = false; }
+	}
+	if (!spawned) { cancel.store(true, std::memory_order_release); for (auto &x : th) x.join(); return fail(KMX_E_NOMEM, "cannot start %d host threads", P); }
+	go.store(true, std::memory_order_release);
 	body(0);
 	for (auto &x : th) x.join();
 	if (err) { snprintf(g_err, sizeof g_err, "%s", err_msg.c_str()); for (int d = 0; d < P; d++) if (hs[d]->state == ST_BUILDING) hs[d]->state = ST_EMPTY; return err; }
@@ -2038,29 +2136,44 @@ static int kmx_create_on_impl(int device, int ci, int cs, int nh, int nb, kmx_mo
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(KMX_E_NODEVICE, "no HIP device: libkmx has no CPU fallback");
 	if (device < 0 || device >= n) return fail(KMX_E_ARG, "device %d: this process sees %d", device, n);
+	int prev = -1;
+	if (hipGetDevice(&prev) != hipSuccess) prev = -1;
 	HIPCHK(hipSetDevice(device));
-	return kmx_create_impl(ci, cs, nh, nb, out);
+	const int rc = kmx_create_impl(ci, cs, nh, nb, out);
+	if (prev >= 0 && prev != device) (void)hipSetDevice(prev);      // the calling thread keeps its current device
+	return rc;
 }
 
 // ------------------------------------------------------------------------------------------ position-range partition (range_kernels.h)
-// Every coupled array cut by position range over the ranks (the north star's partition); the caller moves
-// the words between the ranks (two all-to-alls per round + a split-size exchange: kmcex_amd/dist.py build_sharded(partition="range")).
-static int kmx_range_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world)
+// Every coupled array cut by position range over the ranks (the north star's partition).  Between a list rank
+// and an owner lies one region of words with an in-band header; two transports move them: the CALLER's (kmx_range_*_dev below:
+// the regions live here, kmcex_amd/dist.py moves them with all-to-alls) and the MAILBOX (kmx_build_from_kmc_multi_ex: the
+// regions live in the owners' inboxes, written through peer mappings, the rounds ordered by events -- no host wait in a round).
+static int range_begin_common(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world, bool mailbox)
 {
 	if (world > KMX_MAX_RANKS) return fail(KMX_E_ARG, "the range partition takes up to %d ranks", KMX_MAX_RANKS);
 	TRY(kmx_shard_begin_impl(m, k, n_bf, n_total, rank, world));   // whole-model sizes; a rank works on its cell range of every array
 	if (m->km_byte_size * 8 > (1ULL << 36)) { m->state = ST_EMPTY; return fail(KMX_E_ARG, "the range partition addresses up to 2^36 positions per array"); }
 	auto &R = m->range;
 	const int nb = m->nb, nh = m->nh;
-	const u64 key = ((u64)nb << 32) | ((u64)nh << 16) | (u64)world;
+	const u64 key = ((u64)nb << 32) | ((u64)nh << 16) | ((u64)world << 1) | (mailbox ? 1u : 0u);
 	if (R.alloc_key != key) {
 		HIPCHK(hipStreamSynchronize(m->stream));
 		free_range(m);
 		const u64 held = (u64)((nb + world - 1) / world), slots = (u64)nb * KMX_BUCKET;
 		R.rd.cap = 2 * held * KMX_BUCKET * (u64)nh;                  // a round's triples behind the previous round's commits
 		R.rd.rt_bits = nh <= 8 ? 22 : 23;
-		TRY(dalloc(&R.rd.send, (u64)world * R.rd.cap, false, m->stream));
-		TRY(dalloc(&R.rd.send_cnt, (u64)KMX_MAX_RANKS * KMX_CTR_STRIDE, true, m->stream));
+		if (mailbox) {
+			TRY(dalloc(&R.d_inbox, (u64)world * R.rd.cap, false, m->stream));
+			TRY(dalloc(&R.d_in_hdr, (u64)KMX_MAX_RANKS * 2, true, m->stream));
+			TRY(dalloc(&R.d_vbox, (u64)world * R.rd.cap, false, m->stream));
+		} else {
+			TRY(dalloc(&R.d_send, (u64)world * R.rd.cap, false, m->stream));
+			TRY(dalloc(&R.d_hdr, (u64)KMX_MAX_RANKS * 2, true, m->stream));
+			HIPCHK(hipHostMalloc((void **)&R.h_hdr, sizeof(u32) * KMX_MAX_RANKS * 2));
+		}
+		TRY(dalloc(&R.rd.ccnt, (u64)KMX_MAX_RANKS * KMX_CTR_STRIDE, true, m->stream));
+		TRY(dalloc(&R.rd.tcnt, (u64)KMX_MAX_RANKS * KMX_CTR_STRIDE, true, m->stream));
 		TRY(dalloc(&R.rd.tidx, slots * nh, false, m->stream));
 		TRY(dalloc(&R.rd.contended, slots, false, m->stream));
 		TRY(dalloc(&R.rd.n_contended, (u64)KMX_MAX_NB * KMX_CTR_STRIDE, true, m->stream));
@@ -2071,20 +2184,34 @@ static int kmx_range_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uin
 		TRY(dalloc(&R.rd.rt_um, slots, false, m->stream));
 		TRY(dalloc(&R.d_oovf, (u64)KMX_MAX_NB, true, m->stream));
 		TRY(dalloc(&R.d_opcnt, (u64)KMX_MAX_NB * KMX_CL_MAXBINS * KMX_CTR_STRIDE, true, m->stream));
-		HIPCHK(hipHostMalloc((void **)&R.h_cnt, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE));
+		TRY(dalloc(&R.d_lver, slots * nh, false, m->stream));        // every triple of a round may come to one owner
 		R.alloc_key = key;
 	}
+	R.mailbox = mailbox;
 	HIPCHK(hipMemsetAsync(R.d_oovf, 0, sizeof(int) * KMX_MAX_NB, m->stream));
 	HIPCHK(hipMemsetAsync(R.rd.n_contended, 0, sizeof(int) * KMX_MAX_NB * KMX_CTR_STRIDE, m->stream));   // (k_range_resolve leaves them zero round by round)
 	HIPCHK(hipMemsetAsync(R.d_opcnt, 0, sizeof(int) * (u64)KMX_MAX_NB * KMX_CL_MAXBINS * KMX_CTR_STRIDE, m->stream));
+	HIPCHK(hipMemsetAsync(R.rd.ccnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, m->stream));         // (k_range_seal leaves them zero; an aborted build may not have)
+	HIPCHK(hipMemsetAsync(R.rd.tcnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, m->stream));
+	if (mailbox) HIPCHK(hipMemsetAsync(R.d_in_hdr, 0, sizeof(u32) * KMX_MAX_RANKS * 2, m->stream));
 	R.plan.rank = rank; R.plan.world = world;
 	for (int q = 0; q <= world; q++) R.plan.cell_lo[q] = (u64)(((unsigned __int128)m->ncells * (unsigned)q) / (unsigned)world);
+	for (int q = 0; q < KMX_MAX_RANKS; q++) {
+		R.rd.out[q] = (!mailbox && q < world) ? R.d_send + (u64)q * R.rd.cap : nullptr;      // (mailbox: range_link points them at the owners' inboxes)
+		R.rd.hdr_out[q] = (!mailbox && q < world) ? R.d_hdr + 2 * q : nullptr;
+		R.rd.vin[q] = nullptr;
+		R.sent_tot[q] = 0;
+	}
 	R.obd = m->bd;                                                  // (kmx_begin carved it; the claim bins are the owner's here)
 	R.obd.cl_cnt[0] = R.obd.cl_cnt[1] = R.d_opcnt;                  // (its detect reads the padded counters and reports per claim, in the verdict bytes)
 	R.obd.cl_ovf = R.d_oovf;
 	R.on = true;
 	R.pending = false;
 	return KMX_OK;
+}
+static int kmx_range_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world)
+{
+	return range_begin_common(m, k, n_bf, n_total, rank, world, false);
 }
 
 static int range_check(kmx_model *m, int t)
@@ -2095,25 +2222,13 @@ static int range_check(kmx_model *m, int t)
 	HIPCHK(hipSetDevice(m->device));
 	return KMX_OK;
 }
-// words per destination rank of what the last emit left in the send regions
-static int range_counts(kmx_model *m, uint64_t *counts)
-{
-	auto &R = m->range;
-	HIPCHK(hipMemcpyAsync(R.h_cnt, R.rd.send_cnt, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, hipMemcpyDeviceToHost, m->stream));
-	HIPCHK(hipStreamSynchronize(m->stream));
-	for (int q = 0; q < R.plan.world; q++) counts[q] = (uint64_t)R.h_cnt[q * KMX_CTR_STRIDE];
-	return KMX_OK;
-}
 
-// Round t, step 1, on the lists this rank holds (t == 0: `lists` are the fresh buffers of the block, i = rank, rank + world, ...;
-// later rounds work on what the last reorder left): triples by destination rank in the send regions, counts[world] on the host.
-static int kmx_range_emit_dev_impl(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists, uint64_t *counts)
+// ---- the three steps of a round, whatever moves the words (all enqueue only)
+// step 1, list rank: (t == 0: the fresh buffers of the block this rank holds, i = rank, rank + world, ...) triples by owner rank
+// behind the commits the last round left in front of the regions; the headers
+static int range_list_emit(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists)
 {
-	TRY(range_check(m, t));
-	if (!counts || (n_lists && !lists)) return fail(KMX_E_ARG, "null argument");
 	auto &R = m->range;
-	for (int q = 0; q < R.plan.world; q++) counts[q] = 0;
-	if (m->km_byte_size == 0) return KMX_OK;                       // divergence D2: no arrays to insert into
 	if (t == 0) {
 		RingLists rl;
 		memset(&rl, 0, sizeof rl);
@@ -2128,57 +2243,42 @@ static int kmx_range_emit_dev_impl(kmx_model *m, int t, const kmx_ring_list *lis
 		for (int i = 0; i < m->nb; i++) R.n0[i] = rl.e[i].active ? rl.e[i].n_host : 0;
 		kmxk::ring_import(m->md, m->bd, m->pp, rl, m->d_stg_kmers, m->d_stg_counts, m->stream);
 	}
-	kmxk::range_emit(m->md, m->bd, R.rd, R.plan, t, m->pp, !R.pending, m->stream);
-	R.pending = false;                                             // the caller ships the regions now: commits of the last round + these triples
-	HIPCHK(hipGetLastError());
-	return range_counts(m, counts);
-}
-
-static int kmx_range_buffers_impl(kmx_model *m, void **d_send, uint64_t *cap_words, uint64_t *cell_lo)
-{
-	if (!m || !m->range.on) return fail(KMX_E_STATE, "kmx_range_* before kmx_range_begin");
-	if (d_send) *d_send = m->range.rd.send;
-	if (cap_words) *cap_words = m->range.rd.cap;
-	if (cell_lo) for (int q = 0; q <= m->range.plan.world; q++) cell_lo[q] = m->range.plan.cell_lo[q];
-	return KMX_OK;
-}
-
-// step 2 on the owner: one verdict byte per received triple (same order)
-static int kmx_range_verdict_dev_impl(kmx_model *m, int t, const uint64_t *d_triples, uint64_t n, uint8_t *d_verdict)
-{
-	TRY(range_check(m, t));
-	if (n && (!d_triples || !d_verdict)) return fail(KMX_E_ARG, "null argument");
-	if (n >> KMX_RANGE_QBITS) return fail(KMX_E_ARG, "a round's exchange holds up to 2^%d words", KMX_RANGE_QBITS);   // (a claim tuple names its triple in that many bits)
-	if (m->km_byte_size == 0) return KMX_OK;
-	kmxk::range_verdict(m->md, m->range.obd, m->range.d_opcnt, t, (const u64 *)d_triples, n, d_verdict, m->stream);
+	kmxk::range_emit(m->md, m->bd, R.rd, R.plan, t, m->pp, false, m->stream);
+	R.pending = false;                                             // the regions are sealed: commits of the last round + these triples
 	HIPCHK(hipGetLastError());
 	return KMX_OK;
 }
-
-// step 3 on the list rank: verdicts (in the order the triples left) -> failures, winners, the contended in list order; the
-// winners' commits by destination rank in the send regions (counts[world] on the host); reorder, km_back, rest table
-static int kmx_range_resolve_dev_impl(kmx_model *m, int t, const uint8_t *d_verdict, uint64_t *counts)
+// step 2, owner: the commit words first, then one verdict byte per triple, to where its sender reads it
+static int range_owner_round(kmx_model *m, int t, const RangeIn &in)
 {
-	TRY(range_check(m, t));
-	if (!counts) return fail(KMX_E_ARG, "null argument");
+	kmxk::range_verdict(m->md, m->range.obd, m->range.d_opcnt, t, in, m->range.d_lver, m->stream);
+	HIPCHK(hipGetLastError());
+	return KMX_OK;
+}
+// step 3, list rank: verdicts -> failures, winners (their commits go to the front of the regions), the contended in list order;
+// reorder_buffer (:529-540); after the last round km_back and the rest table
+static int range_list_finish(kmx_model *m, int t)
+{
 	auto &R = m->range;
-	for (int q = 0; q < R.plan.world; q++) counts[q] = 0;
-	if (m->km_byte_size == 0) return KMX_OK;
 	const int nb = m->nb, pp = m->pp;
-	kmxk::range_resolve(m->md, m->bd, R.rd, R.plan, t, pp, d_verdict, m->stream);
-	R.pending = true;                                              // the winners' commits wait in the send regions for the next round's triples
-	HIPCHK(hipGetLastError());                                     // (their counts are read with the next emit's: no host wait here)
+	kmxk::range_resolve(m->md, m->bd, R.rd, R.plan, t, pp, m->stream);
+	R.pending = true;
+	HIPCHK(hipGetLastError());
 	m->pp ^= 1;
 	m->rounds++;
 	if (t == nb - 1) {
 		// the lists never leave their rank: survivors -> rest table, then km_back ONCE for the block -- every k-mer of a held list
 		// that is not a survivor was inserted in one of the rounds (kmodel.hpp:548-550), as in the single-GPU build
-		for (int i = R.plan.rank; i < nb; i += R.plan.world) {
-			TRY(ensure_rest_capacity(m, (u64)KMX_BUCKET + (u64)nb));
-			kmxk::rest_append(m->md, m->bd, m->pp, i, 1, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream);
-			if (R.n0[i] > 0) {
-				if (m->kmb_deferred) TRY(kmback_reserve(m, (u64)R.n0[i]));
-				kmxk::kmback_emit(m->md, m->bd, m->bd.kmers, m->bd.surv, i, 1, 0, m->pp, i * (int)KMX_BUCKET + R.n0[i], m->kmb, m->stream);
+		const int held = R.plan.rank < nb ? (nb - 1 - R.plan.rank) / R.plan.world + 1 : 0;
+		if (held) {
+			TRY(ensure_rest_capacity(m, (u64)held * KMX_BUCKET + (u64)nb));
+			kmxk::rest_append(m->md, m->bd, m->pp, R.plan.rank, held, m->d_rest_kmers, m->d_rest_counts, m->d_rest_n, m->d_stale_kmers, m->d_stale_counts, m->d_feedback, m->stream, R.plan.world);
+			u64 n_mine = 0;
+			int n_in_block = 0;                                        // (the held lists' lengths are what a block of this many k-mers gives them)
+			for (int i = R.plan.rank; i < nb; i += R.plan.world) { n_mine += (u64)R.n0[i]; if (R.n0[i] > 0) n_in_block = i * (int)KMX_BUCKET + R.n0[i]; }
+			if (n_mine) {
+				if (m->kmb_deferred) TRY(kmback_reserve(m, n_mine));
+				kmxk::kmback_emit(m->md, m->bd, m->bd.kmers, m->bd.surv, R.plan.rank, held, 0, m->pp, n_in_block, m->kmb, m->stream, R.plan.world);
 			}
 		}
 		m->blocks++;
@@ -2187,26 +2287,144 @@ static int kmx_range_resolve_dev_impl(kmx_model *m, int t, const uint8_t *d_verd
 	return KMX_OK;
 }
 
-// ... and on the owner: the winners' tag / value bits (kmodel.hpp:611-618)
+// ---- the mailbox transport (kmx_build_from_kmc_multi_ex): handle d's regions ARE the owners' inboxes.  Every handle of `hs`
+// has been through range_begin_common(..., mailbox); devices that differ get peer access to each other's memory.
+static int range_link(kmx_model **hs, int P, int d)
+{
+	kmx_model *m = hs[d];
+	auto &R = m->range;
+	HIPCHK(hipSetDevice(m->device));
+	for (int q = 0; q < P; q++) {
+		if (!hs[q]->range.on || !hs[q]->range.mailbox || hs[q]->range.rd.cap != R.rd.cap) return fail(KMX_E_STATE, "handle %d is not part of this range-partitioned build", q);
+		if (hs[q]->device != m->device) {
+			int can = 0;
+			HIPCHK(hipDeviceCanAccessPeer(&can, m->device, hs[q]->device));
+			if (!can) return fail(KMX_E_NODEVICE, "device %d cannot map the memory of device %d: no peer access", m->device, hs[q]->device);
+			const hipError_t e = hipDeviceEnablePeerAccess(hs[q]->device, 0);
+			if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(KMX_E_NODEVICE, "hipDeviceEnablePeerAccess(%d): %s", hs[q]->device, hipGetErrorString(e));
+			(void)hipGetLastError();
+		}
+		R.rd.out[q] = hs[q]->range.d_inbox + (u64)d * R.rd.cap;          // sender d's region in owner q's inbox
+		R.rd.hdr_out[q] = hs[q]->range.d_in_hdr + 2 * d;
+		R.rd.vin[q] = R.d_vbox + (u64)q * R.rd.cap;                      // owner q answers into this rank's box
+		R.in.reg[q] = R.d_inbox + (u64)q * R.rd.cap;                     // ... and as an owner: sender q's region here,
+		R.in.vout[q] = hs[q]->range.d_vbox + (u64)d * R.rd.cap;          // its verdicts into sender q's box
+	}
+	R.in.hdr = R.d_in_hdr;
+	R.in.world = P;
+	return KMX_OK;
+}
+
+// ---- the caller-moved transport (kmcex_amd/dist.py): the regions stay here, the caller reads the headers and ships the words
+static int range_read_headers(kmx_model *m, uint64_t *counts)
+{
+	auto &R = m->range;
+	HIPCHK(hipMemcpyAsync(R.h_hdr, R.d_hdr, sizeof(u32) * KMX_MAX_RANKS * 2, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipStreamSynchronize(m->stream));
+	for (int q = 0; q < R.plan.world; q++) {
+		counts[q] = (uint64_t)R.h_hdr[2 * q] + (uint64_t)R.h_hdr[2 * q + 1];
+		counts[R.plan.world + q] = (uint64_t)R.h_hdr[2 * q];
+		R.sent_tot[q] = counts[q];
+	}
+	return KMX_OK;
+}
+static int range_caller_moved(kmx_model *m)
+{
+	if (m->range.mailbox) return fail(KMX_E_STATE, "this build moves its words through the owners' inboxes");
+	return KMX_OK;
+}
+static int kmx_range_emit_dev_impl(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists, uint64_t *counts)
+{
+	TRY(range_check(m, t));
+	TRY(range_caller_moved(m));
+	if (!counts || (n_lists && !lists)) return fail(KMX_E_ARG, "null argument");
+	auto &R = m->range;
+	for (int q = 0; q < 2 * R.plan.world; q++) counts[q] = 0;
+	if (m->km_byte_size == 0) return KMX_OK;                       // divergence D2: no arrays to insert into
+	TRY(range_list_emit(m, t, lists, n_lists));
+	return range_read_headers(m, counts);
+}
+
+static int kmx_range_buffers_impl(kmx_model *m, void **d_send, uint64_t *cap_words, uint64_t *cell_lo)
+{
+	if (!m || !m->range.on) return fail(KMX_E_STATE, "kmx_range_* before kmx_range_begin");
+	if (d_send) *d_send = m->range.d_send;
+	if (cap_words) *cap_words = m->range.rd.cap;
+	if (cell_lo) for (int q = 0; q <= m->range.plan.world; q++) cell_lo[q] = m->range.plan.cell_lo[q];
+	return KMX_OK;
+}
+
+// what came in: the regions of the `n_src` senders back to back, totals[s] words each with commits[s] commit words in front;
+// the verdict bytes are laid out the same way (one per word; those of the commit words stay unwritten)
+static int range_in_of(kmx_model *m, const uint64_t *d_words, const uint64_t *totals, const uint64_t *commits, int n_src, uint8_t *d_verdict, RangeIn &in)
+{
+	memset(&in, 0, sizeof in);
+	if (n_src < 0 || n_src > KMX_MAX_RANKS) return fail(KMX_E_ARG, "%d regions", n_src);
+	u64 off = 0;
+	for (int s = 0; s < n_src; s++) {
+		if (commits[s] > totals[s] || totals[s] >> 32) return fail(KMX_E_ARG, "bad counts of region %d", s);
+		in.reg[s] = (const u64 *)d_words + off;
+		in.vout[s] = d_verdict ? d_verdict + off : nullptr;
+		in.nc[s] = (u32)commits[s]; in.nt[s] = (u32)(totals[s] - commits[s]);
+		off += totals[s];
+	}
+	in.world = n_src;
+	return KMX_OK;
+}
+static int kmx_range_verdict_dev_impl(kmx_model *m, int t, const uint64_t *d_words, const uint64_t *totals, const uint64_t *commits, int n_src, uint8_t *d_verdict)
+{
+	TRY(range_check(m, t));
+	TRY(range_caller_moved(m));
+	if (!totals || !commits) return fail(KMX_E_ARG, "null argument");
+	u64 n = 0, ntr = 0;
+	for (int s = 0; s < n_src && s < KMX_MAX_RANKS; s++) { n += totals[s]; ntr += totals[s] - commits[s]; }
+	if (n && (!d_words || !d_verdict)) return fail(KMX_E_ARG, "null argument");
+	if (ntr >> KMX_RANGE_QBITS) return fail(KMX_E_ARG, "a round's exchange holds up to 2^%d triples", KMX_RANGE_QBITS);   // (a claim tuple names its triple in that many bits)
+	if (m->km_byte_size == 0 || !n) return KMX_OK;
+	RangeIn in;
+	TRY(range_in_of(m, d_words, totals, commits, n_src, d_verdict, in));
+	return range_owner_round(m, t, in);
+}
+
+// verdicts in the order the words left (regions back to back, in rank order)
+static int kmx_range_resolve_dev_impl(kmx_model *m, int t, const uint8_t *d_verdict)
+{
+	TRY(range_check(m, t));
+	TRY(range_caller_moved(m));
+	auto &R = m->range;
+	if (m->km_byte_size == 0) return KMX_OK;
+	u64 off = 0;
+	for (int q = 0; q < R.plan.world; q++) { R.rd.vin[q] = d_verdict ? d_verdict + off : nullptr; off += R.sent_tot[q]; }
+	if (off && !d_verdict) return fail(KMX_E_ARG, "null argument");
+	return range_list_finish(m, t);
+}
+
+// ... and on the owner: the winners' tag / value bits of a last exchange (kmodel.hpp:611-618)
 static int kmx_range_commit_dev_impl(kmx_model *m, const uint64_t *d_commits, uint64_t n)
 {
 	TRY(range_check(m, 0));
+	TRY(range_caller_moved(m));
 	if (n && !d_commits) return fail(KMX_E_ARG, "null argument");
-	if (m->km_byte_size == 0) return KMX_OK;
-	kmxk::range_commit_apply(m->md, (const u64 *)d_commits, n, m->stream);
+	if (m->km_byte_size == 0 || !n) return KMX_OK;
+	RangeIn in;
+	const uint64_t tot[1] = {n};
+	TRY(range_in_of(m, d_commits, tot, tot, 1, nullptr, in));
+	kmxk::range_commit_apply(m->md, in, m->stream);
 	HIPCHK(hipGetLastError());
 	return KMX_OK;
 }
-// what is pending in the send regions (the commits of the last round) for a last exchange at the end of the build
+// end of the build: what is still pending in front of the regions (the commits of the last round) for a last exchange
 static int kmx_range_flush_dev_impl(kmx_model *m, uint64_t *counts)
 {
 	TRY(range_check(m, 0));
+	TRY(range_caller_moved(m));
 	if (!counts) return fail(KMX_E_ARG, "null argument");
 	auto &R = m->range;
-	for (int q = 0; q < R.plan.world; q++) counts[q] = 0;
+	for (int q = 0; q < 2 * R.plan.world; q++) counts[q] = 0;
 	if (!R.pending || m->km_byte_size == 0) return KMX_OK;
 	R.pending = false;
-	return range_counts(m, counts);
+	kmxk::range_seal(R.rd, R.plan, m->stream);
+	return range_read_headers(m, counts);
 }
 
 // device memory of one filter / array of this handle, for the collectives of the caller (which: as kmx_download; 3 = the
@@ -2925,12 +3143,13 @@ extern "C" int kmx_ring_stale_dup_dev(kmx_model *m, int first_unused_row) { retu
 extern "C" int kmx_shard_local(kmx_model *m, kmx_stats *partial, void **d_rest_kmers, void **d_rest_counts) { return guarded([&] { return kmx_shard_local_impl(m, partial, d_rest_kmers, d_rest_counts); }); }
 extern "C" int kmx_shard_complete(kmx_model *m, const uint64_t *d_rest_kmers, const int32_t *d_rest_counts, uint64_t n_rest, const kmx_stats *totals) { return guarded([&] { return kmx_shard_complete_impl(m, d_rest_kmers, d_rest_counts, n_rest, totals); }); }
 extern "C" int kmx_create_on(int device, int ci, int cs, int nh, int nb, kmx_model **out) { return guarded([&] { return kmx_create_on_impl(device, ci, cs, nh, nb, out); }); }
-extern "C" int kmx_build_from_kmc_multi(kmx_model **models, int n_models, const char *db_prefix) { return guarded([&] { return kmx_build_from_kmc_multi_impl(models, n_models, db_prefix); }); }
+extern "C" int kmx_build_from_kmc_multi(kmx_model **models, int n_models, const char *db_prefix) { return guarded([&] { return kmx_build_from_kmc_multi_ex_impl(models, n_models, db_prefix, KMX_PARTITION_RING); }); }
+extern "C" int kmx_build_from_kmc_multi_ex(kmx_model **models, int n_models, const char *db_prefix, int partition) { return guarded([&] { return kmx_build_from_kmc_multi_ex_impl(models, n_models, db_prefix, partition); }); }
 extern "C" int kmx_range_begin(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world) { return guarded([&] { return kmx_range_begin_impl(m, k, n_bf, n_total, rank, world); }); }
 extern "C" int kmx_range_buffers(kmx_model *m, void **d_send, uint64_t *cap_words, uint64_t *cell_lo) { return guarded([&] { return kmx_range_buffers_impl(m, d_send, cap_words, cell_lo); }); }
 extern "C" int kmx_range_emit_dev(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists, uint64_t *counts) { return guarded([&] { return kmx_range_emit_dev_impl(m, t, lists, n_lists, counts); }); }
-extern "C" int kmx_range_verdict_dev(kmx_model *m, int t, const uint64_t *d_triples, uint64_t n, uint8_t *d_verdict) { return guarded([&] { return kmx_range_verdict_dev_impl(m, t, d_triples, n, d_verdict); }); }
-extern "C" int kmx_range_resolve_dev(kmx_model *m, int t, const uint8_t *d_verdict, uint64_t *counts) { return guarded([&] { return kmx_range_resolve_dev_impl(m, t, d_verdict, counts); }); }
+extern "C" int kmx_range_verdict_dev(kmx_model *m, int t, const uint64_t *d_words, const uint64_t *totals, const uint64_t *commits, int n_src, uint8_t *d_verdict) { return guarded([&] { return kmx_range_verdict_dev_impl(m, t, d_words, totals, commits, n_src, d_verdict); }); }
+extern "C" int kmx_range_resolve_dev(kmx_model *m, int t, const uint8_t *d_verdict) { return guarded([&] { return kmx_range_resolve_dev_impl(m, t, d_verdict); }); }
 extern "C" int kmx_range_commit_dev(kmx_model *m, const uint64_t *d_commits, uint64_t n) { return guarded([&] { return kmx_range_commit_dev_impl(m, d_commits, n); }); }
 extern "C" int kmx_range_flush_dev(kmx_model *m, uint64_t *counts) { return guarded([&] { return kmx_range_flush_dev_impl(m, counts); }); }
 extern "C" int kmx_dev_view(kmx_model *m, int which, int index, void **ptr, uint64_t *bytes) { return guarded([&] { return kmx_dev_view_impl(m, which, index, ptr, bytes); }); }

@@ -170,9 +170,13 @@ struct RangePlan {
 	int rank, world;
 	u64 cell_lo[KMX_MAX_RANKS + 1];   // rank q owns the cells [cell_lo[q], cell_lo[q+1]) -- 16 positions each -- of every array
 };
+// Between a list rank and an owner lies one REGION of `cap` 64-bit words: the winners' commits of a round in front, the next
+// round's triples behind them, a header {commits, triples} beside it.  The list rank's side:
 struct RangeDev {
-	u64 *send;               // [world][cap] words leaving this rank, by destination (triples of a round, then its winners' commits)
-	int *send_cnt;           // [KMX_MAX_RANKS * KMX_CTR_STRIDE] words per destination
+	u64 *out[KMX_MAX_RANKS];             // out[q]: the region for owner q -- this rank's own memory (the caller moves the words) or owner q's inbox through a peer mapping
+	u32 *hdr_out[KMX_MAX_RANKS];         // hdr_out[q][0..1]: where k_range_seal leaves {commits, triples} of that region for owner q
+	const unsigned char *vin[KMX_MAX_RANKS];   // vin[q][off]: verdict byte of word `off` of the region for owner q
+	int *ccnt, *tcnt;        // [KMX_MAX_RANKS * KMX_CTR_STRIDE] commits / triples per destination written since the last seal
 	u64 cap;
 	u32 *tidx;               // [nb*BUCKET][nh] where the triple of hash j of a slot went: destination << 28 | index in its region
 	u32 *contended;          // [nb*BUCKET] slots of the contended candidates of a list (any order)
@@ -183,6 +187,14 @@ struct RangeDev {
 	u32 *rt_eidx;            // [nb*BUCKET][nh]
 	u32 *rt_um;              // [nb*BUCKET] per contended record (same index as `contended`): its positions wanted with both values
 	u32 rt_bits;
+};
+// ... and the owner's: what it received from every sender, and where the verdict bytes go
+struct RangeIn {
+	const u64 *reg[KMX_MAX_RANKS];       // region of sender s
+	unsigned char *vout[KMX_MAX_RANKS];  // vout[s][off]: where sender s reads the verdict of word `off` of its region (its own memory, possibly through a peer mapping)
+	const u32 *hdr;                      // hdr[2 s], hdr[2 s + 1]: commits / triples of region s, in device memory (in band) -- or null and
+	u32 nc[KMX_MAX_RANKS], nt[KMX_MAX_RANKS];   // the counts by value (the caller moved the words and knows them)
+	int world;
 };
 
 enum { SLOT_UNDECIDED = 0, SLOT_FAILED = 1, SLOT_INSERTED = 2, SLOT_CONTENDED = 3 };

@@ -4,24 +4,25 @@
 //
 // Rank q owns the cells [cell_lo[q], cell_lo[q+1]) -- 16 positions each -- of EVERY array.  List i of a block lives on rank
 // i % P for the whole block: it hashes its k-mers, keeps the list order and reorders locally (kmodel.hpp:529-540); k-mers
-// never move.  A round (all lists at once, list i against array (i + t) % nb, kmodel.hpp:560-565) is two all-to-alls (the
-// winners' commits of round t travel with the triples of round t + 1; a last exchange flushes them at the end of the build):
+// never move.  Between a list rank s and an owner q lies ONE REGION of 64-bit words (RangeDev::out[q]): the winners' commits of
+// round t in front, the triples of round t + 1 behind them, and a two-word header {commits, triples} (k_range_seal) -- the
+// counts travel IN BAND, no kernel of a round needs a number from the host.  Where the region lives is the transport's
+// business: in the owner's memory, written through a peer mapping (kmx_build_from_kmc_multi_ex: one process, the rounds ordered
+// by events), or in the sender's, moved by the caller's all-to-all (kmx_range_*_dev, kmcex_amd/dist.py).  A round (all lists at
+// once, list i against array (i + t) % nb, kmodel.hpp:560-565):
 //   1. k_range_emit        list rank: one TRIPLE (position, wanted value, list, slot, hash index) per position of every attempt,
-//                          binned by owner rank and, inside a workgroup's run, sorted by claim bin          -> all-to-all
-//   2. k_range_verdict     owner: reads the cell -- conflict with a set tag (kmodel.hpp:604-610) | untagged --, files every
-//      k_round_detect      untagged claim in the position-hashed bins of the single-GPU path (one atomic per wave and bin) and
-//      <..., RANGE>        lets ITS detect kernel find the positions wanted with both values by claims of this round: the owner
-//      k_range_verdict2    sees every claim on its positions, so contention is found where the bits live; detect answers in the
-//                          verdict byte of the triple a claim came from (verdict2: bin overflow only).  One byte per triple
-//                                                                                                          -> all-to-all back
+//      k_range_seal        by owner rank and, inside a workgroup's run, sorted by claim bin; header out        -> owner
+//   2. k_range_commit_apply owner: the commit words of every region first (the set loop kmodel.hpp:611-618 of the round before:
+//      k_range_verdict     the order the sequential algorithm has), then the cell of every triple -- conflict with a set tag
+//      k_round_detect      (kmodel.hpp:604-610) | untagged --; every untagged claim is filed in the position-hashed bins of the
+//      <..., RANGE>        single-GPU path (one atomic per wave and bin) and ITS detect kernel finds the positions wanted with both
+//      k_range_ship        values by claims of this round: the owner sees every claim on its positions, so contention is found
+//                          where the bits live.  One verdict byte per triple, shipped to where the sender reads it  -> list rank
 //   3. k_range_apply       list rank: a slot with a conflict anywhere has failed (final: bits are never cleared); a candidate
-//      k_range_resolve     none of whose untagged positions is wanted with both values wins outright; the others are decided
-//      k_range_commit_emit in list order from the verdicts alone, on their both-wanted positions (the only writers that can
-//                          matter to them are earlier contended winners): priority reservations on an exact position table,
-//                          the smallest undecided slot always wins its turn.  The winners' (position, value, array) words stay
-//                          in the send regions, IN FRONT of the next round's triples (bit 63 marks them): the owner applies
-//                          them (k_range_commit_apply) before it reads a cell for that round's verdicts -- the order the
-//                          sequential algorithm has.
+//      k_range_resolve     none of whose untagged positions is wanted with both values wins outright and its commit words go
+//                          straight to the front of the regions; the others are decided in list order from the verdicts alone, on
+//                          their both-wanted positions (the only writers that can matter to them are earlier contended winners):
+//                          priority reservations on an exact position table, the smallest undecided slot always wins its turn.
 // Then k_reorder and, after the last round, k_rest_append and the block's km_back emission -- the single-GPU kernels.
 #pragma once
 
@@ -43,9 +44,46 @@ __device__ __forceinline__ int range_owner(const RangePlan &pl, u64 cell)
 	return q;
 }
 
-// Appends this thread's `cnt` (<= NHM) words, each to the region of its destination rank: the workgroup counts per
-// destination in LDS, reserves each run with ONE global atomic, and remembers where every word went (where[j]).
-template <int NHM> __device__ __forceinline__ void range_block_append(const RangeDev &rd, int world, const u64 *word, const int *dest, u32 valid, u32 *where, int *s_cnt, int *s_base)
+// What an owner received: one region per sender; the counts from the headers (device memory) or, when the caller moved the
+// words and knows them, by value.  Staged in LDS (lanes index the regions independently: not from the kernel arguments).
+struct RangeInLds {
+	u32 pc[KMX_MAX_RANKS + 1], pt[KMX_MAX_RANKS + 1];   // exclusive prefix sums of the commits / triples over the regions
+	u32 nc[KMX_MAX_RANKS];                              // commits in front of region s
+	const u64 *reg[KMX_MAX_RANKS];
+	unsigned char *vout[KMX_MAX_RANKS];
+};
+__device__ __forceinline__ void range_in_stage(const RangeIn &in, RangeInLds &L)
+{
+	if (threadIdx.x == 0) {
+		u32 c = 0, t = 0;
+		for (int s = 0; s < in.world; s++) {
+			const u32 nc = in.hdr ? in.hdr[2 * s] : in.nc[s], nt = in.hdr ? in.hdr[2 * s + 1] : in.nt[s];
+			L.pc[s] = c; L.pt[s] = t; L.nc[s] = nc;
+			L.reg[s] = in.reg[s]; L.vout[s] = in.vout[s];
+			c += nc; t += nt;
+		}
+		L.pc[in.world] = c; L.pt[in.world] = t;
+	}
+	__syncthreads();
+}
+__device__ __forceinline__ int range_seg_of(const u32 *pre, int world, u32 q)
+{
+	int s = 0;
+#pragma unroll 1
+	while (s + 1 < world && q >= pre[s + 1]) s++;
+	return s;
+}
+// the list side's view of its regions, staged the same way
+struct RangeOutLds { u64 *out[KMX_MAX_RANKS]; };
+__device__ __forceinline__ void range_out_stage(const RangeDev &rd, int world, RangeOutLds &L)
+{
+	if ((int)threadIdx.x < world) L.out[threadIdx.x] = rd.out[threadIdx.x];
+	__syncthreads();
+}
+
+// Appends this thread's `cnt` (<= NHM) COMMIT words, each to the front part of the region of its destination rank: the workgroup
+// counts per destination in LDS and reserves each run with ONE global atomic.
+template <int NHM> __device__ __forceinline__ void range_block_append(const RangeDev &rd, const RangeOutLds &L, int world, const u64 *word, const int *dest, u32 valid, int *s_cnt, int *s_base)
 {
 	if ((int)threadIdx.x < world) s_cnt[threadIdx.x] = 0;
 	__syncthreads();
@@ -54,22 +92,19 @@ template <int NHM> __device__ __forceinline__ void range_block_append(const Rang
 	for (int j = 0; j < NHM; j++)
 		if ((valid >> j) & 1u) rank[j] = atomicAdd(&s_cnt[dest[j]], 1);
 	__syncthreads();
-	if ((int)threadIdx.x < world) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(rd.send_cnt + (int)threadIdx.x * KMX_CTR_STRIDE, s_cnt[threadIdx.x]) : 0;
+	if ((int)threadIdx.x < world) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(rd.ccnt + (int)threadIdx.x * KMX_CTR_STRIDE, s_cnt[threadIdx.x]) : 0;
 	__syncthreads();
 #pragma unroll
 	for (int j = 0; j < NHM; j++)
-		if ((valid >> j) & 1u) {
-			const u64 off = (u64)(s_base[dest[j]] + rank[j]);
-			rd.send[(u64)dest[j] * rd.cap + off] = word[j];
-			if (where) where[j] = ((u32)dest[j] << 28) | (u32)off;
-		}
+		if ((valid >> j) & 1u) L.out[dest[j]][(u64)(s_base[dest[j]] + rank[j])] = word[j];
 	__syncthreads();
 }
 
-// The same for a round's triples, SORTED by (destination, claim bin of the position) inside the workgroup's run: the owner files
-// untagged claims in the position-hashed bins of its list, and with the triples of one bin next to each other a wave there
-// reserves a run of tuples with ONE atomic instead of one per lane (k_range_verdict).  s_key: KMX_MAX_RANKS * 256 + 1 counters.
-template <int NHM> __device__ __forceinline__ void range_block_append_sorted(const RangeDev &rd, int world, const u64 *word, const int *dest, u32 valid, u32 *where, int *s_key, int *s_base, int *s_wsum)
+// The same for a round's triples, behind the commits, SORTED by (destination, claim bin of the position) inside the workgroup's
+// run: the owner files untagged claims in the position-hashed bins of its list, and with the triples of one bin next to each other
+// a wave there reserves a run of tuples with ONE atomic instead of one per lane (k_range_verdict).  s_key: KMX_MAX_RANKS * 256 + 1
+// counters.  where[j]: destination << 28 | index in its region (where the verdict byte will be).
+template <int NHM> __device__ __forceinline__ void range_block_append_sorted(const RangeDev &rd, const RangeOutLds &L, int world, const u64 *word, const int *dest, u32 valid, u32 *where, int *s_key, int *s_base, int *s_wsum)
 {
 	const int K = world * KMX_CL_MAXBINS;
 	for (int q = threadIdx.x; q <= K; q += 256) s_key[q] = 0;
@@ -102,14 +137,15 @@ template <int NHM> __device__ __forceinline__ void range_block_append_sorted(con
 	__syncthreads();
 	if ((int)threadIdx.x < world) {
 		const int tot = s_key[((int)threadIdx.x + 1) * KMX_CL_MAXBINS] - s_key[(int)threadIdx.x * KMX_CL_MAXBINS];
-		s_base[threadIdx.x] = tot ? atomicAdd(rd.send_cnt + (int)threadIdx.x * KMX_CTR_STRIDE, tot) : 0;
+		// (the commits of the round before are all in place: their counter is only read here)
+		s_base[threadIdx.x] = rd.ccnt[(int)threadIdx.x * KMX_CTR_STRIDE] + (tot ? atomicAdd(rd.tcnt + (int)threadIdx.x * KMX_CTR_STRIDE, tot) : 0);
 	}
 	__syncthreads();
 #pragma unroll
 	for (int j = 0; j < NHM; j++)
 		if ((valid >> j) & 1u) {
 			const u64 off = (u64)(s_base[dest[j]] + (s_key[key[j]] - s_key[dest[j] * KMX_CL_MAXBINS]) + rank[j]);
-			rd.send[(u64)dest[j] * rd.cap + off] = word[j];
+			L.out[dest[j]][off] = word[j];
 			where[j] = ((u32)dest[j] << 28) | (u32)off;
 		}
 	__syncthreads();
@@ -119,9 +155,11 @@ template <int NHM> __device__ __forceinline__ void range_block_append_sorted(con
 template <int W, int NHM> __global__ __launch_bounds__(256) void k_range_emit(ModelDev md, BlockDev bd, RangeDev rd, RangePlan pl, int t, int pp)
 {
 	__shared__ int s_key[KMX_MAX_RANKS * KMX_CL_MAXBINS + 1], s_base[KMX_MAX_RANKS], s_wsum[4];
+	__shared__ RangeOutLds L;
 	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
 	const int n = bd.n[pp][i];
 	if ((int)blockIdx.x * 256 >= n) return;                             // uniform
+	range_out_stage(rd, pl.world, L);
 	const u64 row = (u64)i * KMX_BUCKET;
 	const int a = (i + t) % md.nb;
 	if (x == 0) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
@@ -149,36 +187,74 @@ template <int W, int NHM> __global__ __launch_bounds__(256) void k_range_emit(Mo
 		bd.uw[pp][row + x] = bin << 16;                                  // the untagged mask arrives with the verdicts
 		bd.status[pp][row + x] = SLOT_UNDECIDED;
 	}
-	range_block_append_sorted<NHM>(rd, pl.world, word, dest, valid, where, s_key, s_base, s_wsum);
+	range_block_append_sorted<NHM>(rd, L, pl.world, word, dest, valid, where, s_key, s_base, s_wsum);
 	if (x < n)
 #pragma unroll
 		for (int j = 0; j < NHM; j++)
 			if (j < md.nh) rd.tidx[(row + x) * (u64)md.nh + j] = where[j];
 }
 
-// 2a. owner: the state of every claimed position; untagged claims go to the detect bins of their list
+// 1b. the header of every region goes to its owner: {commits in front, triples behind them}; the counters start over (the
+// next words this rank writes into a region are the commits of the round being decided, from its front)
+__global__ __launch_bounds__(64) void k_range_seal(RangeDev rd, int world)
+{
+	const int q = threadIdx.x;
+	if (q >= world) return;
+	const u32 nc = (u32)rd.ccnt[q * KMX_CTR_STRIDE], nt = (u32)rd.tcnt[q * KMX_CTR_STRIDE];
+	rd.hdr_out[q][0] = nc;
+	rd.hdr_out[q][1] = nt;
+	rd.ccnt[q * KMX_CTR_STRIDE] = 0;
+	rd.tcnt[q * KMX_CTR_STRIDE] = 0;
+}
+
+// 2a. owner: the winners' tag / value bits of the round before (kmodel.hpp:611-618), the commit words in front of every region
+// (ovf: the owner's overflow flags of the round before -- k_range_ship has read them -- are reset here, ahead of this round's k_range_verdict)
+__global__ __launch_bounds__(256) void k_range_commit_apply(ModelDev md, RangeIn in, int *ovf)
+{
+	__shared__ RangeInLds L;
+	if (ovf && blockIdx.x == 0 && (int)threadIdx.x < md.nb) ovf[threadIdx.x] = 0;
+	range_in_stage(in, L);
+	const u32 n = L.pc[in.world];
+	for (u32 c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
+		const int s = range_seg_of(L.pc, in.world, c);
+		const u64 tr = L.reg[s][c - L.pc[s]];
+		const u64 pos = RT_POS(tr);
+		const u32 b = bit_in_cell(pos);
+		atomicOr(md.cells[RT_LIST(tr)] + (pos >> 4), CELL_TAG(b) | (RT_WANT(tr) ? CELL_VAL(b) : 0u));
+	}
+}
+
+// 2b. owner: the state of every claimed position; untagged claims go to the detect bins of their list
 // (The bin counters of this kernel are PADDED, one per 128-byte line (pcnt[(list * bins + bin) * KMX_CTR_STRIDE]): every lane's
 // returning atomic goes to a counter of its own choosing, and with the 1280 counters of the claim bins packed into 80 lines the
 // lines serialised them -- 761 us per launch against 150 for the gathers; k_round_detect<..., RANGE> reads and resets the padded
-// form.  A claim tuple names the triple it came from, so that detect answers in that triple's verdict byte.)
+// form.  A claim tuple names the triple it came from -- its index q among ALL the triples received this round, regions in rank
+// order --, so that detect answers in that triple's verdict byte: lver[q].)
 // (The triples of a sender's workgroup arrive sorted by claim bin -- range_block_append_sorted --, so neighbouring lanes mostly file
 // into the same bin: the lanes of a wave that follow each other with the same (list, bin) reserve their tuples with ONE atomic.)
-template <int NHM> __global__ __launch_bounds__(256) void k_range_verdict(ModelDev md, BlockDev obd, int *pcnt, int t, const u64 *triples, u64 n, unsigned char *verdict)
+template <int NHM> __global__ __launch_bounds__(256) void k_range_verdict(ModelDev md, BlockDev obd, int *pcnt, int t, RangeIn in, unsigned char *lver)
 {
 	constexpr int NBIN = KMX_CL_BINS(NHM), CAP = KMX_CL_CAP_OF(NHM);
+	__shared__ RangeInLds L;
+	range_in_stage(in, L);
+	u32 n = L.pt[in.world];
+	if (n >> KMX_RANGE_QBITS) n = 0;                                    // (cannot happen: at most nb * 2^18 * nh <= 2^26 triples exist in a round)
 	const int lane = threadIdx.x & 63;
-	for (u64 base = (u64)blockIdx.x * 256; base < n; base += (u64)gridDim.x * 256) {   // (uniform trip count: the wave votes below)
-		const u64 q = base + threadIdx.x;
+	for (u32 base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {   // (uniform trip count: the wave votes below)
+		const u32 q = base + threadIdx.x;
 		const bool act = q < n;
-		const u64 tr = act ? triples[q] : RT_COMMIT;
-		const bool claim = !(tr & RT_COMMIT);                           // (a commit of the previous round was applied by the launch before this one)
+		u64 tr = 0;
+		if (act) {
+			const int s = range_seg_of(L.pt, in.world, q);
+			tr = L.reg[s][L.nc[s] + (q - L.pt[s])];
+		}
 		const u64 pos = RT_POS(tr);
 		const u32 i = RT_LIST(tr), want = RT_WANT(tr);
 		unsigned char v = 0;
 		u64 mx = 0;
 		u32 key = 0x80000000u | (u32)lane;                              // lanes without a claim: a key of their own
 		bool untagged = false;
-		if (claim) {
+		if (act) {
 			const int a = (int)((i + (u32)t) % (u32)md.nb);
 			const cell_t c = md.cells[a][pos >> 4];
 			const u32 b = bit_in_cell(pos);
@@ -205,61 +281,102 @@ template <int NHM> __global__ __launch_bounds__(256) void k_range_verdict(ModelD
 			if (g < CAP) obd.cl_tup[0][((u64)i * NBIN + (key & (KMX_CL_MAXBINS - 1))) * CAP + g] = CL_RANGE_TUPLE(mx, want, q);
 			else obd.cl_ovf[i] = 1;                                     // tuples lost: every untagged claim of the list counts as contended
 		}
-		if (act) verdict[q] = v;
+		if (act) lver[q] = v;
 	}
 }
-// 2b. k_round_detect<..., RANGE> on the owner's bins has marked the claims that sit on positions wanted with both values.  What
-// is left for this kernel is the rare overflow: a bin lost tuples (or does not fit its table), so every untagged claim of that
-// list counts as contended.
-__global__ __launch_bounds__(256) void k_range_verdict2(BlockDev obd, int nb, const u64 *triples, u64 n, unsigned char *verdict)
+// 2c. k_round_detect<..., RANGE> on the owner's bins has marked the claims that sit on positions wanted with both values (lver).
+// The verdict bytes go to where the senders read them: byte `off` of region s for the word `off` of that region.  (A bin that lost
+// tuples or does not fit its table: every untagged claim of that list counts as contended.)
+__global__ __launch_bounds__(256) void k_range_ship(BlockDev obd, int nb, RangeIn in, const unsigned char *lver)
 {
+	__shared__ RangeInLds L;
+	range_in_stage(in, L);
+	u32 n = L.pt[in.world];
+	if (n >> KMX_RANGE_QBITS) n = 0;
 	bool any = false;
 	for (int i = 0; i < nb; i++) any |= obd.cl_ovf[i] != 0;             // uniform
-	if (!any) return;
-	for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < n; q += (u64)gridDim.x * 256) {
-		const unsigned char v = verdict[q];
-		if ((v & RV_UNTAGGED) && obd.cl_ovf[RT_LIST(triples[q])]) verdict[q] = v | RV_BOTH;
+	for (u32 q = blockIdx.x * 256 + threadIdx.x; q < n; q += gridDim.x * 256) {
+		const int s = range_seg_of(L.pt, in.world, q);
+		const u32 off = L.nc[s] + (q - L.pt[s]);
+		unsigned char v = lver[q];
+		if (any && (v & RV_UNTAGGED) && obd.cl_ovf[RT_LIST(L.reg[s][off])]) v |= RV_BOTH;
+		L.vout[s][off] = v;
 	}
 }
 
-// 3a. list rank: the verdicts of a slot's positions, gathered from where its triples went
-template <int NHM> __global__ __launch_bounds__(256) void k_range_apply(ModelDev md, BlockDev bd, RangeDev rd, int world, int pp, const unsigned char *verdict)
+// 3a. list rank: the verdicts of a slot's positions, read from where its triples went; an uncontended winner's commit words --
+// one per position it saw untagged (kmodel.hpp:611-618) -- go straight to the front of the regions, by owner rank
+template <int NHM> __global__ __launch_bounds__(256) void k_range_apply(ModelDev md, BlockDev bd, RangeDev rd, RangePlan pl, int t, int pp)
 {
-	__shared__ int s_fail, s_cnt, s_base;
-	__shared__ u64 s_off[KMX_MAX_RANKS];
+	__shared__ int s_fail, s_cnt, s_base, s_acnt[KMX_MAX_RANKS], s_abase[KMX_MAX_RANKS];
+	__shared__ RangeOutLds L;
+	__shared__ const unsigned char *s_vin[KMX_MAX_RANKS];
 	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
 	const int n = bd.n[pp][i];
 	if ((int)blockIdx.x * 256 >= n) return;                             // uniform
-	if (threadIdx.x == 0) {
-		s_fail = 0; s_cnt = 0;
-		u64 o = 0;
-		for (int q = 0; q < world; q++) { s_off[q] = o; o += (u64)rd.send_cnt[q * KMX_CTR_STRIDE]; }   // the triples travelled grouped by destination, in rank order
-	}
-	__syncthreads();
+	if (threadIdx.x == 0) { s_fail = 0; s_cnt = 0; }
+	if ((int)threadIdx.x < pl.world) s_vin[threadIdx.x] = rd.vin[threadIdx.x];
+	range_out_stage(rd, pl.world, L);
 	const u64 row = (u64)i * KMX_BUCKET;
 	bool failed = false, contended = false;
-	u32 both_of_slot = 0;
+	u32 both_of_slot = 0, valid = 0;
+	u64 word[NHM];
+	int dest[NHM];
 	if (x < n) {
 		u32 um = 0, both = 0;
 #pragma unroll
 		for (int j = 0; j < NHM; j++)
 			if (j < md.nh) {
 				const u32 w = rd.tidx[(row + x) * (u64)md.nh + j];
-				const unsigned char v = verdict[s_off[w >> 28] + (w & 0x0FFFFFFFu)];
+				dest[j] = (int)(w >> 28);
+				const unsigned char v = s_vin[w >> 28][w & 0x0FFFFFFFu];
 				failed |= (v & RV_CONFLICT) != 0;
 				um |= (v & RV_UNTAGGED) ? 1u << j : 0u;
 				both |= (v & RV_BOTH) ? 1u << j : 0u;
 			}
 		contended = !failed && both != 0;
 		both_of_slot = both;
-		bd.uw[pp][row + x] |= um;
+		const u32 want = bd.uw[pp][row + x] >> 16;
+		bd.uw[pp][row + x] = (want << 16) | um;
 		if (failed) bd.status[pp][row + x] = SLOT_FAILED;
+		else if (!contended && um) {                                    // nobody wants the other value on any of its positions: it has won
+			const CRec<NHM> cr = crec_load<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh);
+			u64 pos[NHM];
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh) pos[j] = ((u64)crec_cell<NHM>(cr, j) << 4) | crec_nib<NHM>(cr, md.nh, j);
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh && ((um >> j) & 1u)) {
+					word[j] = RT_COMMIT | RT_MAKE(pos[j], value_at_position<NHM>(md, pos, um, want, j), (i + t) % md.nb, 0, 0);
+					valid |= 1u << j;
+				}
+		}
 	}
 	const u64 fm = __ballot(failed);
 	if ((threadIdx.x & 63) == 0 && fm) atomicAdd(&s_fail, (int)__popcll(fm));
 	const int slot = block_append_slot(rd.n_contended + i * KMX_CTR_STRIDE, contended, &s_cnt, &s_base);
 	if (contended) { rd.contended[row + slot] = (u32)x; rd.rt_um[row + slot] = both_of_slot; }
 	if (threadIdx.x == 0 && s_fail) atomicAdd(bd.tile_cnt[pp] + i * KMX_NTILES + (int)(blockIdx.x >> 2), s_fail);   // survivors per 1024-slot tile (k_reorder)
+	range_block_append<NHM>(rd, L, pl.world, word, dest, valid, s_acnt, s_abase);
+}
+
+// a contended candidate that won its turn in k_range_resolve: its commit words (few hundred per list and round: one atomic each)
+template <int NHM> __device__ __forceinline__ void range_winner_commits(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangeOutLds &L, const RangePlan &pl, int t, int pp, int i, u64 row, u32 x)
+{
+	const u32 uw = bd.uw[pp][row + x], um = uw & 0xFFFFu, want = uw >> 16;
+	const CRec<NHM> cr = crec_load<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh);
+	u64 pos[NHM];
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if (j < md.nh) pos[j] = ((u64)crec_cell<NHM>(cr, j) << 4) | crec_nib<NHM>(cr, md.nh, j);
+#pragma unroll
+	for (int j = 0; j < NHM; j++)
+		if (j < md.nh && ((um >> j) & 1u)) {
+			const int q = range_owner(pl, pos[j] >> 4);
+			const int off = atomicAdd(rd.ccnt + q * KMX_CTR_STRIDE, 1);
+			L.out[q][(u64)off] = RT_COMMIT | RT_MAKE(pos[j], value_at_position<NHM>(md, pos, um, want, j), (i + t) % md.nb, 0, 0);
+		}
 }
 
 // 3b. the contended candidates of a list, in list order, from the verdicts alone.  ONE workgroup per list.  Only the
@@ -276,7 +393,7 @@ template <int NHM> __global__ __launch_bounds__(256) void k_range_apply(ModelDev
 __device__ __forceinline__ u32 rt_hash(u64 pos) { return (u32)((pos * 0x9E3779B97F4A7C15ULL) >> 32); }
 constexpr int RT_LDS_BITS = 12, RT_LDS = 1 << RT_LDS_BITS, RT_RPT = 2;        // 4096 entries: key | mark in one u64 (32 KB) + reservations (16 KB)
 #define RT_LDS_MARK(v) (1ULL << (62 + (v)))
-template <int NHM> __device__ __forceinline__ u64 range_resolve_lds(const ModelDev &md, const BlockDev &bd, int pp, int i, u64 row, int nc, const u32 *cont, const u32 *bothm,
+template <int NHM> __device__ __forceinline__ u64 range_resolve_lds(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangeOutLds &Lo, const RangePlan &pl, int t, int pp, int i, u64 row, int nc, const u32 *cont, const u32 *bothm,
                                                                     u64 *s_key, u32 *s_resv, int *s_pending, int *s_succ)
 {
 	constexpr u32 TM = RT_LDS - 1;
@@ -343,6 +460,7 @@ template <int NHM> __device__ __forceinline__ u64 range_resolve_lds(const ModelD
 						atomicOr(&s_key[e[k][j]], RT_LDS_MARK(v));
 					}
 				bd.status[pp][row + x[k]] = SLOT_INSERTED;
+				range_winner_commits<NHM>(md, bd, rd, Lo, pl, t, pp, i, row, x[k]);
 				live[k] = false;
 				succ++;
 			}
@@ -369,15 +487,16 @@ template <int NHM> __device__ __forceinline__ u64 range_resolve_lds(const ModelD
 	}
 	return iters;
 }
-template <int NHM> __global__ __launch_bounds__(1024) void k_range_resolve(ModelDev md, BlockDev bd, RangeDev rd, int world, int pp)
+template <int NHM> __global__ __launch_bounds__(1024) void k_range_resolve(ModelDev md, BlockDev bd, RangeDev rd, RangePlan pl, int t, int pp)
 {
 	__shared__ int s_pending, s_succ, s_ent;
 	__shared__ u64 s_key[RT_LDS];
 	__shared__ u32 s_resv[RT_LDS];
-	const int i = blockIdx.x, tab = i / world;                          // the lists a rank holds are i = rank, rank + world, ...: one table each
+	const int i = blockIdx.x, tab = i / pl.world;                       // the lists a rank holds are i = rank, rank + world, ...: one table each
 	const int nc = rd.n_contended[i * KMX_CTR_STRIDE];
-	if (blockIdx.x == 0 && (int)threadIdx.x < world) rd.send_cnt[threadIdx.x * KMX_CTR_STRIDE] = 0;   // k_range_apply has read where the triples went: the regions now take the winners' commits
 	if (nc == 0) return;
+	__shared__ RangeOutLds Lo;
+	range_out_stage(rd, pl.world, Lo);
 	const u64 row = (u64)i * KMX_BUCKET;
 	const u32 *cont = rd.contended + row;
 	u32 *cur = rd.rt_um + row;                                          // per record: mask of both-wanted positions still believed untagged (| live)
@@ -390,7 +509,7 @@ template <int NHM> __global__ __launch_bounds__(1024) void k_range_resolve(Model
 	}
 	__syncthreads();
 	u64 iters = 0;
-	if (nc <= 1024 * RT_RPT && s_ent * 2 <= RT_LDS) iters = range_resolve_lds<NHM>(md, bd, pp, i, row, nc, cont, cur, s_key, s_resv, &s_pending, &s_succ);
+	if (nc <= 1024 * RT_RPT && s_ent * 2 <= RT_LDS) iters = range_resolve_lds<NHM>(md, bd, rd, Lo, pl, t, pp, i, row, nc, cont, cur, s_key, s_resv, &s_pending, &s_succ);
 	else {
 		int tb = 10;
 		while ((1u << tb) < 4u * (u32)nc * (u32)md.nh && tb < (int)rd.rt_bits) tb++;
@@ -455,6 +574,7 @@ template <int NHM> __global__ __launch_bounds__(1024) void k_range_resolve(Model
 						atomicOr(&mark[e], 1u << v);
 					}
 				bd.status[pp][row + x] = SLOT_INSERTED;
+				range_winner_commits<NHM>(md, bd, rd, Lo, pl, t, pp, i, row, x);
 				cur[r] = 0;
 				succ++;
 			}
@@ -491,91 +611,55 @@ template <int NHM> __global__ __launch_bounds__(1024) void k_range_resolve(Model
 	}
 }
 
-// 3c. the winners' tag / value bits, by owner rank: one word per position they saw untagged (kmodel.hpp:611-618)
-template <int NHM> __global__ __launch_bounds__(256) void k_range_commit_emit(ModelDev md, BlockDev bd, RangeDev rd, RangePlan pl, int t, int pp)
-{
-	__shared__ int s_cnt[KMX_MAX_RANKS], s_base[KMX_MAX_RANKS];
-	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-	const int n = bd.n[pp][i];
-	if ((int)blockIdx.x * 256 >= n) return;                             // uniform
-	const u64 row = (u64)i * KMX_BUCKET;
-	u64 word[NHM];
-	int dest[NHM];
-	u32 valid = 0;
-	if (x < n && bd.status[pp][row + x] != SLOT_FAILED) {
-		const u32 uw = bd.uw[pp][row + x], um = uw & 0xFFFFu, want = uw >> 16;
-		const CRec<NHM> cr = crec_load<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh);
-		u64 pos[NHM];
-#pragma unroll
-		for (int j = 0; j < NHM; j++)
-			if (j < md.nh) pos[j] = ((u64)crec_cell<NHM>(cr, j) << 4) | crec_nib<NHM>(cr, md.nh, j);
-#pragma unroll
-		for (int j = 0; j < NHM; j++)
-			if (j < md.nh && ((um >> j) & 1u)) {
-				word[j] = RT_COMMIT | RT_MAKE(pos[j], value_at_position<NHM>(md, pos, um, want, j), (i + t) % md.nb, 0, 0);
-				dest[j] = range_owner(pl, pos[j] >> 4);
-				valid |= 1u << j;
-			}
-	}
-	range_block_append<NHM>(rd, pl.world, word, dest, valid, nullptr, s_cnt, s_base);
-}
-// ... and their application on the owner: the commit words among what it received (the others are the round's triples)
-// (ovf: the owner's overflow flags of the round before -- k_range_verdict2 has read them -- are reset here, ahead of this round's k_range_verdict)
-__global__ __launch_bounds__(256) void k_range_commit_apply(ModelDev md, const u64 *words, u64 n, int *ovf)
-{
-	if (ovf && blockIdx.x == 0 && (int)threadIdx.x < md.nb) ovf[threadIdx.x] = 0;
-	for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < n; q += (u64)gridDim.x * 256) {
-		const u64 tr = words[q];
-		if (!(tr & RT_COMMIT)) continue;
-		const u64 pos = RT_POS(tr);
-		const u32 b = bit_in_cell(pos);
-		atomicOr(md.cells[RT_LIST(tr)] + (pos >> 4), CELL_TAG(b) | (RT_WANT(tr) ? CELL_VAL(b) : 0u));
-	}
-}
-
 namespace kmxk {
 
-static inline unsigned range_grid(u64 n) { return (unsigned)std::min<u64>((n + 255) / 256, 1u << 16); }
+// (the counts live on the device: every launch has a fixed grid that strides over what the headers say)
+static inline unsigned range_grid(const ModelDev &md) { return (unsigned)std::min<u64>(((u64)md.nb * KMX_BUCKET * (u64)md.nh / 4 + 255) / 256, 4096); }
 
-// fresh: nothing is pending in the send regions (else the triples are appended behind the previous round's commits)
+// step 1, list rank: the triples of round t behind the commits of the round before, then the headers.  fresh: a build starts
+// (no commits are pending and the counters may hold what an aborted build left)
 void range_emit(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangePlan &pl, int t, int pp, bool fresh, hipStream_t st)
 {
-	if (fresh) hipMemsetAsync(rd.send_cnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, st);
+	if (fresh) { hipMemsetAsync(rd.ccnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, st); hipMemsetAsync(rd.tcnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, st); }
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_range_emit<W, NHM>), dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, md, bd, rd, pl, t, pp));
+	hipLaunchKernelGGL(k_range_seal, dim3(1), dim3(64), 0, st, rd, pl.world);
 }
-// obd: the owner's view (its own overflow flags and padded bin counters; the claim bins of the handle, unused by the list side here)
-void range_verdict(const ModelDev &md, const BlockDev &obd_, int *pcnt, int t, const u64 *triples, u64 n, unsigned char *verdict, hipStream_t st)
+// the headers alone: the commits of the last round of a build
+void range_seal(const RangeDev &rd, const RangePlan &pl, hipStream_t st) { hipLaunchKernelGGL(k_range_seal, dim3(1), dim3(64), 0, st, rd, pl.world); }
+// step 2, owner.  obd: the owner's view (its own overflow flags and padded bin counters; the claim bins of the handle, unused by the
+// list side here); lver: one byte per triple received
+void range_verdict(const ModelDev &md, const BlockDev &obd_, int *pcnt, int t, const RangeIn &in, unsigned char *lver, hipStream_t st)
 {
-	if (!n) return;
 	BlockDev obd = obd_;
-	obd.rverdict = verdict;
-	hipLaunchKernelGGL(k_range_commit_apply, dim3(range_grid(n)), dim3(256), 0, st, md, triples, n, obd.cl_ovf);      // the previous round's winners first
+	obd.rverdict = lver;
+	const unsigned g = range_grid(md);
+	hipLaunchKernelGGL(k_range_commit_apply, dim3(g), dim3(256), 0, st, md, in, obd.cl_ovf);      // the previous round's winners first
 	if (md.nh <= 8) {
-		hipLaunchKernelGGL((k_range_verdict<8>), dim3(range_grid(n)), dim3(256), 0, st, md, obd, pcnt, t, triples, n, verdict);
+		hipLaunchKernelGGL((k_range_verdict<8>), dim3(g), dim3(256), 0, st, md, obd, pcnt, t, in, lver);
 		hipLaunchKernelGGL((k_round_detect<8, 1024, KMX_CL_TBITS(8), true>), dim3(KMX_CL_BINS(8), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, 0);
 	} else {
-		hipLaunchKernelGGL((k_range_verdict<16>), dim3(range_grid(n)), dim3(256), 0, st, md, obd, pcnt, t, triples, n, verdict);
+		hipLaunchKernelGGL((k_range_verdict<16>), dim3(g), dim3(256), 0, st, md, obd, pcnt, t, in, lver);
 		hipLaunchKernelGGL((k_round_detect<16, 1024, KMX_CL_TBITS(16), true>), dim3(KMX_CL_BINS(16), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, 0);
 	}
-	hipLaunchKernelGGL(k_range_verdict2, dim3(std::min(range_grid(n), 2048u)), dim3(256), 0, st, obd, md.nb, triples, n, verdict);   // (grid-stride; nearly always it only reads the flags)
+	hipLaunchKernelGGL(k_range_ship, dim3(std::min(g, 1024u)), dim3(256), 0, st, obd, md.nb, in, (const unsigned char *)lver);
 }
-void range_resolve(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangePlan &pl, int t, int pp, const unsigned char *verdict, hipStream_t st)
+// step 3, list rank
+void range_resolve(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangePlan &pl, int t, int pp, hipStream_t st)
 {
 	const dim3 grid(KMX_BUCKET / 256, md.nb);
 	if (md.nh <= 8) {
-		hipLaunchKernelGGL((k_range_apply<8>), grid, dim3(256), 0, st, md, bd, rd, pl.world, pp, verdict);
-		hipLaunchKernelGGL((k_range_resolve<8>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl.world, pp);      // (its first workgroup resets send_cnt)
-		hipLaunchKernelGGL((k_range_commit_emit<8>), grid, dim3(256), 0, st, md, bd, rd, pl, t, pp);
+		hipLaunchKernelGGL((k_range_apply<8>), grid, dim3(256), 0, st, md, bd, rd, pl, t, pp);
+		hipLaunchKernelGGL((k_range_resolve<8>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl, t, pp);
 	} else {
-		hipLaunchKernelGGL((k_range_apply<16>), grid, dim3(256), 0, st, md, bd, rd, pl.world, pp, verdict);
-		hipLaunchKernelGGL((k_range_resolve<16>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl.world, pp);      // (its first workgroup resets send_cnt)
-		hipLaunchKernelGGL((k_range_commit_emit<16>), grid, dim3(256), 0, st, md, bd, rd, pl, t, pp);
+		hipLaunchKernelGGL((k_range_apply<16>), grid, dim3(256), 0, st, md, bd, rd, pl, t, pp);
+		hipLaunchKernelGGL((k_range_resolve<16>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl, t, pp);
 	}
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, md.nb), dim3(256), 0, st, md, bd, t, pp, 0));   // (no REC_WON records here: Un stays 0)
 }
-void range_commit_apply(const ModelDev &md, const u64 *commits, u64 n, hipStream_t st)
+// the commit words of a last exchange
+void range_commit_apply(const ModelDev &md, const RangeIn &in, hipStream_t st)
 {
-	if (n) hipLaunchKernelGGL(k_range_commit_apply, dim3(range_grid(n)), dim3(256), 0, st, md, commits, n, (int *)nullptr);
+	hipLaunchKernelGGL(k_range_commit_apply, dim3(range_grid(md)), dim3(256), 0, st, md, in, (int *)nullptr);
 }
 
 }   // namespace kmxk

@@ -340,17 +340,19 @@ class DeviceEngine:
         return torch.cat(parts) if parts else self._send[:0]
 
     def range_emit(self, t, lists):
-        counts = self.m.range_emit_dev(t, [(l["list"], l["n"], l["kmers"].data_ptr() if l["n"] else 0, l["counts"].data_ptr() if l["n"] else 0) for l in lists])
-        return self._regions(counts), counts
+        """-> the regions back to back, words per destination, commit words among them (in front of each region)"""
+        counts, commits = self.m.range_emit_dev(t, [(l["list"], l["n"], l["kmers"].data_ptr() if l["n"] else 0, l["counts"].data_ptr() if l["n"] else 0) for l in lists])
+        return self._regions(counts), counts, commits
 
-    def range_verdict(self, t, triples):
-        ver = torch.empty(triples.numel(), dtype=torch.uint8, device=self.device)
-        if triples.numel():
-            self.m.range_verdict_dev(t, triples.data_ptr(), triples.numel(), ver.data_ptr())
+    def range_verdict(self, t, words, totals, commits):
+        """words: what the senders left for this rank, back to back (totals[s] words of sender s, commits[s] commit words in front)"""
+        ver = torch.empty(words.numel(), dtype=torch.uint8, device=self.device)
+        if words.numel():
+            self.m.range_verdict_dev(t, words.data_ptr(), totals, commits, ver.data_ptr())
         return ver
 
     def range_resolve(self, t, verdicts):
-        """the winners' commits stay in the send regions, in front of the next round's triples"""
+        """the winners' commits go to the front of the regions; the next emit appends its triples behind them"""
         self.m.range_resolve_dev(t, verdicts.data_ptr() if verdicts.numel() else 0)
 
     def range_flush(self):
@@ -526,10 +528,11 @@ def build_range_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: to
                     n_i = list_length(n_km, nb, b, i)
                     lists.append({"list": i, "n": n_i, "kmers": km_mine[pos:pos + n_i], "counts": cnt_mine[pos:pos + n_i]})
                     pos += n_i
-            words, out_counts = eng.range_emit(t, lists)                                # 1. last round's commits + this round's triples -> range owners
-            in_counts = comm.all_to_all_ints(out_counts, dev)
+            words, out_counts, out_commits = eng.range_emit(t, lists)                   # 1. last round's commits + this round's triples -> range owners
+            hdr = comm.all_to_all_ints([c | (cc << 32) for c, cc in zip(out_counts, out_commits)], dev)   # the regions' headers: words | commit words in front << 32
+            in_counts, in_commits = [h & 0xFFFFFFFF for h in hdr], [h >> 32 for h in hdr]
             got = comm.all_to_all_v(words, out_counts, in_counts)
-            ver = eng.range_verdict(t, got)                                             # 2. commits applied, one verdict byte per word back, same order
+            ver = eng.range_verdict(t, got, in_counts, in_commits)                      # 2. commits applied, one verdict byte per word back, same order
             back = comm.all_to_all_v(ver, in_counts, out_counts)
             eng.range_resolve(t, back)                                                  # 3. winners decided; their commits wait for the next round's triples
     if n_blocks:                                                                        # the last round's commits

@@ -82,11 +82,18 @@ class RangeOracleEngine(OracleEngine):
         p = np.concatenate([self.pending_p] + poss)
         self.pending_w, self.pending_p = np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
         sent, self.order, counts = self._by_dest(w, p)
-        return torch.from_numpy(sent.copy()), counts
+        dest_c = self._owner(p[: self.n_commits]) if self.n_commits else np.zeros(0, dtype=np.int64)
+        commits = np.bincount(dest_c, minlength=self.world).astype(np.int64).tolist()       # (in front of each region: the sort is stable)
+        return torch.from_numpy(sent.copy()), counts, commits
 
-    def range_verdict(self, t, words):
+    def range_verdict(self, t, words, totals, commits):
         allw = _np(words)
         is_commit = allw < 0                                        # bit 63
+        off = 0
+        for tot, nc in zip(totals, commits):                        # the headers say the same: commits[s] commit words in front of region s
+            assert is_commit[off: off + nc].all() and not is_commit[off + nc: off + tot].any()
+            off += tot
+        assert off == len(allw)
         self.range_commit(torch.from_numpy(np.ascontiguousarray(allw[is_commit])))       # the previous round's winners first
         ver_all = np.zeros(len(allw), dtype=np.uint8)
         tr = allw[~is_commit]

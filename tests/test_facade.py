@@ -38,18 +38,32 @@ def test_driver_reproduces_reference_model_files(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices", ["0,0", "0,0,0", "0,0,0,0,0"])
-def test_driver_on_several_devices_reproduces_reference_model_files(tmp_path, devices):
-    """KMX_DEVICES: KModel::init from C++ on several handles (all on device 0 here: the pool has one GPU) -- one host thread per
-    handle, the ring of whole arrays with hipMemcpyPeerAsync hand-offs (kmx_build_from_kmc_multi) -- writes the reference's files."""
+@pytest.mark.parametrize("devices,partition", [("0,0", "ring"), ("0,0,0", "ring"), ("0,0,0,0,0", "ring"), ("0", "range"), ("0,0", "range"), ("0,0,0", "range"), ("0,0,0,0,0,0,0,0", "range")])
+def test_driver_on_several_devices_reproduces_reference_model_files(tmp_path, devices, partition):
+    """KMX_DEVICES + KMX_PARTITION: KModel::init from C++ on several handles (all on device 0 here: the pool has one GPU) -- one
+    host thread per handle; the ring of whole arrays with hipMemcpyPeerAsync hand-offs, or the north star's position-range
+    partition with the words of a round written into the owners' inboxes (kmx_build_from_kmc_multi_ex) -- writes the reference's files."""
     exe = _compile(tmp_path)
     tiny = os.path.join(ROOT, "tests", "golden", "tiny")
-    env = dict(os.environ, KMC_BIN="/nonexistent", KMX_DEVICES=devices)
+    env = dict(os.environ, KMC_BIN="/nonexistent", KMX_DEVICES=devices, KMX_PARTITION=partition)
     p = subprocess.run([exe, "-k31", "-nh7", "-nb5", "-ci1", "-cs1023", "reads.fq", os.path.join(tiny, "db"), str(tmp_path)],
                        capture_output=True, text=True, env=env)
     assert p.returncode == 0, p.stdout + p.stderr
     for f in ("header", "km.bin", "rest.bin"):
         assert sha_file(os.path.join(str(tmp_path), "db", f)) == sha_file(os.path.join(tiny, f)), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("var,value", [("KMX_DEVICES", "0,,1"), ("KMX_DEVICES", "0,x"), ("KMX_DEVICES", "0,"), ("KMX_PARTITION", "hash")])
+def test_driver_rejects_settings_that_do_not_parse(tmp_path, var, value):
+    """a malformed KMX_DEVICES / KMX_PARTITION is an error message and exit(1), not a silent single-GPU build"""
+    exe = _compile(tmp_path)
+    tiny = os.path.join(ROOT, "tests", "golden", "tiny")
+    env = dict(os.environ, KMC_BIN="/nonexistent", KMX_DEVICES="0,0")
+    env[var] = value
+    p = subprocess.run([exe, "-k31", "-nh7", "-nb5", "-ci1", "-cs1023", "reads.fq", os.path.join(tiny, "db"), str(tmp_path)],
+                       capture_output=True, text=True, env=env)
+    assert p.returncode == 1 and var in p.stdout, p.stdout + p.stderr
 
 
 def test_facade_query_program_compiles(tmp_path):

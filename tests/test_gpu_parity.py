@@ -491,10 +491,14 @@ def test_init_from_kmc2_database_unsorted_listing(case, golden, tmp_path):
     assert sha_occ(m.kmer_to_occ_packed(query_set(km, k))) == g["occ_sha256"]
 
 
-@pytest.mark.parametrize("name,handles", [("k31_multiblock_ci1", 2), ("k31_multiblock_ci1", 5), ("k55_multiblock", 3), ("k31_multiblock_ci2", 4), ("tiny_k31", 8)])
-def test_init_by_several_handles_from_cxx(name, handles, golden, tmp_path):
-    """kmx_build_from_kmc_multi: KModel::init(db) by several handles from ONE process (here all on device 0), a host thread
-    each, the ring of whole arrays with peer copies.  EVERY handle ends with the reference's files; statistics and answers too."""
+@pytest.mark.parametrize("partition", ["ring", "range"])
+@pytest.mark.parametrize("name,handles", [("k31_multiblock_ci1", 2), ("k31_multiblock_ci1", 5), ("k55_multiblock", 3), ("k31_multiblock_ci2", 4), ("tiny_k31", 8),
+                                          ("k31_multiblock_ci1", 1), ("k27_ci3_nb8", 3), ("k31_nh3_nb1", 3)])
+def test_init_by_several_handles_from_cxx(name, handles, partition, golden, tmp_path):
+    """kmx_build_from_kmc_multi_ex: KModel::init(db) by several handles from ONE process (here all on device 0), a host thread
+    each.  "ring": whole arrays, peer copies.  "range" (the north star's partition): every array cut by position range, the
+    words of a round written straight into the owners' inboxes, events between the steps, no host wait inside a round.
+    EVERY handle ends with the reference's files; statistics and answers too."""
     from kmcex_amd import api
     _, k, ci, cs, nh, nb, n = CASE[name]
     g = golden["cases"][name]
@@ -502,7 +506,7 @@ def test_init_by_several_handles_from_cxx(name, handles, golden, tmp_path):
     db = str(tmp_path / "db")
     kmcdb.write_kmc1(db, km, cnt, k, ci, cs)
     ms = [KModel(ci, cs, nh, nb) for _ in range(handles)]
-    api.init_multi(ms, db)
+    api.init_multi(ms, db, partition)
     for j, m in enumerate(ms):
         out = str(tmp_path / f"m{j}")
         os.makedirs(out)
@@ -512,11 +516,14 @@ def test_init_by_several_handles_from_cxx(name, handles, golden, tmp_path):
         st = m.stats()
         assert (st.attempts, st.successes, st.rest_entries) == (g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
     assert sha_occ(ms[-1].kmer_to_occ_packed(query_set(km, k))) == g["occ_sha256"]
+    api.init_multi(ms, db, partition)                               # a second build on the same handles (buffers, inboxes and events are kept or re-made)
+    assert sha_occ(ms[0].kmer_to_occ_packed(query_set(km, k))) == g["occ_sha256"]
     for m in ms:
         m.close()
 
 
-def test_init_by_several_handles_unsorted_listing(golden, tmp_path):
+@pytest.mark.parametrize("partition", ["ring", "range"])
+def test_init_by_several_handles_unsorted_listing(partition, golden, tmp_path):
     """the same on a KMC2-layout database (bin-major listing): the slices of the ranks follow the listing, not the sorted order"""
     from kmcex_amd import api
     name, k, ci, cs, nh, nb, n, n_bins = KMC2_CASES[0]
@@ -525,7 +532,7 @@ def test_init_by_several_handles_unsorted_listing(golden, tmp_path):
     db = str(tmp_path / "db")
     kmcdb.write_kmc2(db, km, cnt, k, ci, cs, n_bins=n_bins)
     ms = [KModel(ci, cs, nh, nb) for _ in range(3)]
-    api.init_multi(ms, db)
+    api.init_multi(ms, db, partition)
     out = str(tmp_path / "m")
     os.makedirs(out)
     ms[1].save(out)
