@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-init-db", action="store_true", help="skip the KModel::init(database) leg")
     ap.add_argument("--no-query-strings", action="store_true", help="skip the kmer_to_occ(vector<string>) leg")
+    ap.add_argument("--genome-bases", type=int, default=30_000_000, help="bases of the genome-like stream of the query_genome leg (0 = skip)")
     ap.add_argument("--no-single-model", action="store_true", help="skip the one-model-over-all-ranks leg")
     ap.add_argument("--single-model-steps", type=int, default=0, help="0: --steps when N > 1 (it is the headline there), 2 at N = 1")
     ap.add_argument("--no-other-partition", action="store_true", help="N > 1: do not also time the partition that was not selected")
@@ -92,15 +93,62 @@ def write_kmc1_from_device(prefix, km, cnt, k, ci, cs):
         f.write(b"KMCP")
 
 
-def init_db_leg(a, km, cnt, reps=3):
-    """KModel::init(db_file) end to end (kmodel.hpp:57-86): listing decode on the host cores, pinned H2D, insert, rest build."""
+def write_kmc2_from_device(prefix, km, cnt, k, ci, cs, n_bins=512, signature_len=5):
+    """The same listing in the layout KMC 3 itself writes (version 0x200, kmc_file.cpp:188-235): records bin-major, one LUT per
+    bin, sorted only inside a bin -- the listing (and so the insert order) is not globally sorted.  The bin of a k-mer is a hash
+    of it (the listing reader never looks at signatures; kmcex_amd/kmcdb.py write_kmc2 is the numpy twin).  Returns the listing order."""
+    import struct
+    from kmcex_amd import kmcdb
+    p = kmcdb.lut_prefix_len(k)
+    sb = (k - p) // 4
+    csz = 1
+    while cs >= (1 << (8 * csz)):
+        csz += 1
+    n = km.numel()
+    h = (km * (-7046029254386353131)) >> 40                       # 0x9E3779B97F4A7C15 as int64: same bits as the uint64 product
+    bins = (h & ((1 << 24) - 1)) % n_bins
+    order = torch.sort(bins, stable=True).indices                 # the input is sorted, so every bin stays sorted
+    kmo, cno, bo = km[order], cnt[order], bins[order]
+    del h, bins
+    with open(prefix + ".kmc_suf", "wb") as f:
+        f.write(b"KMCS")
+        step = 1 << 25
+        for lo in range(0, n, step):
+            x, c = kmo[lo:lo + step], cno[lo:lo + step].to(torch.int64)
+            cols = [((x >> (8 * (sb - 1 - j))) & 0xFF).to(torch.uint8) for j in range(sb)] + [((c >> (8 * b)) & 0xFF).to(torch.uint8) for b in range(csz)]
+            f.write(torch.stack(cols, dim=1).cpu().numpy().tobytes())
+        f.write(b"KMCS")
+    key = bo * (4 ** p) + (kmo >> (2 * (k - p)))                  # (bin, prefix) ascending along the file
+    lut = torch.searchsorted(key, torch.arange(n_bins * 4 ** p, dtype=torch.int64, device=km.device), right=False).cpu().numpy().astype(np.uint64)
+    sig_map = np.zeros(4 ** signature_len + 1, dtype=np.uint32)
+    hdr = struct.pack("<IIIIIIIQB", k, 0, csz, p, signature_len, ci, cs & 0xFFFFFFFF, n, 0)
+    hdr = hdr + b"\0" * (60 - len(hdr)) + struct.pack("<I", 0x200)
+    with open(prefix + ".kmc_pre", "wb") as f:
+        f.write(b"KMCP")
+        f.write(lut.tobytes())
+        f.write(struct.pack("<Q", n))
+        f.write(sig_map.tobytes())
+        f.write(hdr)
+        f.write(struct.pack("<I", 64))
+        f.write(b"KMCP")
+    return order
+
+
+def init_db_leg(a, km, cnt, reps=3, layout="kmc1"):
+    """KModel::init(db_file) end to end (kmodel.hpp:57-86): listing decode on the host cores, pinned H2D, insert, rest build.
+    layout "kmc1": one sorted listing (KMC 1 / the reference's test databases); "kmc2": what KMC 3 writes -- 512 bins, each
+    sorted, listed bin by bin (kmc_file.cpp:188-235): another insert order, another (equally valid) model."""
     import shutil
     from kmcex_amd import KModel
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     tmp = tempfile.mkdtemp(prefix="kmx_bench_db_", dir=base)
+    tag = "init_db" if layout == "kmc1" else "init_db_kmc2"
     try:
         db = os.path.join(tmp, "db")
-        write_kmc1_from_device(db, km, cnt, a.k, a.ci, a.cs)
+        if layout == "kmc1":
+            write_kmc1_from_device(db, km, cnt, a.k, a.ci, a.cs)
+        else:
+            write_kmc2_from_device(db, km, cnt, a.k, a.ci, a.cs)
         m = KModel(a.ci, a.cs, a.nh, a.nb)
         ts = []
         for _ in range(reps + 1):                                 # first call allocates: warm-up
@@ -110,11 +158,67 @@ def init_db_leg(a, km, cnt, reps=3):
         st = m.stats()
         m.close()
         best, mean = min(ts[1:]), sum(ts[1:]) / reps
-        return {"init_db_value": km.numel() / mean, "init_db_ms": mean * 1e3, "init_db_best_ms": best * 1e3, "init_db_reps": reps,
-                "init_db_what": "KModel::init(database in tmpfs): KMC listing decode + pinned hipMemcpyAsync + insert + rest build, wall clock",
-                "init_db_attempts": st.attempts, "init_db_bytes": os.path.getsize(db + ".kmc_suf")}
+        what = ("KModel::init(database in tmpfs): KMC listing decode + pinned hipMemcpyAsync + insert + rest build, wall clock" if layout == "kmc1" else
+                "the same on a KMC2-layout database (what KMC 3 writes): 512 bins listed bin by bin, unsorted insert order")
+        return {f"{tag}_value": km.numel() / mean, f"{tag}_ms": mean * 1e3, f"{tag}_best_ms": best * 1e3, f"{tag}_reps": reps,
+                f"{tag}_what": what, f"{tag}_attempts": st.attempts, f"{tag}_bytes": os.path.getsize(db + ".kmc_suf")}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def genome_leg(a, dev, n_bases, reps=2):
+    """Throughput where the data is NOT uniformly random: all overlapping k-mers of a random sequence (their de Bruijn
+    neighbours are in the set, which is what the query's neighbour disambiguation, kmodel.hpp:286-359, feeds on).  Insert,
+    query of the stored k-mers, query of their successors (3 of 4 absent), and -- from one accounting pass, never timed --
+    the fraction of queries that entered the neighbour path."""
+    from kmcex_amd import KModel, synth_torch
+    k = a.k
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    bases = torch.randint(0, 4, (n_bases,), dtype=torch.int64, device=dev, generator=g)
+    n = n_bases - k + 1
+    v = torch.zeros(n, dtype=torch.int64, device=dev)
+    for j in range(k):
+        v = (v << 2) | bases[j:j + n]
+    v &= (1 << (2 * k)) - 1
+    del bases
+    km = torch.unique(torch.minimum(v, synth_torch.revcomp(v, k)), sorted=True)
+    del v
+    cnt = synth_torch.d1_counts(km.numel(), a.ci, a.cs, 2, dev)
+    n = km.numel()
+    m = KModel(a.ci, a.cs, a.nh, a.nb)
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    succ = ((km[: n // 2] << 2) | 1) & ((1 << (2 * k)) - 1)        # successors of stored k-mers: 1 of 4 is in the sequence
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+
+    def timed(fn):
+        ts = []
+        for _ in range(reps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return sum(ts[1:]) / reps
+    t_ins = timed(lambda: m.build_dev(k, km.data_ptr(), cnt.data_ptr(), n))
+    t_q = timed(lambda: m.kmer_to_occ_dev(km.data_ptr(), n, out.data_ptr()))
+    t_s = timed(lambda: m.kmer_to_occ_dev(succ.data_ptr(), succ.numel(), out.data_ptr()))
+    nonzero = float((out[: succ.numel()] != 0).float().mean().item())
+    m.set_profile(2)                                              # accounting variant of the query kernel
+    m.kmer_to_occ_dev(km.data_ptr(), n, out.data_ptr())
+    f_stored = m.stats().query_neighbour_calls / n
+    m.kmer_to_occ_dev(succ.data_ptr(), succ.numel(), out.data_ptr())
+    f_succ = m.stats().query_neighbour_calls / succ.numel()
+    m.set_profile(False)
+    st = m.stats()
+    m.close()
+    return {"genome_bases": n_bases, "genome_kmers": n, "genome_insert_value": n / t_ins, "genome_insert_ms": t_ins * 1e3,
+            "query_genome_value": n / t_q, "query_genome_ms": t_q * 1e3,
+            "query_genome_successors_value": succ.numel() / t_s, "query_genome_successors_answered_nonzero": nonzero,
+            "query_genome_neighbour_path_fraction": {"stored": f_stored, "successors": f_succ},
+            "genome_attempts_per_kmer": st.attempts / max(st.n_km, 1),
+            "genome_what": f"all overlapping {k}-mers of a random {n_bases}-base sequence, canonical, distinct, D1 counts: insert (kmx_build_dev), "
+                           "kmer_to_occ of the stored k-mers and of their successors, resident in HBM; neighbour_path_fraction from an accounting pass"}
 
 
 def source_digest():
@@ -433,6 +537,18 @@ def main():
         foot = max(int(st.km_byte_size) * 2 * a.nb, 1 << 26)              # the cells of all arrays (4 bytes per 16 positions)
         tg = api.microbench(8, foot, 1 << 27, 3)                           # 4-byte random loads: what check_emit issues
         ta = api.microbench(5, foot, 1 << 27, 3)                           # 32-bit random atomic ORs: what commit issues
+        tp = api.microbench(20, foot, 1 << 27, 3)                          # both side by side on two streams: ONE budget of random DRAM operations
+        pair_ops = 3.0 * (1 << 27) / tp                                    # a gather = 1 operation, an atomic = a read + a write
+        if traffic:
+            roof["traffic_frac"] = traffic / (dv["seconds"] / max(dv["launches"], 1)) / 8e12     # what the memory system really moved per launch / its time / 8 TB/s
+        roof["note"] = ("achieved prices a touched position at G = 32 B (SURVEY 8d); at the fabric a random 4-byte load fetches 64 B "
+                        "(calibration in the PMC file), so traffic > alg_bytes_per_launch is the access granule, not re-reads: traffic_frac is the HBM rate")
+        if dom == "commit_check" and stp.piped_gathers:
+            ops = stp.piped_gathers + 2 * stp.piped_atomics                # the random DRAM operations a whole build needs (its fused launches issue all of them)
+            roof["budget_frac_whole_build"] = ops / (t_ins / a.steps) / pair_ops
+            roof["budget"] = {"random_ops_per_build": ops, "pair_ceiling_ops_per_s": pair_ops, "build_ops_per_s": ops / (t_ins / a.steps),
+                              "fused_launches_ops_per_s": ops / (dv["seconds"] / a.steps),
+                              "note": "gathers + 2 x atomics of one build / ms_per_step, against gathers and atomics run side by side in this same run (kmx_microbench mode 20)"}
         roof["random_access_ceiling_GBps_at_32B"] = (1 << 27) * G / tg / 1e9     # measured 4-byte gather rate, priced at G per touch
         roof["frac_of_random_access_ceiling"] = ach / roof["random_access_ceiling_GBps_at_32B"]
         extra = {"kernel_classes": classes,
@@ -440,7 +556,6 @@ def main():
                  "insert_alg_GBps_whole_step": total_insert_alg / (t_ins / a.steps) / 1e9,
                  "insert_frac_of_8TBps": total_insert_alg / (t_ins / a.steps) / 8e12,
                  "query_alg_GBps": alg["query"] / (t_q / a.steps) / 1e9,
-                 "query_frac_of_8TBps": alg["query"] / (t_q / a.steps) / 8e12,           # SURVEY §8d formula: 48 touches priced per query
                  "query_touches_per_query_pmc": q_pmc,                                    # what the counters saw (early exits)
                  "query_frac_of_8TBps_counted": (q_pmc * G * q.numel() / (t_q / a.steps) / 8e12) if q_pmc else None,
                  "random_access_ceiling": {"footprint_bytes": foot, "gather_Gtouch_s": (1 << 27) / tg / 1e9,
@@ -453,6 +568,18 @@ def main():
             init_db = init_db_leg(a, km, cnt)
         except Exception as e:  # noqa: BLE001
             init_db = {"init_db_error": repr(e)}
+    if rank == 0 and world == 1 and not a.no_init_db and a.k <= 31:
+        try:
+            init_db.update(init_db_leg(a, km, cnt, layout="kmc2"))
+            init_db["init_db_kmc2_over_kmc1"] = init_db["init_db_kmc2_value"] / init_db["init_db_value"] if init_db.get("init_db_value") else None
+        except Exception as e:  # noqa: BLE001
+            init_db["init_db_kmc2_error"] = repr(e)
+    if rank == 0 and world == 1 and a.genome_bases > 0 and a.k <= 31:
+        try:
+            init_db.update(genome_leg(a, dev, a.genome_bases))
+            init_db["query_genome_over_random"] = init_db["query_genome_value"] / (nq_all * a.steps / t_q)
+        except Exception as e:  # noqa: BLE001
+            init_db["genome_error"] = repr(e)
     if rank == 0 and world == 1 and not a.no_query_strings and a.k <= 31:
         try:
             query_step()

@@ -45,8 +45,9 @@ typedef struct kmx_stats {
 	uint64_t byte_km_back;    /* kmodel.hpp:439                                                 */
 	uint64_t byte_bf[3], byte_bf_back[3];                          /* kmodel.hpp:411-416        */
 	uint64_t fast_commits;    /* successes decided by the uncontended fast path                 */
-	uint64_t contended;       /* attempts that went through the ordered slow path               */
-	uint64_t finisher_iters;  /* iterations of the single-workgroup ordered finisher            */
+	uint64_t contended;       /* attempts that went through the ordered slow path -- TIMING-DEPENDENT (a few units in 7e5 from run  */
+	uint64_t finisher_iters;  /* to run, like the next one: which candidates meet in flight); iterations of the ordered finisher.   */
+	                          /* Every other count of this struct is a function of the input alone.                                 */
 	uint64_t blocks, rounds;  /* nb*2^18 blocks and rounds executed                             */
 	int32_t  k, ci, cs, nh, nb, bf_num;
 	int32_t  device, reserved;
@@ -55,6 +56,8 @@ typedef struct kmx_stats {
 	uint64_t piped_commits;   /* (accounting for the per-kernel roofline: collected only by builds under kmx_set_profile(m, 2)) */
 	uint64_t piped_gathers;   /* random 4-byte loads / 32-bit atomic ORs those launches actually ISSUED: the check     */
 	uint64_t piped_atomics;   /* stops at the first conflicting group, a winner sets only its untagged positions      */
+	uint64_t query_neighbour_calls;  /* packed device queries answered under kmx_set_profile(m, 2) since the last build: how many entered   */
+	uint64_t query_accounted;        /* the neighbour disambiguation (kmodel.hpp:344-359) / how many were asked                          */
 } kmx_stats;
 
 const char *kmx_last_error(void);
@@ -192,6 +195,11 @@ int kmx_save(kmx_model *m, const char *dir);
 int kmx_load(const char *dir, kmx_model **out);
 
 int kmx_get_stats(kmx_model *m, kmx_stats *st);
+/* the same, writing at most `size` bytes: kmx_stats only ever grows at its end, so a caller that passes sizeof of ITS kmx_stats
+ * is safe against a newer library (kmx_get_stats and kmx_shard_local write the library's full struct: compare kmx_abi_version()
+ * first).  ABI 5 (this header): kmx_stats + query_neighbour_calls / query_accounted; kmx_range_* move regions with in-band
+ * headers; piped_* are filled only by builds under kmx_set_profile(m, 2) (since ABI 4).                                    */
+int kmx_get_stats_n(kmx_model *m, void *st, uint64_t size);
 
 /* Raw on-disk-layout views for byte-level parity checks (kmodel.hpp:183-202).
  * which: 0 bf[i], 1 bf_back[i], 2 km_back, 3 value array i (bit_array_1), 4 tag array i (bit_array_2),
@@ -231,6 +239,7 @@ int kmx_kernel_classes(void);           /* what this library writes: KMX_KERNEL_
 /* on = 1: time the kernel classes of the next builds / queries; on = 2: no timing, but the fused launches of the next builds
  * run their ACCOUNTING variant (kmx_stats piped_*: what they examined, committed and issued) -- it is slower than the
  * product's kernel, so it is never the one that is timed; 0: neither                                                    */
+/* (any other value: KMX_E_ARG)                                                                                          */
 int kmx_set_profile(kmx_model *m, int on);
 int kmx_get_kernel_times(kmx_model *m, double *seconds, uint64_t *launches, int reset);
 

@@ -32,7 +32,8 @@ class Stats(C.Structure):
                 ("k", C.c_int32), ("ci", C.c_int32), ("cs", C.c_int32), ("nh", C.c_int32), ("nb", C.c_int32),
                 ("bf_num", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32), ("rest_bytes", C.c_uint64),
                 ("piped_attempts", C.c_uint64), ("piped_commits", C.c_uint64),
-                ("piped_gathers", C.c_uint64), ("piped_atomics", C.c_uint64)]
+                ("piped_gathers", C.c_uint64), ("piped_atomics", C.c_uint64),
+                ("query_neighbour_calls", C.c_uint64), ("query_accounted", C.c_uint64)]
 
 
 # every symbol include/kmx.h declares (tests check that the library exports all of them)
@@ -44,7 +45,7 @@ ABI_SYMBOLS = [
     "kmx_set_profile", "kmx_get_kernel_times", "kmx_kmc_info", "kmx_kmc_read", "kmx_debug_mod",
     "kmx_count_classes_dev", "kmx_shard_begin", "kmx_shard_classify_dev", "kmx_ring_msg_bytes", "kmx_ring_round_dev",
     "kmx_ring_stale_dup_dev", "kmx_shard_local", "kmx_shard_complete", "kmx_dev_view", "kmx_or_words_dev",
-    "kmx_debug_pack_strings", "kmx_kernel_classes", "kmx_abi_version",
+    "kmx_debug_pack_strings", "kmx_kernel_classes", "kmx_abi_version", "kmx_get_stats_n",
     "kmx_create_on", "kmx_build_from_kmc_multi", "kmx_build_from_kmc_multi_ex", "kmx_range_begin", "kmx_range_buffers", "kmx_range_emit_dev", "kmx_range_verdict_dev", "kmx_range_resolve_dev", "kmx_range_commit_dev", "kmx_range_flush_dev",
 ]
 
@@ -143,6 +144,7 @@ def load_library():
     _sig(L, "kmx_debug_pack_strings", [vp, vp, i32, i32, u64, vp, C.POINTER(i32)])
     _sig(L, "kmx_kernel_classes", [])
     _sig(L, "kmx_abi_version", [])
+    _sig(L, "kmx_get_stats_n", [vp, vp, u64])
     L.kmx_set_profile.argtypes = [vp, i32]
     L.kmx_get_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), i32]
     _lib = L

@@ -1885,9 +1885,15 @@ template <int W> __global__ __launch_bounds__(256) void k_ring_import(BlockDev b
 }
 
 // survivors of the round (list[pp], after k_reorder) in list order -> message
-template <int W> __global__ __launch_bounds__(256) void k_ring_export(BlockDev bd, int pp, RingLists rl)
+template <int W> __global__ __launch_bounds__(256) void k_ring_export(BlockDev bd, int pp, RingLists rl, u64 *feedback)
 {
 	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	// a rank that hands every list on never runs k_rest_append, which reports the contention figures to the host: the fullest late
+	// claim bin (it picks the form of the late rounds' k_round_detect) is reported here too (a maximum over the build so far)
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+		const u64 late = bd.stats[ST_MAX_LATE_BIN];                     // (0 unless a bin went beyond 1024 tuples: the host's words are then not touched)
+		if (late && late > feedback[2]) feedback[2] = late;
+	}
 	const RingList e = rl.e[i];
 	if (!e.active || !e.dst_msg) return;
 	const int n = bd.n[pp][i];
@@ -2110,7 +2116,9 @@ template <int W> __device__ __forceinline__ int neighbour_bins(const ModelDev &m
 }
 
 // KModel::kmer_to_occ (kmodel.hpp:100-116) on packed k-mers
-template <int W> __global__ __launch_bounds__(256) void k_query(ModelDev md, const u64 *kmers, u64 n, int *out)
+// ACCT (never the timed kernel: kmx_set_profile(m, 2)): counts the queries that enter the neighbour disambiguation
+// (get_neighbor_kmer_bin, kmodel.hpp:344-359: up to 8 nested lookups in one lane) in acct[0]
+template <int W, bool ACCT> __global__ __launch_bounds__(256) void k_query(ModelDev md, const u64 *kmers, u64 n, int *out, u64 *acct)
 {
 	const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
 	if (q >= n) return;
@@ -2123,7 +2131,7 @@ template <int W> __global__ __launch_bounds__(256) void k_query(ModelDev md, con
 	Aligned<W> al = left_align<W>(v, md.k);
 	Premixed<W> pf = premix_string<W>(al, md.gfull);
 	Premixed<W> pb = premix_string<W>(drop_first_base<W>(al), md.gback);
-	out[q] = occ_from_filters<W>(md, md.gfull, md.gback, pf, pb, [&](int *cand) { return neighbour_bins<W>(md, v, cand); });
+	out[q] = occ_from_filters<W>(md, md.gfull, md.gback, pf, pb, [&](int *cand) { if (ACCT) atomicAdd(acct, 1ULL); return neighbour_bins<W>(md, v, cand); });
 }
 
 // ------------------------------------------------------------------------------------------ query on raw strings
@@ -2657,9 +2665,9 @@ void ring_import(const ModelDev &md, const BlockDev &bd, int pp, const RingLists
 {
 	DISPATCH_W(words(md), hipLaunchKernelGGL(k_ring_import<W>, dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, bd, md.nb, pp, rl, stg_kmers, stg_counts));
 }
-void ring_export(const ModelDev &md, const BlockDev &bd, int pp, const RingLists &rl, hipStream_t st)
+void ring_export(const ModelDev &md, const BlockDev &bd, int pp, const RingLists &rl, u64 *feedback, hipStream_t st)
 {
-	DISPATCH_W(words(md), hipLaunchKernelGGL(k_ring_export<W>, dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, bd, pp, rl));
+	DISPATCH_W(words(md), hipLaunchKernelGGL(k_ring_export<W>, dim3(KMX_BUCKET / 256, md.nb), dim3(256), 0, st, bd, pp, rl, feedback));
 }
 void or_words(u32 *dst, const u32 *src, u64 n, hipStream_t st)
 {
@@ -2669,11 +2677,13 @@ void or_words(u32 *dst, const u32 *src, u64 n, hipStream_t st)
 	hipLaunchKernelGGL(k_or_words, dim3((unsigned)blocks), dim3(256), 0, st, dst, src, n);
 }
 
-void query(const ModelDev &md, const u64 *kmers, u64 n, int *out, hipStream_t st, KernelProf *prof)
+// acct != null: the accounting variant (queries that enter the neighbour disambiguation are counted there)
+void query(const ModelDev &md, const u64 *kmers, u64 n, int *out, hipStream_t st, KernelProf *prof, u64 *acct)
 {
 	if (!n) return;
 	KPROF_BEGIN(prof, KC_QUERY, st);
-	DISPATCH_W(words(md), hipLaunchKernelGGL(k_query<W>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, md, kmers, n, out));
+	if (acct) DISPATCH_W(words(md), hipLaunchKernelGGL((k_query<W, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, md, kmers, n, out, acct));
+	else DISPATCH_W(words(md), hipLaunchKernelGGL((k_query<W, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, md, kmers, n, out, (u64 *)nullptr));
 	KPROF_END(prof, st);
 }
 

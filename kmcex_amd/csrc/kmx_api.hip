@@ -40,14 +40,15 @@ void rest_append(const ModelDev &, const BlockDev &, int, int, int, u64 *, int *
 void kmback_emit(const ModelDev &, const BlockDev &, const u64 *, const unsigned char *, int, int, int, int, int, const BitScatter &, hipStream_t, int istride = 1);
 void bs_apply(const BitScatter &, hipStream_t);
 void ring_import(const ModelDev &, const BlockDev &, int, const RingLists &, u64 *, u32 *, hipStream_t);
-void ring_export(const ModelDev &, const BlockDev &, int, const RingLists &, hipStream_t);
+void ring_export(const ModelDev &, const BlockDev &, int, const RingLists &, u64 *, hipStream_t);
 void or_words(u32 *, const u32 *, u64, hipStream_t);
 void range_emit(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, bool, hipStream_t);
 void range_seal(const RangeDev &, const RangePlan &, hipStream_t);
-void range_verdict(const ModelDev &, const BlockDev &, int *, int, const RangeIn &, unsigned char *, hipStream_t);
+void range_verdict(const ModelDev &, const BlockDev &, int *, int, const RangeIn &, unsigned char *, int, hipStream_t);
+void range_apply(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, bool, hipStream_t);
 void range_resolve(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, hipStream_t);
-void range_commit_apply(const ModelDev &, const RangeIn &, hipStream_t);
-void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *);
+void range_commit_apply(const ModelDev &, const RangeIn &, int, hipStream_t);
+void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *, u64 *acct = nullptr);
 void query_ascii(const ModelDev &, int, const unsigned char *, int, u64, int *, hipStream_t);
 void cells_from_disk(const unsigned char *, const unsigned char *, u64, cell_t *, u64, hipStream_t);
 void cells_to_disk(const cell_t *, u64, u64, int, unsigned char *, hipStream_t);
@@ -454,7 +455,10 @@ static int create_device_side(kmx_model *m)
 	HIPCHK(hipHostMalloc((void **)&m->h_total, 64));
 	HIPCHK(hipHostMalloc((void **)&m->h_feedback, 64, hipHostMallocMapped));
 	HIPCHK(hipHostGetDevicePointer((void **)&m->d_feedback, m->h_feedback, 0));
-	m->h_feedback[0] = ~0ULL; m->h_feedback[1] = 0; m->h_feedback[2] = 0;
+	// [2]: the fullest claim bin of a late round (t >= 2), which picks the form of their k_round_detect: until the device reports
+	// one, a guess -- a quarter of a list still alive, every survivor a candidate on all its positions -- so that wide
+	// configurations (nh >= 9: 2304 > 2048) start on the full-size tables instead of overflowing the small ones
+	m->h_feedback[0] = ~0ULL; m->h_feedback[1] = 0; m->h_feedback[2] = (u64)KMX_BUCKET * (u64)m->nh / KMX_CL_MAXBINS / 4;
 	{
 		auto env_int = [](const char *name, int dflt) { const char *v = hook_env(name); return v ? atoi(v) : dflt; };
 		m->dbg_nsub0 = env_int("KMX_NSUB0", -1);
@@ -881,7 +885,10 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 	HIPCHK(hipMemsetAsync(m->d_stale_counts, 0, (u64)nb * 4, m->stream));
 	HIPCHK(hipMemsetAsync(m->d_stats, 0, ST_N * 8, m->stream));
 	m->blocks = 0; m->rounds = 0;
-	m->h_feedback[0] = ~0ULL; m->h_feedback[1] = 0; m->h_feedback[2] = 0;
+	// [2]: the fullest claim bin of a late round (t >= 2), which picks the form of their k_round_detect: until the device reports
+	// one, a guess -- a quarter of a list still alive, every survivor a candidate on all its positions -- so that wide
+	// configurations (nh >= 9: 2304 > 2048) start on the full-size tables instead of overflowing the small ones
+	m->h_feedback[0] = ~0ULL; m->h_feedback[1] = 0; m->h_feedback[2] = (u64)KMX_BUCKET * (u64)m->nh / KMX_CL_MAXBINS / 4;
 	{   // first guess of the contended set per list in round 0: a candidate is contended when one of its nh positions
 		// is also claimed with the other value by one of the ~2^18*nh/2 opposite claims spread over the L positions
 		const double L = (double)m->km_byte_size * 8.0;
@@ -1709,7 +1716,7 @@ static int kmx_ring_round_dev_impl(kmx_model *m, int t, const kmx_ring_list *lis
 	TRY(kmback_emit(m, t, pp, -1, (u64)n_lists * KMX_BUCKET));
 	bool any_out = false;
 	for (int i = 0; i < nb; i++) any_out |= rl.e[i].active && rl.e[i].dst_msg;
-	if (any_out) kmxk::ring_export(m->md, m->bd, pp ^ 1, rl, m->stream);
+	if (any_out) kmxk::ring_export(m->md, m->bd, pp ^ 1, rl, m->d_feedback, m->stream);
 	for (int i = 0; i < nb; i++)
 		if (rl.e[i].active && !rl.e[i].dst_msg) {
 			TRY(ensure_rest_capacity(m, (u64)KMX_BUCKET + (u64)nb));
@@ -1820,8 +1827,9 @@ static int owner_of_array_ring(int a, int nb, int world) { return a * std::min(w
 static int range_begin_common(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world, bool mailbox);
 static int range_link(kmx_model **hs, int P, int d);
 static int range_list_emit(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists);
-static int range_owner_round(kmx_model *m, int t, const RangeIn &in);
-static int range_list_finish(kmx_model *m, int t);
+static int range_owner_round(kmx_model *m, int t, const RangeIn &in, int commits);
+static int range_list_apply(kmx_model *m, int t);
+static int range_list_order(kmx_model *m, int t);
 static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *db_prefix, int partition)
 {
 	if (!hs || !db_prefix || P < 1) return fail(KMX_E_ARG, "null argument");
@@ -1854,7 +1862,9 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 		u64 n = 0, n_c = 0, n_r = 0, rec_lo = 0;
 		uint64_t nbf[3] = {0, 0, 0};
 		std::vector<u64 *> msg;                                    // [nb * 2] list i, parity
-		hipEvent_t ev_round = nullptr, ev_copied = nullptr;     // ring: the round is enqueued / the hand-offs are; range: the regions are sealed / the verdicts shipped
+		hipEvent_t ev_round = nullptr, ev_copied = nullptr;     // ring: the round is enqueued / the hand-offs are
+		hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // range: the regions are sealed / the verdicts shipped / the bulk of the commits is out / ... is applied
+		hipStream_t side = nullptr;                               // range: the owner's stream for the bulk of the commits
 		kmx_stats st;
 		void *rest_k = nullptr, *rest_c = nullptr;
 	};
@@ -1874,6 +1884,11 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 	kmx_stats totals;
 	memset(&totals, 0, sizeof totals);
 	auto list_len = [&](u64 b, int i) { const u64 lo = (b * (u64)nb + (u64)i) * KMX_BUCKET; return (int)std::min<u64>(n_km > lo ? n_km - lo : 0, KMX_BUCKET); };
+	const bool trace = getenv("KMX_INIT_TRACE") != nullptr;          // wall-clock phase times of handle 0 on stderr; the rounds are bracketed by a stream synchronisation only when tracing
+	const auto t_start = std::chrono::steady_clock::now();
+	auto mark = [&](int d, const char *what) {
+		if (trace && d == 0) fprintf(stderr, "[kmx multi %s P=%d] %-28s %8.2f ms\n", by_range ? "range" : "ring", P, what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+	};
 	auto body = [&](int d) {
 		kmx_model *m = hs[d];
 		Rank &r = R[(size_t)d];
@@ -1885,11 +1900,16 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 		if (!err) {
 			const std::vector<uint64_t> &lut = db.lut();
 			bool ok = hip_ok(hipEventCreateWithFlags(&r.ev_round, hipEventDisableTiming), "event") && hip_ok(hipEventCreateWithFlags(&r.ev_copied, hipEventDisableTiming), "event") &&
+			          hip_ok(hipEventCreateWithFlags(&r.ev[0], hipEventDisableTiming), "event") && hip_ok(hipEventCreateWithFlags(&r.ev[1], hipEventDisableTiming), "event") &&
+			          hip_ok(hipEventCreateWithFlags(&r.ev[2], hipEventDisableTiming), "event") && hip_ok(hipEventCreateWithFlags(&r.ev[3], hipEventDisableTiming), "event") &&
+			          (!by_range || hip_ok(hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking), "stream")) &&
 			          hip_ok(hipMalloc((void **)&r.d_lut, lut.size() * 8), "hipMalloc") && hip_ok(hipMemcpy(r.d_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice), "LUT copy") &&
 			          hip_ok(hipMalloc((void **)&r.d_km, std::max<u64>(r.n, 1) * W * 8), "hipMalloc") && hip_ok(hipMalloc((void **)&r.d_cnt, std::max<u64>(r.n, 1) * 4), "hipMalloc") &&
 			          hip_ok(hipMalloc((void **)&r.d_ck, std::max<u64>(r.n, 1) * W * 8), "hipMalloc") && hip_ok(hipMalloc((void **)&r.d_cc, std::max<u64>(r.n, 1) * 4), "hipMalloc");
 			const u64 B = u64(1) << 23;
+			mark(d, "  device buffers");
 			if (ok) ok = hip_ok(hipHostMalloc((void **)&r.h_raw, std::min<u64>(B, std::max<u64>(r.n, 1)) * rb + 16), "hipHostMalloc") && hip_ok(hipMalloc((void **)&r.d_raw, std::min<u64>(B, std::max<u64>(r.n, 1)) * rb + 16), "hipMalloc");
+			mark(d, "  pinned slot");
 			KmcDecode kd;
 			kd.lut = r.d_lut; kd.n_lut = lut.size() - 1; kd.prefix_mask = db.prefix_mask();
 			kd.rec_bytes = (u32)rb; kd.suf_bytes = db.suffix_bytes(); kd.cnt_bytes = db.counter_bytes();
@@ -1902,7 +1922,9 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 				if (ok) ok = hip_ok(hipStreamSynchronize(st), "decode");          // the pinned slot is reused
 			}
 			if (ok && db.io_failed()) { fail(KMX_E_IO, "reading %s.kmc_suf failed", db_prefix); note(KMX_E_IO); ok = false; }
+			mark(d, "  slice decoded");
 			if (ok) note(kmx_count_classes_dev_impl(m, r.d_cnt, r.n, r.nbf));      // kmodel.hpp:423-428 on the slice
+			mark(d, "  pass 1 on the slice");
 		}
 		bar.wait();
 		if (d == 0) for (int q = 0; q < P; q++) for (int c = 0; c < 3; c++) nbf_all[c] += R[(size_t)q].nbf[c];
@@ -1911,6 +1933,7 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 		if (!err) note(by_range ? range_begin_common(m, k, nbf_all, db.kmer_count(), d, P, true) : kmx_shard_begin_impl(m, k, nbf_all, db.kmer_count(), d, P));
 		if (!err) { uint64_t nc = 0; if (!note(kmx_shard_classify_dev_impl(m, (const uint64_t *)r.d_km, r.d_cnt, r.n, (uint64_t *)r.d_ck, r.d_cc, &nc))) r.n_c = nc; }
 		if (!err) hip_ok(hipStreamSynchronize(st), "classify");
+		mark(d, "  begin + classify");
 		bar.wait();
 		if (d == 0) {
 			for (int q = 0; q < P; q++) offs[(size_t)q + 1] = offs[(size_t)q] + R[(size_t)q].n_c;
@@ -1943,17 +1966,30 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 			}
 			if (ok) hip_ok(hipStreamSynchronize(st), "routing");
 		}
+		if (trace) hipStreamSynchronize(st);
 		bar.wait();
+		mark(d, "decode, classify, routing");
 		// ---- the rounds (kmodel.hpp:560-565), by range: this rank holds the lists i = d, d + P, ... for the whole block and owns a
 		// cell range of every array; the words of a round are written straight into the owners' inboxes (peer mappings), the
 		// verdict bytes straight into the senders' boxes, and two events per rank order the three steps -- the host threads
 		// only enqueue, nothing here waits for a device
 		u64 pos = 0;
 		if (by_range) {
-			auto wait_all = [&](bool emitted) {
+			// The BULK of a round's commits (the uncontended winners': 99.6 %) is complete when k_range_apply ends: the owners CAN set
+			// those bits on a side stream while the list ranks still order their contended candidates, reorder and hash the next
+			// round's triples; what the resolver adds is applied in front of the next verdicts.  Measured on one GPU (1 and 2
+			// handles, profiles/r05_range_cxx_overlap_ab.txt) it buys nothing: under the atomics k_range_resolve takes 67 us
+			// instead of 35 and k_reorder 20 instead of 6.6 -- the ordered chain stretches by what the overlap hides -- so it is
+			// OFF unless KMX_RANGE_OVERLAP=1 (under KMX_TEST_HOOKS) asks for it; a node where every GPU applies 1/P of the commits
+			// is where to try it again.
+			const char *ov = hook_env("KMX_RANGE_OVERLAP");
+			const bool overlap = ov && ov[0] == '1';
+			enum { EV_EMIT = 0, EV_VER, EV_BULK, EV_BULK_DONE };
+			auto wait_all = [&](hipStream_t on, int which, bool self) {
 				for (int q = 0; q < P; q++)
-					if (q != d) hip_ok(hipStreamWaitEvent(st, emitted ? R[(size_t)q].ev_round : R[(size_t)q].ev_copied, 0), "wait");
+					if (q != d || self) hip_ok(hipStreamWaitEvent(on, R[(size_t)q].ev[which], 0), "wait");
 			};
+			bool bulk_ahead = false;                                          // the side stream holds a commit launch the next verdicts depend on
 			for (u64 b = 0; b < n_blocks; b++) {
 				const u64 n_in_block = std::min<u64>(blk, n_km - b * blk);
 				if (!err && n_in_block < blk && b > 0) {                     // quirk Q1 (kmodel.hpp:520-527), on the rank that holds the list
@@ -1971,19 +2007,39 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 							l.src_kmers = r.d_rk + pos * W; l.src_counts = r.d_rc + pos;
 							pos += (u64)l.n_host;
 						}
-					if (!err) { hip_ok(hipSetDevice(m->device), "hipSetDevice"); note(range_list_emit(m, t, lists, n_lists)); }   // 1. commits of the round before + this round's triples -> the owners' inboxes
-					if (!err) hip_ok(hipEventRecord(r.ev_round, st), "event");
+					if (!err) { hip_ok(hipSetDevice(m->device), "hipSetDevice"); note(range_list_emit(m, t, lists, n_lists)); }   // 1. this round's triples behind the commits of the round before -> the owners' inboxes
+					if (!err) hip_ok(hipEventRecord(r.ev[EV_EMIT], st), "event");
 					bar.wait();
-					if (!err) { wait_all(true); note(range_owner_round(m, t, m->range.in)); }     // 2. commits applied, one verdict byte per triple -> the senders' boxes
-					if (!err) hip_ok(hipEventRecord(r.ev_copied, st), "event");
+					if (!err) {                                                                     // 2. commits applied, one verdict byte per triple -> the senders' boxes
+						wait_all(st, EV_EMIT, false);
+						if (bulk_ahead) hip_ok(hipStreamWaitEvent(st, r.ev[EV_BULK_DONE], 0), "wait");
+						note(range_owner_round(m, t, m->range.in, bulk_ahead ? RANGE_LATE : RANGE_ALL));
+						hip_ok(hipEventRecord(r.ev[EV_VER], st), "event");
+					}
 					bar.wait();
-					if (!err) { wait_all(false); note(range_list_finish(m, t)); }                  // 3. winners decided; their commits go to the front of the regions
+					if (!err) { wait_all(st, EV_VER, false); note(range_list_apply(m, t)); }       // 3. failures, winners: the bulk of the commits is in the owners' inboxes
+					if (overlap) {
+						if (!err) hip_ok(hipEventRecord(r.ev[EV_BULK], st), "event");
+						bar.wait();
+						if (!err) {
+							wait_all(r.side, EV_BULK, true);
+							kmxk::range_commit_apply(m->md, m->range.in, RANGE_BULK, r.side);
+							hip_ok(hipEventRecord(r.ev[EV_BULK_DONE], r.side), "event");
+						}
+						bulk_ahead = true;
+					}
+					if (!err) note(range_list_order(m, t));                                        //    ... the contended in list order, reorder
 				}
 			}
 			if (n_blocks) {                                                   // the last round's commits
-				if (!err) { kmxk::range_seal(m->range.rd, m->range.plan, st); m->range.pending = false; hip_ok(hipEventRecord(r.ev_round, st), "event"); }
+				if (!err) { kmxk::range_seal(m->range.rd, m->range.plan, st); m->range.pending = false; hip_ok(hipEventRecord(r.ev[EV_EMIT], st), "event"); }
 				bar.wait();
-				if (!err) { wait_all(true); kmxk::range_commit_apply(m->md, m->range.in, st); hip_ok(hipGetLastError(), "commit"); }
+				if (!err) {
+					wait_all(st, EV_EMIT, false);
+					if (bulk_ahead) hip_ok(hipStreamWaitEvent(st, r.ev[EV_BULK_DONE], 0), "wait");
+					kmxk::range_commit_apply(m->md, m->range.in, bulk_ahead ? RANGE_LATE : RANGE_ALL, st);
+					hip_ok(hipGetLastError(), "commit");
+				}
 			}
 		} else
 		// ---- the rounds, ring: this rank attempts the lists whose array it owns; survivors travel as messages
@@ -2029,8 +2085,10 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 			}
 		}
 		// ---- merge: survivors to every rank, filters OR-ed (set_bit is an OR, kmodel.hpp:576-581), every array from its owner
+		if (trace && d == 0) mark(d, "rounds enqueued");
 		if (!err) note(kmx_shard_local_impl(m, &r.st, &r.rest_k, &r.rest_c));
 		bar.wait();
+		mark(d, "rounds done on every handle");
 		if (d == 0) {
 			for (int q = 0; q < P; q++) {
 				const kmx_stats &s2 = R[(size_t)q].st;
@@ -2100,12 +2158,15 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 		if (!err) note(kmx_shard_complete_impl(m, (const uint64_t *)r.d_allk, r.d_allc, n_rest_all, &totals));
 		hipStreamSynchronize(st);
 		bar.wait();                                                         // nobody frees what a peer may still be reading
+		mark(d, "merged and complete");
 		hipFree(r.d_km); hipFree(r.d_cnt); hipFree(r.d_ck); hipFree(r.d_cc); hipFree(r.d_rk); hipFree(r.d_rc); hipFree(r.d_allk); hipFree(r.d_allc);
 		hipFree(r.d_lut); hipFree(r.d_raw); hipFree(r.d_tmp);
 		if (r.h_raw) hipHostFree(r.h_raw);
 		for (u64 *p : r.msg) hipFree(p);
 		if (r.ev_round) hipEventDestroy(r.ev_round);
 		if (r.ev_copied) hipEventDestroy(r.ev_copied);
+		for (hipEvent_t e : r.ev) if (e) hipEventDestroy(e);
+		if (r.side) { hipStreamSynchronize(r.side); hipStreamDestroy(r.side); }
 	};
 	// (a body must reach every barrier whatever happens to it: an exception -- bad_alloc in one of its vectors -- is noted like
 	// any other error and the walk goes on with empty steps; a thread that cannot be created leaves the build with an error
@@ -2165,12 +2226,12 @@ static int range_begin_common(kmx_model *m, int k, const uint64_t n_bf[3], uint6
 		R.rd.rt_bits = nh <= 8 ? 22 : 23;
 		if (mailbox) {
 			TRY(dalloc(&R.d_inbox, (u64)world * R.rd.cap, false, m->stream));
-			TRY(dalloc(&R.d_in_hdr, (u64)KMX_MAX_RANKS * 2, true, m->stream));
+			TRY(dalloc(&R.d_in_hdr, (u64)KMX_MAX_RANKS * KMX_RANGE_HDR, true, m->stream));
 			TRY(dalloc(&R.d_vbox, (u64)world * R.rd.cap, false, m->stream));
 		} else {
 			TRY(dalloc(&R.d_send, (u64)world * R.rd.cap, false, m->stream));
-			TRY(dalloc(&R.d_hdr, (u64)KMX_MAX_RANKS * 2, true, m->stream));
-			HIPCHK(hipHostMalloc((void **)&R.h_hdr, sizeof(u32) * KMX_MAX_RANKS * 2));
+			TRY(dalloc(&R.d_hdr, (u64)KMX_MAX_RANKS * KMX_RANGE_HDR, true, m->stream));
+			HIPCHK(hipHostMalloc((void **)&R.h_hdr, sizeof(u32) * KMX_MAX_RANKS * KMX_RANGE_HDR));
 		}
 		TRY(dalloc(&R.rd.ccnt, (u64)KMX_MAX_RANKS * KMX_CTR_STRIDE, true, m->stream));
 		TRY(dalloc(&R.rd.tcnt, (u64)KMX_MAX_RANKS * KMX_CTR_STRIDE, true, m->stream));
@@ -2193,12 +2254,13 @@ static int range_begin_common(kmx_model *m, int k, const uint64_t n_bf[3], uint6
 	HIPCHK(hipMemsetAsync(R.d_opcnt, 0, sizeof(int) * (u64)KMX_MAX_NB * KMX_CL_MAXBINS * KMX_CTR_STRIDE, m->stream));
 	HIPCHK(hipMemsetAsync(R.rd.ccnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, m->stream));         // (k_range_seal leaves them zero; an aborted build may not have)
 	HIPCHK(hipMemsetAsync(R.rd.tcnt, 0, sizeof(int) * KMX_MAX_RANKS * KMX_CTR_STRIDE, m->stream));
-	if (mailbox) HIPCHK(hipMemsetAsync(R.d_in_hdr, 0, sizeof(u32) * KMX_MAX_RANKS * 2, m->stream));
+	if (mailbox) HIPCHK(hipMemsetAsync(R.d_in_hdr, 0, sizeof(u32) * KMX_MAX_RANKS * KMX_RANGE_HDR, m->stream));
+	else HIPCHK(hipMemsetAsync(R.d_hdr, 0, sizeof(u32) * KMX_MAX_RANKS * KMX_RANGE_HDR, m->stream));
 	R.plan.rank = rank; R.plan.world = world;
 	for (int q = 0; q <= world; q++) R.plan.cell_lo[q] = (u64)(((unsigned __int128)m->ncells * (unsigned)q) / (unsigned)world);
 	for (int q = 0; q < KMX_MAX_RANKS; q++) {
 		R.rd.out[q] = (!mailbox && q < world) ? R.d_send + (u64)q * R.rd.cap : nullptr;      // (mailbox: range_link points them at the owners' inboxes)
-		R.rd.hdr_out[q] = (!mailbox && q < world) ? R.d_hdr + 2 * q : nullptr;
+		R.rd.hdr_out[q] = (!mailbox && q < world) ? R.d_hdr + KMX_RANGE_HDR * q : nullptr;
 		R.rd.vin[q] = nullptr;
 		R.sent_tot[q] = 0;
 	}
@@ -2249,15 +2311,24 @@ static int range_list_emit(kmx_model *m, int t, const kmx_ring_list *lists, int 
 	return KMX_OK;
 }
 // step 2, owner: the commit words first, then one verdict byte per triple, to where its sender reads it
-static int range_owner_round(kmx_model *m, int t, const RangeIn &in)
+// (commits: RANGE_ALL, or RANGE_LATE when the bulk of them was applied ahead, on the side stream)
+static int range_owner_round(kmx_model *m, int t, const RangeIn &in, int commits)
 {
-	kmxk::range_verdict(m->md, m->range.obd, m->range.d_opcnt, t, in, m->range.d_lver, m->stream);
+	kmxk::range_verdict(m->md, m->range.obd, m->range.d_opcnt, t, in, m->range.d_lver, commits, m->stream);
 	HIPCHK(hipGetLastError());
 	return KMX_OK;
 }
-// step 3, list rank: verdicts -> failures, winners (their commits go to the front of the regions), the contended in list order;
-// reorder_buffer (:529-540); after the last round km_back and the rest table
-static int range_list_finish(kmx_model *m, int t)
+// step 3, list rank: verdicts -> failures and winners; the uncontended winners' commits (the bulk) are in front of the regions
+// and their count in the headers when this launch ends
+static int range_list_apply(kmx_model *m, int t)
+{
+	kmxk::range_apply(m->md, m->bd, m->range.rd, m->range.plan, t, m->pp, m->range.mailbox, m->stream);   // (mailbox: + the bulk count into the owners' headers)
+	HIPCHK(hipGetLastError());
+	return KMX_OK;
+}
+// ... then the contended in list order (their commits behind the bulk); reorder_buffer (:529-540); after the last round km_back
+// and the rest table
+static int range_list_order(kmx_model *m, int t)
 {
 	auto &R = m->range;
 	const int nb = m->nb, pp = m->pp;
@@ -2305,7 +2376,7 @@ static int range_link(kmx_model **hs, int P, int d)
 			(void)hipGetLastError();
 		}
 		R.rd.out[q] = hs[q]->range.d_inbox + (u64)d * R.rd.cap;          // sender d's region in owner q's inbox
-		R.rd.hdr_out[q] = hs[q]->range.d_in_hdr + 2 * d;
+		R.rd.hdr_out[q] = hs[q]->range.d_in_hdr + KMX_RANGE_HDR * d;
 		R.rd.vin[q] = R.d_vbox + (u64)q * R.rd.cap;                      // owner q answers into this rank's box
 		R.in.reg[q] = R.d_inbox + (u64)q * R.rd.cap;                     // ... and as an owner: sender q's region here,
 		R.in.vout[q] = hs[q]->range.d_vbox + (u64)d * R.rd.cap;          // its verdicts into sender q's box
@@ -2319,11 +2390,11 @@ static int range_link(kmx_model **hs, int P, int d)
 static int range_read_headers(kmx_model *m, uint64_t *counts)
 {
 	auto &R = m->range;
-	HIPCHK(hipMemcpyAsync(R.h_hdr, R.d_hdr, sizeof(u32) * KMX_MAX_RANKS * 2, hipMemcpyDeviceToHost, m->stream));
+	HIPCHK(hipMemcpyAsync(R.h_hdr, R.d_hdr, sizeof(u32) * KMX_MAX_RANKS * KMX_RANGE_HDR, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipStreamSynchronize(m->stream));
 	for (int q = 0; q < R.plan.world; q++) {
-		counts[q] = (uint64_t)R.h_hdr[2 * q] + (uint64_t)R.h_hdr[2 * q + 1];
-		counts[R.plan.world + q] = (uint64_t)R.h_hdr[2 * q];
+		counts[q] = (uint64_t)R.h_hdr[KMX_RANGE_HDR * q] + (uint64_t)R.h_hdr[KMX_RANGE_HDR * q + 1];
+		counts[R.plan.world + q] = (uint64_t)R.h_hdr[KMX_RANGE_HDR * q];
 		R.sent_tot[q] = counts[q];
 	}
 	return KMX_OK;
@@ -2383,7 +2454,7 @@ static int kmx_range_verdict_dev_impl(kmx_model *m, int t, const uint64_t *d_wor
 	if (m->km_byte_size == 0 || !n) return KMX_OK;
 	RangeIn in;
 	TRY(range_in_of(m, d_words, totals, commits, n_src, d_verdict, in));
-	return range_owner_round(m, t, in);
+	return range_owner_round(m, t, in, RANGE_ALL);
 }
 
 // verdicts in the order the words left (regions back to back, in rank order)
@@ -2396,7 +2467,8 @@ static int kmx_range_resolve_dev_impl(kmx_model *m, int t, const uint8_t *d_verd
 	u64 off = 0;
 	for (int q = 0; q < R.plan.world; q++) { R.rd.vin[q] = d_verdict ? d_verdict + off : nullptr; off += R.sent_tot[q]; }
 	if (off && !d_verdict) return fail(KMX_E_ARG, "null argument");
-	return range_list_finish(m, t);
+	TRY(range_list_apply(m, t));
+	return range_list_order(m, t);
 }
 
 // ... and on the owner: the winners' tag / value bits of a last exchange (kmodel.hpp:611-618)
@@ -2409,7 +2481,7 @@ static int kmx_range_commit_dev_impl(kmx_model *m, const uint64_t *d_commits, ui
 	RangeIn in;
 	const uint64_t tot[1] = {n};
 	TRY(range_in_of(m, d_commits, tot, tot, 1, nullptr, in));
-	kmxk::range_commit_apply(m->md, in, m->stream);
+	kmxk::range_commit_apply(m->md, in, RANGE_ALL, m->stream);
 	HIPCHK(hipGetLastError());
 	return KMX_OK;
 }
@@ -2485,6 +2557,14 @@ static int kmx_query_packed_dev_impl(kmx_model *m, const uint64_t *d_kmers, uint
 	if (!m) return fail(KMX_E_ARG, "null model");
 	if (m->state != ST_READY) return fail(KMX_E_STATE, "query before the model is built or loaded");
 	HIPCHK(hipSetDevice(m->device));
+	if (m->prof.count && m->d_stats) {                            // accounting (kmx_set_profile(m, 2)): never the timed kernel
+		kmxk::query(m->md, (const u64 *)d_kmers, n, d_out, m->stream, &m->prof, m->d_stats + ST_QUERY_NEIGH);
+		u64 got = 0;
+		HIPCHK(hipMemcpyAsync(&got, m->d_stats + ST_QUERY_NEIGH, 8, hipMemcpyDeviceToHost, m->stream));
+		HIPCHK(hipStreamSynchronize(m->stream));
+		m->h_stats[ST_QUERY_NEIGH] = got; m->h_stats[ST_QUERY_N] += n;
+		return KMX_OK;
+	}
 	kmxk::query(m->md, (const u64 *)d_kmers, n, d_out, m->stream, &m->prof);
 	HIPCHK(hipGetLastError());
 	return KMX_OK;
@@ -2599,8 +2679,10 @@ static int query_pipeline(kmx_model *m, u64 n, size_t item_bytes, int T, STAGE s
 		}
 		return true;
 	};
+	std::atomic<bool> worker_threw{false};
 	auto worker = [&](int t) {
 		u64 p = 0;
+		try {                                                        // (`stage` may grow a vector: a worker that throws ends the pipeline with KMX_E_NOMEM, not the process)
 		for (;;) {
 			const u64 id = next.fetch_add(1, std::memory_order_relaxed);
 			if (id >= first[n_phase]) return;
@@ -2622,9 +2704,16 @@ static int query_pipeline(kmx_model *m, u64 n, size_t item_bytes, int T, STAGE s
 				copied[c].fetch_add(1, std::memory_order_release);
 			}
 		}
+		} catch (...) { worker_threw = true; abort = true; }
 	};
+	// the tasks come from one counter, so the pipeline works with however many workers could be started (a pid-limited
+	// container may refuse some of up to 32); with none at all the calling thread cannot both pack and drive: an error
 	std::vector<std::thread> th;
-	for (int t = 0; t < T; t++) th.emplace_back(worker, t);
+	try { th.reserve((size_t)T); } catch (...) { return fail(KMX_E_NOMEM, "out of memory"); }
+	for (int t = 0; t < T; t++) {
+		try { th.emplace_back(worker, t); } catch (...) { break; }
+	}
+	if (th.empty()) return fail(KMX_E_NOMEM, "cannot start a worker thread for the query pipeline");
 	int rc = KMX_OK;
 	auto publish = [&](u64 c) {                                   // chunk c's answers are in its pinned slot
 		hipError_t e;
@@ -2634,7 +2723,7 @@ static int query_pipeline(kmx_model *m, u64 n, size_t item_bytes, int T, STAGE s
 		ready[c].store(1, std::memory_order_release);
 	};
 	for (u64 c = 0; c < nc && !rc; c++) {
-		wait_for([&] { return packed[c].load(std::memory_order_acquire) == subs_of(c); });
+		if (!wait_for([&] { return packed[c].load(std::memory_order_acquire) == subs_of(c); })) { rc = fail(KMX_E_NOMEM, "out of memory in a query worker"); break; }
 		if (!enqueue(c)) { rc = fail(KMX_E_NODEVICE, "query pipeline: enqueue failed"); break; }
 		if (c >= 1) publish(c - 1);
 	}
@@ -2642,6 +2731,7 @@ static int query_pipeline(kmx_model *m, u64 n, size_t item_bytes, int T, STAGE s
 	else abort = true;
 	for (auto &x : th) x.join();
 	hipStreamSynchronize(F.to_dev); hipStreamSynchronize(F.to_host);
+	if (worker_threw && !rc) rc = fail(KMX_E_NOMEM, "out of memory in a query worker");
 	if (hipStreamSynchronize(m->stream) != hipSuccess && !rc) rc = fail(KMX_E_NODEVICE, "query failed");
 	if (!rc && hipGetLastError() != hipSuccess) rc = fail(KMX_E_NODEVICE, "query kernel failed");
 	return rc;
@@ -2968,8 +3058,19 @@ static int kmx_get_stats_impl(kmx_model *m, kmx_stats *st)
 	st->blocks = m->blocks; st->rounds = m->rounds;
 	st->piped_attempts = m->h_stats[ST_PIPE_ATTEMPTS]; st->piped_commits = m->h_stats[ST_PIPE_SUCC];
 	st->piped_gathers = m->h_stats[ST_PIPE_GATHERS]; st->piped_atomics = m->h_stats[ST_PIPE_ATOMICS];
+	st->query_neighbour_calls = m->h_stats[ST_QUERY_NEIGH]; st->query_accounted = m->h_stats[ST_QUERY_N];
 	st->rest_bytes = m->rest.suff_bin_size + 4 * m->rest.entries + 4 * (u64)m->rest.pre_buffer_size + 4 * (u64)m->rest.map_size;
 	st->k = m->k; st->ci = m->ci; st->cs = m->cs; st->nh = m->nh; st->nb = m->nb; st->bf_num = m->bf_num; st->device = m->device;
+	return KMX_OK;
+}
+
+// the first `size` bytes of the struct: a caller built against an older (shorter) kmx_stats names its own sizeof
+static int kmx_get_stats_n_impl(kmx_model *m, void *st, uint64_t size)
+{
+	if (!st) return fail(KMX_E_ARG, "null argument");
+	kmx_stats full;
+	TRY(kmx_get_stats_impl(m, &full));
+	memcpy(st, &full, (size_t)std::min<uint64_t>(size, sizeof full));
 	return KMX_OK;
 }
 
@@ -3096,6 +3197,7 @@ static int kmx_microbench_impl(int mode, uint64_t bytes, uint64_t touches, int i
 static int kmx_set_profile_impl(kmx_model *m, int on)
 {
 	if (!m) return fail(KMX_E_ARG, "null model");
+	if (on < 0 || on > 2) return fail(KMX_E_ARG, "kmx_set_profile: 0 (off), 1 (timing) or 2 (accounting), got %d", on);
 	m->prof.on = on == 1;                                         // 1: per-class timing of the product's kernels
 	m->prof.count = on == 2;                                      // 2: no timing; the fused launches run their accounting variant (kmx_stats piped_*)
 	return KMX_OK;
@@ -3178,6 +3280,7 @@ extern "C" int kmx_debug_pack_strings(const char *const *strs, const char *flat,
 }
 extern "C" int kmx_kernel_classes(void) { return KMX_KERNEL_CLASSES; }
 extern "C" int kmx_abi_version(void) { return KMX_ABI_VERSION; }
+extern "C" int kmx_get_stats_n(kmx_model *m, void *st, uint64_t size) { return guarded([&] { return kmx_get_stats_n_impl(m, st, size); }); }
 extern "C" int kmx_microbench(int mode, uint64_t bytes, uint64_t touches, int iters, double *seconds) { return guarded([&] { return kmx_microbench_impl(mode, bytes, touches, iters, seconds); }); }
 extern "C" int kmx_set_profile(kmx_model *m, int on) { return guarded([&] { return kmx_set_profile_impl(m, on); }); }
 static_assert(KC_N == KMX_KERNEL_CLASSES, "include/kmx.h promises KMX_KERNEL_CLASSES entries");

@@ -77,6 +77,7 @@ enum { ST_ATTEMPTS = 0, ST_SUCCESSES, ST_SLOW_SUCC, ST_CONTENDED, ST_FIN_ITERS, 
        ST_PIPE_GATHERS, ST_PIPE_ATOMICS,      // random 4-byte loads / 32-bit atomic ORs issued inside those launches (the staged fetch stops early; one atomic per NEW tag bit)
        ST_MAX_LATE_BIN,                       // fullest claim bin of a late round (t >= 2) since the last block: picks the form of their k_round_detect
        ST_DELTA_FAILS,                        // candidates of a stale check that a still-uncommitted winner of the previous visit ruled out (k_round_detect)
+       ST_QUERY_NEIGH, ST_QUERY_N,            // accounting queries (kmx_set_profile(m, 2)): how many entered the neighbour disambiguation / were asked
        ST_N };
 
 #define KMX_CLS_TILE 2048                      // k-mers per classification tile (front end)
@@ -165,6 +166,7 @@ struct RingLists { RingList e[KMX_MAX_NB]; };
 
 // ---- the position-range partition of the coupled arrays over several GPUs (range_kernels.h)
 #define KMX_MAX_RANKS 16
+#define KMX_RANGE_HDR 4                        // u32 words of a region's header: commits, triples, bulk commits (the first part of the commits, complete early), pad
 #define KMX_RANGE_QBITS 27                     // a claim tuple on the owner names the received triple it came from in this many bits (kernels.hip CL_RANGE_TUPLE)
 struct RangePlan {
 	int rank, world;
@@ -174,7 +176,7 @@ struct RangePlan {
 // round's triples behind them, a header {commits, triples} beside it.  The list rank's side:
 struct RangeDev {
 	u64 *out[KMX_MAX_RANKS];             // out[q]: the region for owner q -- this rank's own memory (the caller moves the words) or owner q's inbox through a peer mapping
-	u32 *hdr_out[KMX_MAX_RANKS];         // hdr_out[q][0..1]: where k_range_seal leaves {commits, triples} of that region for owner q
+	u32 *hdr_out[KMX_MAX_RANKS];         // hdr_out[q][0..2]: where the header {commits, triples, bulk commits} of that region is left for owner q
 	const unsigned char *vin[KMX_MAX_RANKS];   // vin[q][off]: verdict byte of word `off` of the region for owner q
 	int *ccnt, *tcnt;        // [KMX_MAX_RANKS * KMX_CTR_STRIDE] commits / triples per destination written since the last seal
 	u64 cap;
@@ -188,11 +190,14 @@ struct RangeDev {
 	u32 *rt_um;              // [nb*BUCKET] per contended record (same index as `contended`): its positions wanted with both values
 	u32 rt_bits;
 };
+// which commit words of a region: all, the BULK (the uncontended winners', complete when k_range_apply ends -- the sender still
+// orders its contended candidates then) or the LATE ones behind them (k_range_resolve's)
+enum { RANGE_ALL = 0, RANGE_BULK = 1, RANGE_LATE = 2 };
 // ... and the owner's: what it received from every sender, and where the verdict bytes go
 struct RangeIn {
 	const u64 *reg[KMX_MAX_RANKS];       // region of sender s
 	unsigned char *vout[KMX_MAX_RANKS];  // vout[s][off]: where sender s reads the verdict of word `off` of its region (its own memory, possibly through a peer mapping)
-	const u32 *hdr;                      // hdr[2 s], hdr[2 s + 1]: commits / triples of region s, in device memory (in band) -- or null and
+	const u32 *hdr;                      // hdr[KMX_RANGE_HDR s + 0 .. 2]: commits / triples / bulk commits of region s, in device memory (in band) -- or null and
 	u32 nc[KMX_MAX_RANKS], nt[KMX_MAX_RANKS];   // the counts by value (the caller moved the words and knows them)
 	int world;
 };

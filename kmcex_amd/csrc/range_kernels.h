@@ -47,20 +47,25 @@ __device__ __forceinline__ int range_owner(const RangePlan &pl, u64 cell)
 // What an owner received: one region per sender; the counts from the headers (device memory) or, when the caller moved the
 // words and knows them, by value.  Staged in LDS (lanes index the regions independently: not from the kernel arguments).
 struct RangeInLds {
-	u32 pc[KMX_MAX_RANKS + 1], pt[KMX_MAX_RANKS + 1];   // exclusive prefix sums of the commits / triples over the regions
-	u32 nc[KMX_MAX_RANKS];                              // commits in front of region s
+	u32 pc[KMX_MAX_RANKS + 1], pt[KMX_MAX_RANKS + 1];   // exclusive prefix sums of the commits taken / the triples over the regions
+	u32 c0[KMX_MAX_RANKS];                              // first commit word taken of region s
+	u32 nc[KMX_MAX_RANKS];                              // commits in front of region s (the triples start there)
 	const u64 *reg[KMX_MAX_RANKS];
 	unsigned char *vout[KMX_MAX_RANKS];
 };
-__device__ __forceinline__ void range_in_stage(const RangeIn &in, RangeInLds &L)
+// part: which commit words the caller is after (kmx_types.h RANGE_ALL / RANGE_BULK / RANGE_LATE)
+__device__ __forceinline__ void range_in_stage(const RangeIn &in, RangeInLds &L, int part = RANGE_ALL)
 {
 	if (threadIdx.x == 0) {
 		u32 c = 0, t = 0;
 		for (int s = 0; s < in.world; s++) {
-			const u32 nc = in.hdr ? in.hdr[2 * s] : in.nc[s], nt = in.hdr ? in.hdr[2 * s + 1] : in.nt[s];
-			L.pc[s] = c; L.pt[s] = t; L.nc[s] = nc;
+			const u32 nc = in.hdr ? in.hdr[KMX_RANGE_HDR * s] : in.nc[s], nt = in.hdr ? in.hdr[KMX_RANGE_HDR * s + 1] : in.nt[s];
+			// (RANGE_BULK runs while the sender is still writing: only word 2 of the header is final then)
+			const u32 nbulk = in.hdr ? in.hdr[KMX_RANGE_HDR * s + 2] : 0;
+			const u32 lo = part == RANGE_LATE ? (nbulk < nc ? nbulk : nc) : 0, hi = part == RANGE_BULK ? nbulk : nc;
+			L.pc[s] = c; L.pt[s] = t; L.nc[s] = nc; L.c0[s] = lo;
 			L.reg[s] = in.reg[s]; L.vout[s] = in.vout[s];
-			c += nc; t += nt;
+			c += hi - lo; t += nt;
 		}
 		L.pc[in.world] = c; L.pt[in.world] = t;
 	}
@@ -151,52 +156,9 @@ template <int NHM> __device__ __forceinline__ void range_block_append_sorted(con
 	__syncthreads();
 }
 
-// 1. every attempt of the lists this rank holds -> triples by owner rank; positions kept per slot (crec) for steps 3
-template <int W, int NHM> __global__ __launch_bounds__(256) void k_range_emit(ModelDev md, BlockDev bd, RangeDev rd, RangePlan pl, int t, int pp)
-{
-	__shared__ int s_key[KMX_MAX_RANKS * KMX_CL_MAXBINS + 1], s_base[KMX_MAX_RANKS], s_wsum[4];
-	__shared__ RangeOutLds L;
-	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
-	const int n = bd.n[pp][i];
-	if ((int)blockIdx.x * 256 >= n) return;                             // uniform
-	range_out_stage(rd, pl.world, L);
-	const u64 row = (u64)i * KMX_BUCKET;
-	const int a = (i + t) % md.nb;
-	if (x == 0) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
-	u64 word[NHM];
-	int dest[NHM];
-	u32 where[NHM], valid = 0;
-	if (x < n) {
-		const u32 raw = bd.list[pp][row + x];
-		const u32 idx = (raw & LIST_HOLE) ? bd.mover[pp][row + (raw & ~LIST_HOLE)] : raw;
-		if (raw & LIST_HOLE) bd.list[pp][row + x] = idx;                // later kernels of the round read plain entries
-		u64 v[W];
-		load_kmer<W>(bd.kmers, row + idx, v);
-		const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
-		Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
-		u64 pos[NHM];
-#pragma unroll
-		for (int j = 0; j < NHM; j++)
-			if (j < md.nh) {
-				pos[j] = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(a * md.nh + j) & 127]), md.km_mod);
-				word[j] = RT_MAKE(pos[j], (bin >> j) & 1u, i, x, j);
-				dest[j] = range_owner(pl, pos[j] >> 4);
-				valid |= 1u << j;
-			}
-		crec_store<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh, pos);
-		bd.uw[pp][row + x] = bin << 16;                                  // the untagged mask arrives with the verdicts
-		bd.status[pp][row + x] = SLOT_UNDECIDED;
-	}
-	range_block_append_sorted<NHM>(rd, L, pl.world, word, dest, valid, where, s_key, s_base, s_wsum);
-	if (x < n)
-#pragma unroll
-		for (int j = 0; j < NHM; j++)
-			if (j < md.nh) rd.tidx[(row + x) * (u64)md.nh + j] = where[j];
-}
-
-// 1b. the header of every region goes to its owner: {commits in front, triples behind them}; the counters start over (the
-// next words this rank writes into a region are the commits of the round being decided, from its front)
-__global__ __launch_bounds__(64) void k_range_seal(RangeDev rd, int world)
+// the header of every region goes to its owner: {commits in front, triples behind them, bulk commits}; the counters start over
+// (the next words this rank writes into a region are the commits of the round being decided, from its front)
+__device__ __forceinline__ void range_seal_regions(const RangeDev &rd, int world)
 {
 	const int q = threadIdx.x;
 	if (q >= world) return;
@@ -207,17 +169,65 @@ __global__ __launch_bounds__(64) void k_range_seal(RangeDev rd, int world)
 	rd.tcnt[q * KMX_CTR_STRIDE] = 0;
 }
 
+// 1. every attempt of the lists this rank holds -> triples by owner rank; positions kept per slot (crec) for steps 3
+template <int W, int NHM> __global__ __launch_bounds__(256) void k_range_emit(ModelDev md, BlockDev bd, RangeDev rd, RangePlan pl, int t, int pp)
+{
+	__shared__ int s_key[KMX_MAX_RANKS * KMX_CL_MAXBINS + 1], s_base[KMX_MAX_RANKS], s_wsum[4];
+	__shared__ RangeOutLds L;
+	const int i = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+	const int n = bd.n[pp][i];
+	if ((int)blockIdx.x * 256 < n) {                                    // uniform
+		range_out_stage(rd, pl.world, L);
+		const u64 row = (u64)i * KMX_BUCKET;
+		const int a = (i + t) % md.nb;
+		if (x == 0) atomicAdd(bd.stats + ST_ATTEMPTS, (u64)n);
+		u64 word[NHM];
+		int dest[NHM];
+		u32 where[NHM], valid = 0;
+		if (x < n) {
+			const u32 raw = bd.list[pp][row + x];
+			const u32 idx = (raw & LIST_HOLE) ? bd.mover[pp][row + (raw & ~LIST_HOLE)] : raw;
+			if (raw & LIST_HOLE) bd.list[pp][row + x] = idx;            // later kernels of the round read plain entries
+			u64 v[W];
+			load_kmer<W>(bd.kmers, row + idx, v);
+			const u32 bin = md.bin_of_occ[bd.counts[row + idx]];
+			Premixed<W> pm = premix_string<W>(left_align<W>(v, md.k), md.gfull);
+			u64 pos[NHM];
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh) {
+					pos[j] = mod_u64(murmur_seeded<W>(pm, md.gfull, c_seeds[(a * md.nh + j) & 127]), md.km_mod);
+					word[j] = RT_MAKE(pos[j], (bin >> j) & 1u, i, x, j);
+					dest[j] = range_owner(pl, pos[j] >> 4);
+					valid |= 1u << j;
+				}
+			crec_store<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh, pos);
+			bd.uw[pp][row + x] = bin << 16;                              // the untagged mask arrives with the verdicts
+			bd.status[pp][row + x] = SLOT_UNDECIDED;
+		}
+		range_block_append_sorted<NHM>(rd, L, pl.world, word, dest, valid, where, s_key, s_base, s_wsum);
+		if (x < n)
+#pragma unroll
+			for (int j = 0; j < NHM; j++)
+				if (j < md.nh) rd.tidx[(row + x) * (u64)md.nh + j] = where[j];
+	}
+}
+
+// 1b. the headers, when the launch that filled the regions has ended (a launch of one wave: a ticket per workgroup in the
+// producer -- same-address atomics serialise at ~11 ns -- costs more than it saves)
+__global__ __launch_bounds__(64) void k_range_seal(RangeDev rd, int world) { range_seal_regions(rd, world); }
+
 // 2a. owner: the winners' tag / value bits of the round before (kmodel.hpp:611-618), the commit words in front of every region
 // (ovf: the owner's overflow flags of the round before -- k_range_ship has read them -- are reset here, ahead of this round's k_range_verdict)
-__global__ __launch_bounds__(256) void k_range_commit_apply(ModelDev md, RangeIn in, int *ovf)
+__global__ __launch_bounds__(256) void k_range_commit_apply(ModelDev md, RangeIn in, int *ovf, int part)
 {
 	__shared__ RangeInLds L;
 	if (ovf && blockIdx.x == 0 && (int)threadIdx.x < md.nb) ovf[threadIdx.x] = 0;
-	range_in_stage(in, L);
+	range_in_stage(in, L, part);
 	const u32 n = L.pc[in.world];
 	for (u32 c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
 		const int s = range_seg_of(L.pc, in.world, c);
-		const u64 tr = L.reg[s][c - L.pc[s]];
+		const u64 tr = L.reg[s][L.c0[s] + (c - L.pc[s])];
 		const u64 pos = RT_POS(tr);
 		const u32 b = bit_in_cell(pos);
 		atomicOr(md.cells[RT_LIST(tr)] + (pos >> 4), CELL_TAG(b) | (RT_WANT(tr) ? CELL_VAL(b) : 0u));
@@ -304,6 +314,14 @@ __global__ __launch_bounds__(256) void k_range_ship(BlockDev obd, int nb, RangeI
 	}
 }
 
+// the BULK of a round's commits -- the uncontended winners', 99.6 % -- is complete when k_range_apply ends: its count goes to the
+// owners right away (header word 2), so that they can set those bits while this rank still orders its contended candidates
+__global__ __launch_bounds__(64) void k_range_seal_bulk(RangeDev rd, int world)
+{
+	const int q = threadIdx.x;
+	if (q < world) rd.hdr_out[q][2] = (u32)rd.ccnt[q * KMX_CTR_STRIDE];
+}
+
 // 3a. list rank: the verdicts of a slot's positions, read from where its triples went; an uncontended winner's commit words --
 // one per position it saw untagged (kmodel.hpp:611-618) -- go straight to the front of the regions, by owner rank
 template <int NHM> __global__ __launch_bounds__(256) void k_range_apply(ModelDev md, BlockDev bd, RangeDev rd, RangePlan pl, int t, int pp)
@@ -361,22 +379,40 @@ template <int NHM> __global__ __launch_bounds__(256) void k_range_apply(ModelDev
 	range_block_append<NHM>(rd, L, pl.world, word, dest, valid, s_acnt, s_abase);
 }
 
-// a contended candidate that won its turn in k_range_resolve: its commit words (few hundred per list and round: one atomic each)
-template <int NHM> __device__ __forceinline__ void range_winner_commits(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangeOutLds &L, const RangePlan &pl, int t, int pp, int i, u64 row, u32 x)
+// the contended candidates that won their turn in k_range_resolve: their commit words, AFTER the ordered loop (inside it every
+// returning atomic would add its latency to each of the loop's dependent iterations).  Every thread of the workgroup calls it;
+// `won` says whether this thread's record x has won.  The workgroup counts per destination in LDS and reserves with one atomic.
+template <int NHM> __device__ __forceinline__ void range_winner_commits(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangeOutLds &L, const RangePlan &pl, int t, int pp, int i, u64 row, u32 x, bool won,
+                                                                        int *s_cc, int *s_cb)
 {
-	const u32 uw = bd.uw[pp][row + x], um = uw & 0xFFFFu, want = uw >> 16;
-	const CRec<NHM> cr = crec_load<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh);
-	u64 pos[NHM];
+	if ((int)threadIdx.x < pl.world) s_cc[threadIdx.x] = 0;
+	__syncthreads();
+	u64 word[NHM];
+	int dest[NHM], rank[NHM];
+	u32 valid = 0;
+	if (won) {
+		const u32 uw = bd.uw[pp][row + x], um = uw & 0xFFFFu, want = uw >> 16;
+		const CRec<NHM> cr = crec_load<NHM>(bd.crec[pp] + (row + x) * (u64)crec_words(md.nh), md.nh);
+		u64 pos[NHM];
+#pragma unroll
+		for (int j = 0; j < NHM; j++)
+			if (j < md.nh) pos[j] = ((u64)crec_cell<NHM>(cr, j) << 4) | crec_nib<NHM>(cr, md.nh, j);
+#pragma unroll
+		for (int j = 0; j < NHM; j++)
+			if (j < md.nh && ((um >> j) & 1u)) {
+				dest[j] = range_owner(pl, pos[j] >> 4);
+				word[j] = RT_COMMIT | RT_MAKE(pos[j], value_at_position<NHM>(md, pos, um, want, j), (i + t) % md.nb, 0, 0);
+				rank[j] = atomicAdd(&s_cc[dest[j]], 1);
+				valid |= 1u << j;
+			}
+	}
+	__syncthreads();
+	if ((int)threadIdx.x < pl.world) s_cb[threadIdx.x] = s_cc[threadIdx.x] ? atomicAdd(rd.ccnt + (int)threadIdx.x * KMX_CTR_STRIDE, s_cc[threadIdx.x]) : 0;
+	__syncthreads();
 #pragma unroll
 	for (int j = 0; j < NHM; j++)
-		if (j < md.nh) pos[j] = ((u64)crec_cell<NHM>(cr, j) << 4) | crec_nib<NHM>(cr, md.nh, j);
-#pragma unroll
-	for (int j = 0; j < NHM; j++)
-		if (j < md.nh && ((um >> j) & 1u)) {
-			const int q = range_owner(pl, pos[j] >> 4);
-			const int off = atomicAdd(rd.ccnt + q * KMX_CTR_STRIDE, 1);
-			L.out[q][(u64)off] = RT_COMMIT | RT_MAKE(pos[j], value_at_position<NHM>(md, pos, um, want, j), (i + t) % md.nb, 0, 0);
-		}
+		if ((valid >> j) & 1u) L.out[dest[j]][(u64)(s_cb[dest[j]] + rank[j])] = word[j];
+	__syncthreads();
 }
 
 // 3b. the contended candidates of a list, in list order, from the verdicts alone.  ONE workgroup per list.  Only the
@@ -391,9 +427,10 @@ template <int NHM> __device__ __forceinline__ void range_winner_commits(const Mo
 // of finish_lds).  Up to 2048 records on 2048 positions are decided in LDS with their state in registers (the usual case:
 // a few hundred records per list and round); larger sets use the table in global memory, without a size limit.
 __device__ __forceinline__ u32 rt_hash(u64 pos) { return (u32)((pos * 0x9E3779B97F4A7C15ULL) >> 32); }
+constexpr u32 RT_WON = 1u << 30;                                     // in a record's mask word: it won its turn
 constexpr int RT_LDS_BITS = 12, RT_LDS = 1 << RT_LDS_BITS, RT_RPT = 2;        // 4096 entries: key | mark in one u64 (32 KB) + reservations (16 KB)
 #define RT_LDS_MARK(v) (1ULL << (62 + (v)))
-template <int NHM> __device__ __forceinline__ u64 range_resolve_lds(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangeOutLds &Lo, const RangePlan &pl, int t, int pp, int i, u64 row, int nc, const u32 *cont, const u32 *bothm,
+template <int NHM> __device__ __forceinline__ u64 range_resolve_lds(const ModelDev &md, const BlockDev &bd, int pp, int i, u64 row, int nc, const u32 *cont, const u32 *bothm, u32 *wonm,
                                                                     u64 *s_key, u32 *s_resv, int *s_pending, int *s_succ)
 {
 	constexpr u32 TM = RT_LDS - 1;
@@ -460,7 +497,7 @@ template <int NHM> __device__ __forceinline__ u64 range_resolve_lds(const ModelD
 						atomicOr(&s_key[e[k][j]], RT_LDS_MARK(v));
 					}
 				bd.status[pp][row + x[k]] = SLOT_INSERTED;
-				range_winner_commits<NHM>(md, bd, rd, Lo, pl, t, pp, i, row, x[k]);
+				wonm[(int)threadIdx.x + k * 1024] = RT_WON;                  // (read again by this very thread when the loop is over: k_range_resolve's tail)
 				live[k] = false;
 				succ++;
 			}
@@ -489,7 +526,7 @@ template <int NHM> __device__ __forceinline__ u64 range_resolve_lds(const ModelD
 }
 template <int NHM> __global__ __launch_bounds__(1024) void k_range_resolve(ModelDev md, BlockDev bd, RangeDev rd, RangePlan pl, int t, int pp)
 {
-	__shared__ int s_pending, s_succ, s_ent;
+	__shared__ int s_pending, s_succ, s_ent, s_cc[KMX_MAX_RANKS], s_cb[KMX_MAX_RANKS];
 	__shared__ u64 s_key[RT_LDS];
 	__shared__ u32 s_resv[RT_LDS];
 	const int i = blockIdx.x, tab = i / pl.world;                       // the lists a rank holds are i = rank, rank + world, ...: one table each
@@ -509,7 +546,7 @@ template <int NHM> __global__ __launch_bounds__(1024) void k_range_resolve(Model
 	}
 	__syncthreads();
 	u64 iters = 0;
-	if (nc <= 1024 * RT_RPT && s_ent * 2 <= RT_LDS) iters = range_resolve_lds<NHM>(md, bd, rd, Lo, pl, t, pp, i, row, nc, cont, cur, s_key, s_resv, &s_pending, &s_succ);
+	if (nc <= 1024 * RT_RPT && s_ent * 2 <= RT_LDS) iters = range_resolve_lds<NHM>(md, bd, pp, i, row, nc, cont, cur, cur, s_key, s_resv, &s_pending, &s_succ);
 	else {
 		int tb = 10;
 		while ((1u << tb) < 4u * (u32)nc * (u32)md.nh && tb < (int)rd.rt_bits) tb++;
@@ -517,7 +554,7 @@ template <int NHM> __global__ __launch_bounds__(1024) void k_range_resolve(Model
 		u64 *key = rd.rt_key + ((u64)tab << rd.rt_bits);
 		u32 *resv = rd.rt_resv + ((u64)tab << rd.rt_bits), *mark = rd.rt_mark + ((u64)tab << rd.rt_bits);
 		u32 *eidx = rd.rt_eidx + row * (u64)md.nh;                      // per record: table entry of each position
-		constexpr u32 LIVE = 1u << 31;
+		constexpr u32 LIVE = 1u << 31, WON = RT_WON;
 		for (u32 q = threadIdx.x; q <= tmask; q += 1024) { key[q] = 0; resv[q] = 0; mark[q] = 0; }
 		drain_vmem();
 		__syncthreads();
@@ -574,8 +611,7 @@ template <int NHM> __global__ __launch_bounds__(1024) void k_range_resolve(Model
 						atomicOr(&mark[e], 1u << v);
 					}
 				bd.status[pp][row + x] = SLOT_INSERTED;
-				range_winner_commits<NHM>(md, bd, rd, Lo, pl, t, pp, i, row, x);
-				cur[r] = 0;
+				cur[r] = WON;                                            // (read again below by this very thread)
 				succ++;
 			}
 			if (succ) atomicAdd(&s_succ, succ);
@@ -604,6 +640,12 @@ template <int NHM> __global__ __launch_bounds__(1024) void k_range_resolve(Model
 			if (!pending) break;
 		}
 	}
+	// the winners' commit words, now that the ordered loop is over (its state is dead: the registers are free for this)
+	for (int r0 = 0; r0 < nc; r0 += 1024) {                              // uniform
+		const int r = r0 + (int)threadIdx.x;
+		const bool won = r < nc && (cur[r] & RT_WON);
+		range_winner_commits<NHM>(md, bd, rd, Lo, pl, t, pp, i, row, r < nc ? cont[r] : 0u, won, s_cc, s_cb);
+	}
 	if (threadIdx.x == 0) {
 		atomicAdd(bd.stats + ST_FIN_ITERS, iters + 1);
 		if (s_succ) atomicAdd(bd.stats + ST_SLOW_SUCC, (u64)s_succ);
@@ -628,12 +670,13 @@ void range_emit(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, cons
 void range_seal(const RangeDev &rd, const RangePlan &pl, hipStream_t st) { hipLaunchKernelGGL(k_range_seal, dim3(1), dim3(64), 0, st, rd, pl.world); }
 // step 2, owner.  obd: the owner's view (its own overflow flags and padded bin counters; the claim bins of the handle, unused by the
 // list side here); lver: one byte per triple received
-void range_verdict(const ModelDev &md, const BlockDev &obd_, int *pcnt, int t, const RangeIn &in, unsigned char *lver, hipStream_t st)
+// commits: which commit words are still to be applied (RANGE_ALL, or RANGE_LATE when the bulk went ahead on another stream)
+void range_verdict(const ModelDev &md, const BlockDev &obd_, int *pcnt, int t, const RangeIn &in, unsigned char *lver, int commits, hipStream_t st)
 {
 	BlockDev obd = obd_;
 	obd.rverdict = lver;
 	const unsigned g = range_grid(md);
-	hipLaunchKernelGGL(k_range_commit_apply, dim3(g), dim3(256), 0, st, md, in, obd.cl_ovf);      // the previous round's winners first
+	hipLaunchKernelGGL(k_range_commit_apply, dim3(commits == RANGE_LATE ? 64u : g), dim3(256), 0, st, md, in, obd.cl_ovf, commits);      // the previous round's winners first
 	if (md.nh <= 8) {
 		hipLaunchKernelGGL((k_range_verdict<8>), dim3(g), dim3(256), 0, st, md, obd, pcnt, t, in, lver);
 		hipLaunchKernelGGL((k_round_detect<8, 1024, KMX_CL_TBITS(8), true>), dim3(KMX_CL_BINS(8), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, 0);
@@ -643,23 +686,25 @@ void range_verdict(const ModelDev &md, const BlockDev &obd_, int *pcnt, int t, c
 	}
 	hipLaunchKernelGGL(k_range_ship, dim3(std::min(g, 1024u)), dim3(256), 0, st, obd, md.nb, in, (const unsigned char *)lver);
 }
-// step 3, list rank
-void range_resolve(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangePlan &pl, int t, int pp, hipStream_t st)
+// step 3, list rank: the verdicts of every slot; the uncontended winners' commits (the bulk) are in the regions when it ends ...
+void range_apply(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangePlan &pl, int t, int pp, bool seal_bulk, hipStream_t st)
 {
 	const dim3 grid(KMX_BUCKET / 256, md.nb);
-	if (md.nh <= 8) {
-		hipLaunchKernelGGL((k_range_apply<8>), grid, dim3(256), 0, st, md, bd, rd, pl, t, pp);
-		hipLaunchKernelGGL((k_range_resolve<8>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl, t, pp);
-	} else {
-		hipLaunchKernelGGL((k_range_apply<16>), grid, dim3(256), 0, st, md, bd, rd, pl, t, pp);
-		hipLaunchKernelGGL((k_range_resolve<16>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl, t, pp);
-	}
+	if (md.nh <= 8) hipLaunchKernelGGL((k_range_apply<8>), grid, dim3(256), 0, st, md, bd, rd, pl, t, pp);
+	else hipLaunchKernelGGL((k_range_apply<16>), grid, dim3(256), 0, st, md, bd, rd, pl, t, pp);
+	if (seal_bulk) hipLaunchKernelGGL(k_range_seal_bulk, dim3(1), dim3(64), 0, st, rd, pl.world);
+}
+// ... then the contended in list order (their commits behind the bulk) and reorder_buffer
+void range_resolve(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangePlan &pl, int t, int pp, hipStream_t st)
+{
+	if (md.nh <= 8) hipLaunchKernelGGL((k_range_resolve<8>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl, t, pp);
+	else hipLaunchKernelGGL((k_range_resolve<16>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl, t, pp);
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, md.nb), dim3(256), 0, st, md, bd, t, pp, 0));   // (no REC_WON records here: Un stays 0)
 }
 // the commit words of a last exchange
-void range_commit_apply(const ModelDev &md, const RangeIn &in, hipStream_t st)
+void range_commit_apply(const ModelDev &md, const RangeIn &in, int part, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_range_commit_apply, dim3(range_grid(md)), dim3(256), 0, st, md, in, (int *)nullptr);
+	hipLaunchKernelGGL(k_range_commit_apply, dim3(range_grid(md)), dim3(256), 0, st, md, in, (int *)nullptr, part);
 }
 
 }   // namespace kmxk

@@ -242,6 +242,27 @@ class Comm:
         out = out.to(local.device) if out.device != local.device else out
         return torch.cat([out[q * width: q * width + int(counts[q])] for q in range(self.world)])
 
+    def all_gather_ranges(self, v: torch.Tensor, lo, window: int = 1 << 24):
+        """every rank holds its range v[lo[rank]:lo[rank + 1]] of `v`; on return every rank holds all of `v` -- in place, window
+        by window (the ranges of a position-range partition differ by at most one element, so a window is one all_gather_into_tensor
+        of equal pieces; the temporaries are world x window elements whatever the array's size is)"""
+        if self.world == 1 and self.shortcut:
+            return
+        width = max(int(lo[q + 1]) - int(lo[q]) for q in range(self.world))
+        for off in range(0, width, window):
+            w = min(window, width - off)
+            mine = v[int(lo[self.rank]) + off: min(int(lo[self.rank]) + off + w, int(lo[self.rank + 1]))]
+            piece = mine if mine.numel() == w else torch.cat([mine, torch.zeros(w - mine.numel(), dtype=v.dtype, device=v.device)])
+            wire = self._wire(piece.contiguous())
+            out = torch.empty(self.world * w, dtype=v.dtype, device=wire.device)
+            dist.all_gather_into_tensor(out, wire, group=self.group)
+            self.collectives += 1
+            self.bytes_sent += piece.numel() * piece.element_size() * (self.world - 1)
+            for q in range(self.world):
+                a, b = int(lo[q]) + off, min(int(lo[q]) + off + w, int(lo[q + 1]))
+                if q != self.rank and b > a:
+                    v[a:b].copy_(out[q * w: q * w + (b - a)])
+
     def or_allreduce(self, words: torch.Tensor, or_into, window: int = 1 << 26):
         """Bitwise OR of `words` (int32, same length on every rank) over the ranks, in place, by position range: an
         all-to-all brings range r of every rank's partial filter to rank r, `or_into(dst, src)` merges them there, an
@@ -554,7 +575,7 @@ def build_range_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: to
         comm.or_allreduce(eng.view("km_back"), eng.or_into)
         for a in range(nb):                                      # every rank's cell range of every array -> every rank
             for v, lo in eng.array_ranges(a):                    # (a view of the array and the ranks' bounds in its elements)
-                v.copy_(comm.all_gather_v(v[lo[rank]:lo[rank + 1]], [lo[q + 1] - lo[q] for q in range(world)]))
+                comm.all_gather_ranges(v, lo)
     eng.complete(rest_km_all, rest_cnt_all, st)
     return {"n_km": n_km, "blocks": n_blocks, "bytes_sent": comm.bytes_sent - sent0, "collectives": comm.collectives - coll0,
             "cells_owned": [int(eng.cell_lo[rank]), int(eng.cell_lo[rank + 1])], "partition": "range"}

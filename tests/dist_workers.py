@@ -168,6 +168,9 @@ def rccl_worker(rank, world, port, spec, out_dir, q):
         assert torch.equal(comm.all_to_all_v(cn[:0], [0], [0]), cn[:0])
         assert torch.equal(comm.all_gather_v(km[:17], [17]), km[:17])
         assert torch.equal(comm.all_gather_v(cn[:0], [0]), cn[:0])
+        r = cn.clone()
+        comm.all_gather_ranges(r, [0, 1000], window=300)             # the range partition's array replication: in place, in windows (4 collectives here)
+        assert torch.equal(r, cn)
         b = cn.clone()
         comm.broadcast(b, 0)
         assert torch.equal(b, cn)

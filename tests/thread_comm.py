@@ -102,6 +102,17 @@ class ThreadComm:
         self._done()
         return out
 
+    def all_gather_ranges(self, v, lo, window=1 << 24):
+        allv = self._swap(v)
+        for q in range(self.world):
+            a, b = int(lo[q]), int(lo[q + 1])
+            if q != self.rank and b > a:
+                v[a:b].copy_(allv[q][a:b])
+        if v.is_cuda:
+            torch.cuda.synchronize()
+        self._done()
+        self.collectives += 1
+
     def or_allreduce(self, words, or_into, window=1 << 26):
         if words.numel() == 0:
             return
