@@ -31,16 +31,38 @@ template <typename T> T rd(const unsigned char *p)
 }
 }   // namespace
 
+// the prefix file is read where it is needed: markers, the tail, the header -- and the LUT(s) straight into lut_ with parallel
+// preads (a KMC2 database with 512 bins has 67 MB of them: through a buffer of the whole file and a copy that is 60 ms)
 bool KmcListing::open(const std::string &prefix)
 {
 	close();
-	std::vector<unsigned char> pre;
-	if (!read_file(prefix + ".kmc_pre", pre) || pre.size() < 4 + 4 + 12 || memcmp(pre.data(), "KMCP", 4) ||
-	    memcmp(pre.data() + pre.size() - 4, "KMCP", 4)) {
+	const int pfd = ::open((prefix + ".kmc_pre").c_str(), O_RDONLY);
+	struct stat psb;
+	auto pread_all = [&](void *dst, size_t bytes, uint64_t off) {
+		unsigned char *d = (unsigned char *)dst;
+		while (bytes) {
+			const ssize_t got = ::pread(pfd, d, bytes, (off_t)off);
+			if (got <= 0) return false;
+			d += got; off += (uint64_t)got; bytes -= (size_t)got;
+		}
+		return true;
+	};
+	unsigned char head[4], tail[12];
+	if (pfd < 0 || fstat(pfd, &psb) != 0 || (size_t)psb.st_size < 4 + 4 + 12 || !pread_all(head, 4, 0) || !pread_all(tail, 12, (uint64_t)psb.st_size - 12) ||
+	    memcmp(head, "KMCP", 4) || memcmp(tail + 8, "KMCP", 4)) {
+		if (pfd >= 0) ::close(pfd);
 		err_ = "cannot open " + prefix + ".kmc_pre (missing or no KMCP markers)";
 		return false;
 	}
-	const size_t end = pre.size();
+	struct Closer { int fd; ~Closer() { ::close(fd); } } closer{pfd};
+	const size_t end = (size_t)psb.st_size;
+	// the last 8 + header_offset bytes: header, offset field, marker (header_offset is one byte: at most 255)
+	std::vector<unsigned char> pre_tail(std::min<size_t>(end, 8 + 255 + 4));
+	if (!pread_all(pre_tail.data(), pre_tail.size(), end - pre_tail.size())) { err_ = "cannot read " + prefix + ".kmc_pre"; return false; }
+	struct TailView {                                               // pre[i] for the bytes of the file that were read
+		const std::vector<unsigned char> &t; size_t end;
+		const unsigned char &operator[](size_t i) const { return t[i - (end - t.size())]; }
+	} pre{pre_tail, end};
 	version_ = rd<uint32_t>(&pre[end - 12]);                        // kmc_file.cpp:184-187
 	const uint32_t header_offset = pre[end - 8];                    // low byte only (:193, :243)
 	if (version_ != 0 && version_ != 0x200) { err_ = "unsupported KMC database version"; return false; }
@@ -81,7 +103,20 @@ bool KmcListing::open(const std::string &prefix)
 	const size_t n_lut = lut_bytes / 8;
 	if (n_lut == 0 || 4 + n_lut * 8 > end) { err_ = "corrupt KMC LUT"; return false; }
 	lut_.resize(n_lut + 1);
-	memcpy(lut_.data(), &pre[4], n_lut * 8);
+	{
+		const size_t bytes = n_lut * 8;
+		const int T = (int)std::max<size_t>(1, std::min<size_t>(8, bytes / (4u << 20) + 1));
+		std::atomic<bool> bad{false};
+		auto part = [&](int t) {
+			const size_t per = ((bytes + T - 1) / T + 4095) & ~size_t(4095), lo = (size_t)t * per, hi = std::min(bytes, lo + per);
+			if (lo < hi && !pread_all((unsigned char *)lut_.data() + lo, hi - lo, 4 + lo)) bad = true;
+		};
+		std::vector<std::thread> th;
+		for (int t = 1; t < T; t++) th.emplace_back(part, t);
+		part(0);
+		for (auto &x : th) x.join();
+		if (bad) { err_ = "cannot read the LUT of " + prefix + ".kmc_pre"; lut_.clear(); return false; }
+	}
 	lut_[n_lut] = total_;
 	prefix_mask_ = (uint64_t(1) << (2 * p_)) - 1;
 	suf_bytes_ = (k_ - p_) / 4;

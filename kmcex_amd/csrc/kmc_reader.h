@@ -9,10 +9,20 @@
 #pragma once
 #include <cstdint>
 #include <atomic>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace kmx {
+
+// a vector whose resize() does not zero what is about to be overwritten (the LUTs of a KMC2 database with 512 bins are 67 MB)
+template <typename T> struct NoInitAlloc : std::allocator<T> {
+	template <typename U> struct rebind { typedef NoInitAlloc<U> other; };
+	template <typename U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+	template <typename U, typename... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<uint64_t, NoInitAlloc<uint64_t>> LutVec;
 
 class KmcListing {
 public:
@@ -47,7 +57,7 @@ public:
 	uint32_t suffix_bytes() const { return suf_bytes_; }
 	uint32_t counter_bytes() const { return counter_size_; }
 	uint64_t prefix_mask() const { return prefix_mask_; }
-	const std::vector<uint64_t> &lut() const { return lut_; }
+	const LutVec &lut() const { return lut_; }
 	void copy_records(uint64_t rec0, uint64_t n, unsigned char *dst) const;
 
 private:
@@ -60,7 +70,7 @@ private:
 	bool read_at(uint64_t off, void *dst, size_t bytes) const;
 	mutable std::atomic<bool> io_failed_{false};
 	std::vector<unsigned char> stage_;       // raw bytes of the batch next_batch is decoding (host decoder only)
-	std::vector<uint64_t> lut_;      // concatenated LUT(s); lut_[size] sentinel = total
+	LutVec lut_;                     // concatenated LUT(s); lut_[size] sentinel = total
 	uint64_t rec_ = 0, avail_ = 0, total_ = 0, max_count_ = 0, prefix_mask_ = 0;
 	uint32_t k_ = 0, mode_ = 0, counter_size_ = 0, p_ = 0, min_count_ = 0, version_ = 0;
 	uint32_t suf_bytes_ = 0, rec_bytes_ = 0;

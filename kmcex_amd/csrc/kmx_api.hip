@@ -1424,6 +1424,38 @@ struct FeedSlot {
 };
 }   // namespace
 
+// the feed of KModel::init(db) on the handle: two pinned slots of B raw records + their device twins, decoded k-mers / counts
+// of a batch, a copy stream, events, the prefix LUT on the device -- kept across calls (kmx_model::KmcFeed)
+static bool feed_alloc(kmx_model *m, size_t B, size_t rb, int W, const kmx::LutVec &lut)
+{
+	auto &F = m->feed;
+	if (hipSetDevice(m->device) != hipSuccess) return false;
+	bool good = F.copy || hipStreamCreateWithFlags(&F.copy, hipStreamNonBlocking) == hipSuccess;
+	for (int s = 0; s < 2 && good; s++) {
+		if (!F.ev_copied[s]) good = hipEventCreateWithFlags(&F.ev_copied[s], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&F.ev_free[s], hipEventDisableTiming) == hipSuccess;
+		if (good && F.raw_cap < B * rb + 16) {
+			if (F.raw[s]) hipHostFree(F.raw[s]);
+			hipFree(F.draw[s]);
+			F.raw[s] = nullptr; F.draw[s] = nullptr;
+			good = hipHostMalloc((void **)&F.raw[s], B * rb + 16) == hipSuccess && hipMalloc((void **)&F.draw[s], B * rb + 16) == hipSuccess;
+		}
+		if (good && F.dk_cap < B * (size_t)W) {
+			hipFree(F.dk[s]); hipFree(F.dc[s]);
+			F.dk[s] = nullptr; F.dc[s] = nullptr;
+			good = hipMalloc((void **)&F.dk[s], B * W * 8) == hipSuccess && hipMalloc((void **)&F.dc[s], B * 4) == hipSuccess;
+		}
+	}
+	if (good) { F.raw_cap = std::max(F.raw_cap, B * rb + 16); F.dk_cap = std::max(F.dk_cap, B * (size_t)W); }
+	if (good && F.lut_cap < lut.size()) {
+		hipFree(F.d_lut); F.d_lut = nullptr;
+		good = hipMalloc((void **)&F.d_lut, lut.size() * 8) == hipSuccess;
+		if (good) F.lut_cap = lut.size();
+	}
+	if (good) good = hipMemcpy(F.d_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+	if (!good) F.raw_cap = F.dk_cap = 0;                         // whatever is half there is replaced next time
+	return good;
+}
+
 static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 {
 	if (!m || !db_prefix) return fail(KMX_E_ARG, "null argument");
@@ -1462,31 +1494,7 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 	// the buffers of pass 2 are (re)allocated beside pass 1 when this database needs larger ones than the handle holds
 	bool ok = false;
 	allocator = std::thread([&] {
-		if (hipSetDevice(m->device) != hipSuccess) return;
-		bool good = F.copy || hipStreamCreateWithFlags(&F.copy, hipStreamNonBlocking) == hipSuccess;
-		for (int s = 0; s < 2 && good; s++) {
-			if (!F.ev_copied[s]) good = hipEventCreateWithFlags(&F.ev_copied[s], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&F.ev_free[s], hipEventDisableTiming) == hipSuccess;
-			if (good && F.raw_cap < B * rb + 16) {
-				if (F.raw[s]) hipHostFree(F.raw[s]);
-				hipFree(F.draw[s]);
-				F.raw[s] = nullptr; F.draw[s] = nullptr;
-				good = hipHostMalloc((void **)&F.raw[s], B * rb + 16) == hipSuccess && hipMalloc((void **)&F.draw[s], B * rb + 16) == hipSuccess;
-			}
-			if (good && F.dk_cap < B * (size_t)W) {
-				hipFree(F.dk[s]); hipFree(F.dc[s]);
-				F.dk[s] = nullptr; F.dc[s] = nullptr;
-				good = hipMalloc((void **)&F.dk[s], B * W * 8) == hipSuccess && hipMalloc((void **)&F.dc[s], B * 4) == hipSuccess;
-			}
-		}
-		if (good) { F.raw_cap = std::max(F.raw_cap, B * rb + 16); F.dk_cap = std::max(F.dk_cap, B * (size_t)W); }
-		const std::vector<uint64_t> &lut = db.lut();
-		if (good && F.lut_cap < lut.size()) {
-			hipFree(F.d_lut); F.d_lut = nullptr;
-			good = hipMalloc((void **)&F.d_lut, lut.size() * 8) == hipSuccess;
-			if (good) F.lut_cap = lut.size();
-		}
-		if (good) good = hipMemcpy(F.d_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
-		if (!good) F.raw_cap = F.dk_cap = 0;                         // whatever is half there is replaced next time
+		const bool good = feed_alloc(m, B, rb, W, db.lut());
 		{ std::lock_guard<std::mutex> lk(mu); ok = good; alloc_done = true; }
 		cv.notify_all();
 	});
@@ -1847,20 +1855,23 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 	const int k = (int)db.kmer_length(), W = db.words(), nb = hs[0]->nb;
 	const u64 N = db.records();
 	const size_t rb = db.record_bytes();
-	{   // a database with unlisted records (KMC never writes one) needs the host decoder: one device builds it
-		uint64_t nbf[3], bad = 0, not_listed = 0;
-		db.count_classes((u32)hs[0]->ci, (u32)hs[0]->cs, hs[0]->bf_num, nbf, &bad, &not_listed, 16);
+	uint64_t nbf_all[3] = {0, 0, 0};
+	{   // pass 1 (kmodel.hpp:423-428) over the whole listing, on the host cores: a scan of the counter bytes, like the one-GPU init.
+		// A database with unlisted records (KMC never writes one) needs the host decoder: one device builds it
+		uint64_t bad = 0, not_listed = 0;
+		const unsigned hw = std::thread::hardware_concurrency();
+		db.count_classes((u32)hs[0]->ci, (u32)hs[0]->cs, hs[0]->bf_num, nbf_all, &bad, &not_listed, hw > 32 ? 32 : (hw > 1 ? (int)hw : 1));
+		if (db.io_failed()) return fail(KMX_E_IO, "reading %s.kmc_suf failed during pass 1", db_prefix);
 		if (bad) return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)bad, hs[0]->ci, hs[0]->cs);
 		if (not_listed) return fail(KMX_E_ARG, "the database holds records outside its header's count range: build it on one device");
+		db.set_threads(std::max(1, (int)std::min(hw ? hw : 1u, 32u) / P));     // every handle's thread reads its slice with this many preads side by side
 	}
 	struct Rank {
-		u64 *d_km = nullptr, *d_ck = nullptr, *d_rk = nullptr, *d_allk = nullptr, *d_lut = nullptr;
+		u64 *d_km = nullptr, *d_ck = nullptr, *d_rk = nullptr, *d_allk = nullptr;
 		u32 *d_cnt = nullptr, *d_cc = nullptr, *d_rc = nullptr;
 		int *d_allc = nullptr;
-		unsigned char *d_raw = nullptr, *h_raw = nullptr;
 		u32 *d_tmp = nullptr;
 		u64 n = 0, n_c = 0, n_r = 0, rec_lo = 0;
-		uint64_t nbf[3] = {0, 0, 0};
 		std::vector<u64 *> msg;                                    // [nb * 2] list i, parity
 		hipEvent_t ev_round = nullptr, ev_copied = nullptr;     // ring: the round is enqueued / the hand-offs are
 		hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // range: the regions are sealed / the verdicts shipped / the bulk of the commits is out / ... is applied
@@ -1878,7 +1889,6 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 	auto note = [&](int rc) { if (rc) { std::lock_guard<std::mutex> lk(err_mu); if (!err.load()) { err = rc; err_msg = g_err; } } return rc; };
 	auto hip_ok = [&](hipError_t e, const char *what) { if (e != hipSuccess) { fail(KMX_E_NODEVICE, "%s: %s", what, hipGetErrorString(e)); note(KMX_E_NODEVICE); return false; } return true; };
 	HostBarrier bar(P);
-	uint64_t nbf_all[3] = {0, 0, 0};
 	u64 n_km = 0, n_blocks = 0, n_rest_all = 0;
 	std::vector<u64> offs((size_t)P + 1, 0), rest_off((size_t)P + 1, 0);
 	kmx_stats totals;
@@ -1894,41 +1904,43 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 		Rank &r = R[(size_t)d];
 		if (!hip_ok(hipSetDevice(m->device), "hipSetDevice")) { /* keep going to the barriers */ }
 		hipStream_t st = m->stream;
-		// ---- this rank's slice of the listing: raw records -> device -> decoded there (k_kmc_decode); pass 1 on the slice
+		// ---- this rank's slice of the listing: raw records -> the two pinned slots of the handle's feed -> device -> decoded there
+		// (k_kmc_decode); the pread of batch b + 1 runs under the copy and the decode of batch b
 		r.rec_lo = N * (u64)d / (u64)P;
 		r.n = N * (u64)(d + 1) / (u64)P - r.rec_lo;
 		if (!err) {
-			const std::vector<uint64_t> &lut = db.lut();
+			const u64 B = u64(1) << 23;
+			auto &F = m->feed;
 			bool ok = hip_ok(hipEventCreateWithFlags(&r.ev_round, hipEventDisableTiming), "event") && hip_ok(hipEventCreateWithFlags(&r.ev_copied, hipEventDisableTiming), "event") &&
 			          hip_ok(hipEventCreateWithFlags(&r.ev[0], hipEventDisableTiming), "event") && hip_ok(hipEventCreateWithFlags(&r.ev[1], hipEventDisableTiming), "event") &&
 			          hip_ok(hipEventCreateWithFlags(&r.ev[2], hipEventDisableTiming), "event") && hip_ok(hipEventCreateWithFlags(&r.ev[3], hipEventDisableTiming), "event") &&
-			          (!by_range || hip_ok(hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking), "stream")) &&
-			          hip_ok(hipMalloc((void **)&r.d_lut, lut.size() * 8), "hipMalloc") && hip_ok(hipMemcpy(r.d_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice), "LUT copy") &&
-			          hip_ok(hipMalloc((void **)&r.d_km, std::max<u64>(r.n, 1) * W * 8), "hipMalloc") && hip_ok(hipMalloc((void **)&r.d_cnt, std::max<u64>(r.n, 1) * 4), "hipMalloc") &&
-			          hip_ok(hipMalloc((void **)&r.d_ck, std::max<u64>(r.n, 1) * W * 8), "hipMalloc") && hip_ok(hipMalloc((void **)&r.d_cc, std::max<u64>(r.n, 1) * 4), "hipMalloc");
-			const u64 B = u64(1) << 23;
-			mark(d, "  device buffers");
-			if (ok) ok = hip_ok(hipHostMalloc((void **)&r.h_raw, std::min<u64>(B, std::max<u64>(r.n, 1)) * rb + 16), "hipHostMalloc") && hip_ok(hipMalloc((void **)&r.d_raw, std::min<u64>(B, std::max<u64>(r.n, 1)) * rb + 16), "hipMalloc");
-			mark(d, "  pinned slot");
+			          (!by_range || hip_ok(hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking), "stream"));
+			if (ok && !feed_alloc(m, (size_t)B, rb, W, db.lut())) { fail(KMX_E_NOMEM, "pinned / device buffers for the listing feed could not be allocated"); note(KMX_E_NOMEM); ok = false; }
+			if (ok) ok = hip_ok(hipMalloc((void **)&r.d_km, std::max<u64>(r.n, 1) * W * 8), "hipMalloc") && hip_ok(hipMalloc((void **)&r.d_cnt, std::max<u64>(r.n, 1) * 4), "hipMalloc") &&
+			             hip_ok(hipMalloc((void **)&r.d_ck, std::max<u64>(r.n, 1) * W * 8), "hipMalloc") && hip_ok(hipMalloc((void **)&r.d_cc, std::max<u64>(r.n, 1) * 4), "hipMalloc");
+			mark(d, "  buffers");
 			KmcDecode kd;
-			kd.lut = r.d_lut; kd.n_lut = lut.size() - 1; kd.prefix_mask = db.prefix_mask();
+			kd.lut = F.d_lut; kd.n_lut = db.lut().size() - 1; kd.prefix_mask = db.prefix_mask();
 			kd.rec_bytes = (u32)rb; kd.suf_bytes = db.suffix_bytes(); kd.cnt_bytes = db.counter_bytes();
-			for (u64 done = 0; ok && done < r.n; done += B) {
+			if (ok) ok = hip_ok(hipEventRecord(F.ev_free[0], st), "event") && hip_ok(hipEventRecord(F.ev_free[1], st), "event") &&
+			             hip_ok(hipEventRecord(F.ev_copied[0], F.copy), "event") && hip_ok(hipEventRecord(F.ev_copied[1], F.copy), "event");
+			int s2 = 0;
+			for (u64 done = 0; ok && done < r.n; done += B, s2 ^= 1) {
 				const u64 c = std::min<u64>(B, r.n - done);
-				db.copy_records(r.rec_lo + done, c, r.h_raw);
-				ok = hip_ok(hipMemcpyAsync(r.d_raw, r.h_raw, c * rb, hipMemcpyHostToDevice, st), "H2D copy");
-				kd.recs = r.d_raw;
+				ok = hip_ok(hipEventSynchronize(F.ev_copied[s2]), "copy");        // the pinned slot has been read (two batches ago)
+				if (!ok) break;
+				db.copy_records(r.rec_lo + done, c, F.raw[s2]);
+				ok = hip_ok(hipStreamWaitEvent(F.copy, F.ev_free[s2], 0), "wait") &&            // the decode that read the device slot two batches ago
+				     hip_ok(hipMemcpyAsync(F.draw[s2], F.raw[s2], c * rb, hipMemcpyHostToDevice, F.copy), "H2D copy") &&
+				     hip_ok(hipEventRecord(F.ev_copied[s2], F.copy), "event") && hip_ok(hipStreamWaitEvent(st, F.ev_copied[s2], 0), "wait");
+				if (!ok) break;
+				kd.recs = F.draw[s2];
 				kmxk::kmc_decode(kd, W, r.rec_lo + done, c, r.d_km + done * W, r.d_cnt + done, st);
-				if (ok) ok = hip_ok(hipStreamSynchronize(st), "decode");          // the pinned slot is reused
+				ok = hip_ok(hipEventRecord(F.ev_free[s2], st), "event");
 			}
 			if (ok && db.io_failed()) { fail(KMX_E_IO, "reading %s.kmc_suf failed", db_prefix); note(KMX_E_IO); ok = false; }
-			mark(d, "  slice decoded");
-			if (ok) note(kmx_count_classes_dev_impl(m, r.d_cnt, r.n, r.nbf));      // kmodel.hpp:423-428 on the slice
-			mark(d, "  pass 1 on the slice");
+			mark(d, "  slice read and enqueued");
 		}
-		bar.wait();
-		if (d == 0) for (int q = 0; q < P; q++) for (int c = 0; c < 3; c++) nbf_all[c] += R[(size_t)q].nbf[c];
-		bar.wait();
 		// ---- sizes from the whole database (kmodel.hpp:402-456), front end on the slice (partial Bloom filters), the coupled class in order
 		if (!err) note(by_range ? range_begin_common(m, k, nbf_all, db.kmer_count(), d, P, true) : kmx_shard_begin_impl(m, k, nbf_all, db.kmer_count(), d, P));
 		if (!err) { uint64_t nc = 0; if (!note(kmx_shard_classify_dev_impl(m, (const uint64_t *)r.d_km, r.d_cnt, r.n, (uint64_t *)r.d_ck, r.d_cc, &nc))) r.n_c = nc; }
@@ -2160,8 +2172,7 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 		bar.wait();                                                         // nobody frees what a peer may still be reading
 		mark(d, "merged and complete");
 		hipFree(r.d_km); hipFree(r.d_cnt); hipFree(r.d_ck); hipFree(r.d_cc); hipFree(r.d_rk); hipFree(r.d_rc); hipFree(r.d_allk); hipFree(r.d_allc);
-		hipFree(r.d_lut); hipFree(r.d_raw); hipFree(r.d_tmp);
-		if (r.h_raw) hipHostFree(r.h_raw);
+		hipFree(r.d_tmp);
 		for (u64 *p : r.msg) hipFree(p);
 		if (r.ev_round) hipEventDestroy(r.ev_round);
 		if (r.ev_copied) hipEventDestroy(r.ev_copied);
