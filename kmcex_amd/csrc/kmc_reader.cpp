@@ -23,6 +23,16 @@ bool read_file(const std::string &path, std::vector<unsigned char> &out)
 	fclose(f);
 	return got == out.size();
 }
+bool pread_fully(int fd, void *dst, size_t bytes, uint64_t off)
+{
+	unsigned char *d = (unsigned char *)dst;
+	while (bytes) {
+		const ssize_t got = ::pread(fd, d, bytes, (off_t)off);
+		if (got <= 0) return false;
+		d += got; off += (uint64_t)got; bytes -= (size_t)got;
+	}
+	return true;
+}
 template <typename T> T rd(const unsigned char *p)
 {
 	T v;
@@ -33,20 +43,12 @@ template <typename T> T rd(const unsigned char *p)
 
 // the prefix file is read where it is needed: markers, the tail, the header -- and the LUT(s) straight into lut_ with parallel
 // preads (a KMC2 database with 512 bins has 67 MB of them: through a buffer of the whole file and a copy that is 60 ms)
-bool KmcListing::open(const std::string &prefix)
+bool KmcListing::open(const std::string &prefix, bool load_lut)
 {
 	close();
 	const int pfd = ::open((prefix + ".kmc_pre").c_str(), O_RDONLY);
 	struct stat psb;
-	auto pread_all = [&](void *dst, size_t bytes, uint64_t off) {
-		unsigned char *d = (unsigned char *)dst;
-		while (bytes) {
-			const ssize_t got = ::pread(pfd, d, bytes, (off_t)off);
-			if (got <= 0) return false;
-			d += got; off += (uint64_t)got; bytes -= (size_t)got;
-		}
-		return true;
-	};
+	auto pread_all = [&](void *dst, size_t bytes, uint64_t off) { return pread_fully(pfd, dst, bytes, off); };
 	unsigned char head[4], tail[12];
 	if (pfd < 0 || fstat(pfd, &psb) != 0 || (size_t)psb.st_size < 4 + 4 + 12 || !pread_all(head, 4, 0) || !pread_all(tail, 12, (uint64_t)psb.st_size - 12) ||
 	    memcmp(head, "KMCP", 4) || memcmp(tail + 8, "KMCP", 4)) {
@@ -54,7 +56,7 @@ bool KmcListing::open(const std::string &prefix)
 		err_ = "cannot open " + prefix + ".kmc_pre (missing or no KMCP markers)";
 		return false;
 	}
-	struct Closer { int fd; ~Closer() { ::close(fd); } } closer{pfd};
+	pre_fd_ = pfd;                                                  // (closed by close(): the LUT may be read later, into the caller's memory)
 	const size_t end = (size_t)psb.st_size;
 	// the last 8 + header_offset bytes: header, offset field, marker (header_offset is one byte: at most 255)
 	std::vector<unsigned char> pre_tail(std::min<size_t>(end, 8 + 255 + 4));
@@ -102,22 +104,8 @@ bool KmcListing::open(const std::string &prefix)
 	}
 	const size_t n_lut = lut_bytes / 8;
 	if (n_lut == 0 || 4 + n_lut * 8 > end) { err_ = "corrupt KMC LUT"; return false; }
-	lut_.resize(n_lut + 1);
-	{
-		const size_t bytes = n_lut * 8;
-		const int T = (int)std::max<size_t>(1, std::min<size_t>(8, bytes / (4u << 20) + 1));
-		std::atomic<bool> bad{false};
-		auto part = [&](int t) {
-			const size_t per = ((bytes + T - 1) / T + 4095) & ~size_t(4095), lo = (size_t)t * per, hi = std::min(bytes, lo + per);
-			if (lo < hi && !pread_all((unsigned char *)lut_.data() + lo, hi - lo, 4 + lo)) bad = true;
-		};
-		std::vector<std::thread> th;
-		for (int t = 1; t < T; t++) th.emplace_back(part, t);
-		part(0);
-		for (auto &x : th) x.join();
-		if (bad) { err_ = "cannot read the LUT of " + prefix + ".kmc_pre"; lut_.clear(); return false; }
-	}
-	lut_[n_lut] = total_;
+	n_lut_ = n_lut;
+	if (load_lut && !lut_loaded()) { err_ = "cannot read the LUT of " + prefix + ".kmc_pre"; return false; }
 	prefix_mask_ = (uint64_t(1) << (2 * p_)) - 1;
 	suf_bytes_ = (k_ - p_) / 4;
 	rec_bytes_ = suf_bytes_ + counter_size_;
@@ -140,9 +128,41 @@ bool KmcListing::open(const std::string &prefix)
 	return true;
 }
 
+// n_lut_ LUT entries + the sentinel (= total) -> dst, with parallel preads
+bool KmcListing::read_lut(uint64_t *dst) const
+{
+	if (pre_fd_ < 0 || !n_lut_) return false;
+	const size_t bytes = n_lut_ * 8;
+	const int T = (int)std::max<size_t>(1, std::min<size_t>(8, bytes / (4u << 20) + 1));
+	std::atomic<bool> bad{false};
+	auto part = [&](int t) {
+		const size_t per = ((bytes + T - 1) / T + 4095) & ~size_t(4095), lo = (size_t)t * per, hi = std::min(bytes, lo + per);
+		if (lo < hi && !pread_fully(pre_fd_, (unsigned char *)dst + lo, hi - lo, 4 + lo)) bad = true;
+	};
+	std::vector<std::thread> th;
+	for (int t = 1; t < T; t++) th.emplace_back(part, t);
+	part(0);
+	for (auto &x : th) x.join();
+	dst[n_lut_] = total_;
+	return !bad;
+}
+// the host copy of the LUT (the host decoder, the tests): loaded on first use
+bool KmcListing::lut_loaded() const
+{
+	if (lut_.size() == n_lut_ + 1) return true;
+	lut_.resize(n_lut_ + 1);
+	if (read_lut(lut_.data())) return true;
+	lut_.clear();
+	io_failed_.store(true, std::memory_order_relaxed);
+	return false;
+}
+
 void KmcListing::close()
 {
 	if (fd_ >= 0) ::close(fd_);
+	if (pre_fd_ >= 0) ::close(pre_fd_);
+	pre_fd_ = -1;
+	n_lut_ = 0;
 	fd_ = -1;
 	file_len_ = 0;
 	lut_.clear();
@@ -168,6 +188,7 @@ void KmcListing::restart() { rec_ = 0; }
 size_t KmcListing::decode_range(const unsigned char *recs, uint64_t rec0, size_t n_recs, uint64_t *kmers, uint32_t *counts) const
 {
 	const int W = words();
+	if (!lut_loaded()) return 0;                                    // (io_failed() is set)
 	const size_t n_lut = lut_.size() - 1;
 	// last LUT entry <= rec0 that is followed by a larger one
 	size_t idx = (size_t)(std::upper_bound(lut_.begin(), lut_.begin() + n_lut, rec0) - lut_.begin());
@@ -217,6 +238,7 @@ size_t KmcListing::decode_range(const unsigned char *recs, uint64_t rec0, size_t
 size_t KmcListing::next_batch(uint64_t *kmers, uint32_t *counts, size_t max_n)
 {
 	if (fd_ < 0 || rec_ >= avail_ || !max_n) return 0;
+	if (!lut_loaded()) return 0;                                    // (before the decode threads start: the load is not theirs to race for)
 	const int W = words();
 	const size_t got = (size_t)std::min<uint64_t>(max_n, avail_ - rec_);
 	stage_.resize(got * rec_bytes_ + 16);                            // the decoders' 8-byte loads may reach past the last field

@@ -28,7 +28,9 @@ class KmcListing {
 public:
 	~KmcListing() { close(); }
 	// false + error() on failure.  Supports KMC1 (version 0) and KMC2 (0x200) prefix files, mode 0 counters.
-	bool open(const std::string &prefix);
+	// load_lut = false: the LUT(s) stay in the file until lut() or read_lut() asks for them (the GPU decoder wants them in ITS
+	// pinned memory: a KMC2 database with 512 bins has 67 MB of them, and a fresh host copy costs its page faults twice)
+	bool open(const std::string &prefix, bool load_lut = true);
 	void close();
 	void restart();                                  // RestartListing
 	uint32_t kmer_length() const { return k_; }
@@ -57,7 +59,9 @@ public:
 	uint32_t suffix_bytes() const { return suf_bytes_; }
 	uint32_t counter_bytes() const { return counter_size_; }
 	uint64_t prefix_mask() const { return prefix_mask_; }
-	const LutVec &lut() const { return lut_; }
+	const LutVec &lut() const { lut_loaded(); return lut_; }     // host copy, loaded on first use (empty + io_failed() if that fails)
+	size_t lut_entries() const { return n_lut_ ? n_lut_ + 1 : 0; }   // with the sentinel
+	bool read_lut(uint64_t *dst) const;                          // lut_entries() words straight from the file (parallel preads)
 	void copy_records(uint64_t rec0, uint64_t n, unsigned char *dst) const;
 
 private:
@@ -70,7 +74,10 @@ private:
 	bool read_at(uint64_t off, void *dst, size_t bytes) const;
 	mutable std::atomic<bool> io_failed_{false};
 	std::vector<unsigned char> stage_;       // raw bytes of the batch next_batch is decoding (host decoder only)
-	LutVec lut_;                     // concatenated LUT(s); lut_[size] sentinel = total
+	mutable LutVec lut_;             // concatenated LUT(s); lut_[size] sentinel = total
+	bool lut_loaded() const;
+	int pre_fd_ = -1;
+	size_t n_lut_ = 0;
 	uint64_t rec_ = 0, avail_ = 0, total_ = 0, max_count_ = 0, prefix_mask_ = 0;
 	uint32_t k_ = 0, mode_ = 0, counter_size_ = 0, p_ = 0, min_count_ = 0, version_ = 0;
 	uint32_t suf_bytes_ = 0, rec_bytes_ = 0;

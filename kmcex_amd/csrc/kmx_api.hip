@@ -246,7 +246,7 @@ struct kmx_model {
 	// freeing ~300 MB of pinned + device memory costs ~30 ms per call on this stack)
 	struct KmcFeed {
 		unsigned char *raw[2] = {nullptr, nullptr}, *draw[2] = {nullptr, nullptr};
-		u64 *km[2] = {nullptr, nullptr}, *dk[2] = {nullptr, nullptr}, *d_lut = nullptr;
+		u64 *km[2] = {nullptr, nullptr}, *dk[2] = {nullptr, nullptr}, *d_lut = nullptr, *h_lut = nullptr;   // h_lut: pinned
 		u32 *cnt[2] = {nullptr, nullptr}, *dc[2] = {nullptr, nullptr};
 		size_t raw_cap = 0, km_cap = 0, dk_cap = 0, lut_cap = 0;   // bytes / bytes / k-mer words / entries
 		hipStream_t copy = nullptr;
@@ -491,6 +491,8 @@ static void free_feed(kmx_model *m)
 		f.ev_copied[s] = f.ev_free[s] = nullptr;
 	}
 	hipFree(f.d_lut); f.d_lut = nullptr;
+	if (f.h_lut) hipHostFree(f.h_lut);
+	f.h_lut = nullptr;
 	f.raw_cap = f.km_cap = f.dk_cap = f.lut_cap = 0;
 }
 
@@ -1426,7 +1428,7 @@ struct FeedSlot {
 
 // the feed of KModel::init(db) on the handle: two pinned slots of B raw records + their device twins, decoded k-mers / counts
 // of a batch, a copy stream, events, the prefix LUT on the device -- kept across calls (kmx_model::KmcFeed)
-static bool feed_alloc(kmx_model *m, size_t B, size_t rb, int W, const kmx::LutVec &lut)
+static bool feed_alloc(kmx_model *m, size_t B, size_t rb, int W, const kmx::KmcListing &db)
 {
 	auto &F = m->feed;
 	if (hipSetDevice(m->device) != hipSuccess) return false;
@@ -1446,12 +1448,16 @@ static bool feed_alloc(kmx_model *m, size_t B, size_t rb, int W, const kmx::LutV
 		}
 	}
 	if (good) { F.raw_cap = std::max(F.raw_cap, B * rb + 16); F.dk_cap = std::max(F.dk_cap, B * (size_t)W); }
-	if (good && F.lut_cap < lut.size()) {
+	// the prefix LUT(s): file -> the handle's pinned buffer (parallel preads into memory that is resident already) -> device
+	const size_t n_lut = db.lut_entries();
+	if (good && F.lut_cap < n_lut) {
 		hipFree(F.d_lut); F.d_lut = nullptr;
-		good = hipMalloc((void **)&F.d_lut, lut.size() * 8) == hipSuccess;
-		if (good) F.lut_cap = lut.size();
+		if (F.h_lut) hipHostFree(F.h_lut);
+		F.h_lut = nullptr;
+		good = hipMalloc((void **)&F.d_lut, n_lut * 8) == hipSuccess && hipHostMalloc((void **)&F.h_lut, n_lut * 8) == hipSuccess;
+		F.lut_cap = good ? n_lut : 0;
 	}
-	if (good) good = hipMemcpy(F.d_lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+	if (good) good = n_lut && db.read_lut((uint64_t *)F.h_lut) && hipMemcpy(F.d_lut, F.h_lut, n_lut * 8, hipMemcpyHostToDevice) == hipSuccess;
 	if (!good) F.raw_cap = F.dk_cap = 0;                         // whatever is half there is replaced next time
 	return good;
 }
@@ -1464,7 +1470,7 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 	const auto t_start = std::chrono::steady_clock::now();
 	auto lap = [&](const char *what) { if (trace) fprintf(stderr, "[kmx] init(db) %-28s at %7.2f ms\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() * 1e3); };
 	kmx::KmcListing db;
-	if (!db.open(db_prefix)) return fail(KMX_E_IO, "can't open the kmer_data_base %s: %s", db_prefix, db.error().c_str());
+	if (!db.open(db_prefix, false)) return fail(KMX_E_IO, "can't open the kmer_data_base %s: %s", db_prefix, db.error().c_str());
 	unsigned hw = std::thread::hardware_concurrency();
 	const int T = hw > 32 ? 16 : (hw > 1 ? (int)hw / 2 : 1);          // per activity: pass 1 and the producer run side by side
 	db.set_threads(T);
@@ -1494,7 +1500,7 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 	// the buffers of pass 2 are (re)allocated beside pass 1 when this database needs larger ones than the handle holds
 	bool ok = false;
 	allocator = std::thread([&] {
-		const bool good = feed_alloc(m, B, rb, W, db.lut());
+		const bool good = feed_alloc(m, B, rb, W, db);
 		{ std::lock_guard<std::mutex> lk(mu); ok = good; alloc_done = true; }
 		cv.notify_all();
 	});
@@ -1567,7 +1573,7 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 	double s_wait = 0;
 	if (!rc) {
 		KmcDecode kd;
-		kd.lut = F.d_lut; kd.n_lut = db.lut().size() - 1; kd.prefix_mask = db.prefix_mask();
+		kd.lut = F.d_lut; kd.n_lut = db.lut_entries() - 1; kd.prefix_mask = db.prefix_mask();
 		kd.rec_bytes = (u32)rb; kd.suf_bytes = db.suffix_bytes(); kd.cnt_bytes = db.counter_bytes();
 		// pass 2 (kmodel.hpp:68-74).  Batch b travels through slot b%2 and device buffers b%2; its copy is enqueued one
 		// batch ahead of its insert, so it runs under the rounds of batch b-1.
@@ -1851,7 +1857,7 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 	}
 	if (P == 1 && !by_range) return kmx_build_from_kmc_impl(hs[0], db_prefix);      // (one handle, by range: the partition's kernels alone, every word "sent" to itself)
 	kmx::KmcListing db;
-	if (!db.open(db_prefix)) return fail(KMX_E_IO, "can't open the kmer_data_base %s: %s", db_prefix, db.error().c_str());
+	if (!db.open(db_prefix, false)) return fail(KMX_E_IO, "can't open the kmer_data_base %s: %s", db_prefix, db.error().c_str());
 	const int k = (int)db.kmer_length(), W = db.words(), nb = hs[0]->nb;
 	const u64 N = db.records();
 	const size_t rb = db.record_bytes();
@@ -1915,12 +1921,12 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 			          hip_ok(hipEventCreateWithFlags(&r.ev[0], hipEventDisableTiming), "event") && hip_ok(hipEventCreateWithFlags(&r.ev[1], hipEventDisableTiming), "event") &&
 			          hip_ok(hipEventCreateWithFlags(&r.ev[2], hipEventDisableTiming), "event") && hip_ok(hipEventCreateWithFlags(&r.ev[3], hipEventDisableTiming), "event") &&
 			          (!by_range || hip_ok(hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking), "stream"));
-			if (ok && !feed_alloc(m, (size_t)B, rb, W, db.lut())) { fail(KMX_E_NOMEM, "pinned / device buffers for the listing feed could not be allocated"); note(KMX_E_NOMEM); ok = false; }
+			if (ok && !feed_alloc(m, (size_t)B, rb, W, db)) { fail(KMX_E_NOMEM, "pinned / device buffers for the listing feed could not be allocated"); note(KMX_E_NOMEM); ok = false; }
 			if (ok) ok = hip_ok(hipMalloc((void **)&r.d_km, std::max<u64>(r.n, 1) * W * 8), "hipMalloc") && hip_ok(hipMalloc((void **)&r.d_cnt, std::max<u64>(r.n, 1) * 4), "hipMalloc") &&
 			             hip_ok(hipMalloc((void **)&r.d_ck, std::max<u64>(r.n, 1) * W * 8), "hipMalloc") && hip_ok(hipMalloc((void **)&r.d_cc, std::max<u64>(r.n, 1) * 4), "hipMalloc");
 			mark(d, "  buffers");
 			KmcDecode kd;
-			kd.lut = F.d_lut; kd.n_lut = db.lut().size() - 1; kd.prefix_mask = db.prefix_mask();
+			kd.lut = F.d_lut; kd.n_lut = db.lut_entries() - 1; kd.prefix_mask = db.prefix_mask();
 			kd.rec_bytes = (u32)rb; kd.suf_bytes = db.suffix_bytes(); kd.cnt_bytes = db.counter_bytes();
 			if (ok) ok = hip_ok(hipEventRecord(F.ev_free[0], st), "event") && hip_ok(hipEventRecord(F.ev_free[1], st), "event") &&
 			             hip_ok(hipEventRecord(F.ev_copied[0], F.copy), "event") && hip_ok(hipEventRecord(F.ev_copied[1], F.copy), "event");
