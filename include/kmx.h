@@ -168,6 +168,17 @@ int kmx_range_verdict_dev(kmx_model *m, int t, const uint64_t *d_words, const ui
  * ones decided in list order); their commits go to the front of the regions for the next emit; reorder_buffer (:529-540),
  * km_back, rest.  Nothing is exchanged now, and no host wait is spent                                                   */
 int kmx_range_resolve_dev(kmx_model *m, int t, const uint8_t *d_verdict);
+/* FIXED-SIZE MESSAGES (no count on the host, two equal-split all-to-alls per round).  Call between kmx_range_begin and the first
+ * emit: every region becomes [header: commits, triples, 0, 0 as uint32 | capx_words 64-bit words], region_words = 2 + capx apart
+ * in *d_send -- capx = the mean of a round's fullest exchange + 25 % + 8192 words, far beyond what uniformly hashed positions
+ * deviate.  Then kmx_range_emit_dev / kmx_range_flush_dev take counts = NULL and do not wait; the owner reads what arrived -- the
+ * world regions of its senders, same layout -- with kmx_range_verdict_inband_dev (verdict byte of word j of region s at
+ * d_verdict[s * capx + j]) and kmx_range_commit_inband_dev; kmx_range_resolve_dev takes the bytes that came back, capx per
+ * destination.  A word that does not fit its region is DROPPED and the build is void: kmx_shard_local reports it in
+ * kmx_stats.reserved (non-zero), and the caller repeats the build with counted messages (kmcex_amd/dist.py does).           */
+int kmx_range_inband(kmx_model *m, void **d_send, uint64_t *region_words, uint64_t *capx_words);
+int kmx_range_verdict_inband_dev(kmx_model *m, int t, const uint64_t *d_recv, int n_src, uint8_t *d_verdict);
+int kmx_range_commit_inband_dev(kmx_model *m, const uint64_t *d_recv, int n_src);
 /* end of the build: what is still pending in front of the regions (counts[q] = counts[world + q] = commit words) for a last exchange ... */
 int kmx_range_flush_dev(kmx_model *m, uint64_t *counts /* [2 world] */);
 /* ... and its application on the owner                                                                                  */

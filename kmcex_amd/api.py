@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "kmx_count_classes_dev", "kmx_shard_begin", "kmx_shard_classify_dev", "kmx_ring_msg_bytes", "kmx_ring_round_dev",
     "kmx_ring_stale_dup_dev", "kmx_shard_local", "kmx_shard_complete", "kmx_dev_view", "kmx_or_words_dev",
     "kmx_debug_pack_strings", "kmx_kernel_classes", "kmx_abi_version", "kmx_get_stats_n",
-    "kmx_create_on", "kmx_build_from_kmc_multi", "kmx_build_from_kmc_multi_ex", "kmx_range_begin", "kmx_range_buffers", "kmx_range_emit_dev", "kmx_range_verdict_dev", "kmx_range_resolve_dev", "kmx_range_commit_dev", "kmx_range_flush_dev",
+    "kmx_create_on", "kmx_build_from_kmc_multi", "kmx_build_from_kmc_multi_ex", "kmx_range_begin", "kmx_range_buffers", "kmx_range_emit_dev", "kmx_range_verdict_dev", "kmx_range_resolve_dev", "kmx_range_commit_dev", "kmx_range_flush_dev", "kmx_range_inband", "kmx_range_verdict_inband_dev", "kmx_range_commit_inband_dev",
 ]
 
 
@@ -140,6 +140,9 @@ def load_library():
     _sig(L, "kmx_range_resolve_dev", [vp, i32, vp])
     _sig(L, "kmx_range_commit_dev", [vp, vp, u64])
     _sig(L, "kmx_range_flush_dev", [vp, C.POINTER(u64)])
+    _sig(L, "kmx_range_inband", [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)])
+    _sig(L, "kmx_range_verdict_inband_dev", [vp, i32, vp, i32, vp])
+    _sig(L, "kmx_range_commit_inband_dev", [vp, vp, i32])
     L.kmx_or_words_dev.argtypes = [vp, vp, vp, u64]
     _sig(L, "kmx_debug_pack_strings", [vp, vp, i32, i32, u64, vp, C.POINTER(i32)])
     _sig(L, "kmx_kernel_classes", [])
@@ -347,6 +350,27 @@ class KModel:
         counts = (C.c_uint64 * (2 * w))()
         _chk(self.L.kmx_range_emit_dev(self.h, t, arr, len(lists), counts))
         return [int(x) for x in counts[:w]], [int(x) for x in counts[w:]]
+
+    def range_inband(self):
+        """fixed-size messages: -> (device pointer of the regions, 64-bit words per region incl. its header, capx)"""
+        p, rw, cx = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        _chk(self.L.kmx_range_inband(self.h, C.byref(p), C.byref(rw), C.byref(cx)))
+        return p.value or 0, int(rw.value), int(cx.value)
+
+    def range_emit_nowait_dev(self, t: int, lists) -> None:
+        arr = (RingList * max(len(lists), 1))()
+        for j, (i, n, pk, pc) in enumerate(lists):
+            arr[j] = RingList(i, n, pk or None, pc or None, None, None)
+        _chk(self.L.kmx_range_emit_dev(self.h, t, arr, len(lists), None))
+
+    def range_flush_nowait_dev(self) -> None:
+        _chk(self.L.kmx_range_flush_dev(self.h, None))
+
+    def range_verdict_inband_dev(self, t: int, d_recv_ptr: int, n_src: int, d_verdict_ptr: int) -> None:
+        _chk(self.L.kmx_range_verdict_inband_dev(self.h, t, d_recv_ptr, n_src, d_verdict_ptr))
+
+    def range_commit_inband_dev(self, d_recv_ptr: int, n_src: int) -> None:
+        _chk(self.L.kmx_range_commit_inband_dev(self.h, d_recv_ptr, n_src))
 
     def range_verdict_dev(self, t: int, d_words_ptr: int, totals, commits, d_verdict_ptr: int) -> None:
         n = len(totals)

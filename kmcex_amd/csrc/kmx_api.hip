@@ -279,6 +279,9 @@ struct kmx_model {
 		u64 *d_send = nullptr;
 		u32 *d_hdr = nullptr, *h_hdr = nullptr;                    // [KMX_MAX_RANKS][2]; h_: pinned copy
 		u64 sent_tot[KMX_MAX_RANKS] = {};                          // words per destination of the last emit (where each region's verdicts start in what comes back)
+		bool inband = false;                                       // the regions travel as fixed-size messages [header | capx words] (kmx_range_inband)
+		u64 capx = 0, cap_full = 0;                                // words per region shipped / the worst case of a round
+		int *d_ovf = nullptr;                                      // raised by a launch that had to drop a word (fixed-size messages only)
 		// mailbox transport: what the other ranks write into (through peer mappings when they sit on other devices)
 		u64 *d_inbox = nullptr;                                    // [world][cap] region of sender s
 		u32 *d_in_hdr = nullptr;                                   // [world][2]
@@ -501,7 +504,7 @@ static void free_range(kmx_model *m)
 	auto &R = m->range;
 	hipFree(R.d_send); hipFree(R.d_hdr); hipFree(R.rd.ccnt); hipFree(R.rd.tcnt); hipFree(R.rd.tidx); hipFree(R.rd.contended); hipFree(R.rd.n_contended);
 	hipFree(R.rd.rt_key); hipFree(R.rd.rt_resv); hipFree(R.rd.rt_mark); hipFree(R.rd.rt_eidx); hipFree(R.rd.rt_um);
-	hipFree(R.d_oovf); hipFree(R.d_opcnt); hipFree(R.d_lver); hipFree(R.d_inbox); hipFree(R.d_in_hdr); hipFree(R.d_vbox);
+	hipFree(R.d_oovf); hipFree(R.d_opcnt); hipFree(R.d_lver); hipFree(R.d_inbox); hipFree(R.d_in_hdr); hipFree(R.d_vbox); hipFree(R.d_ovf);
 	if (R.h_hdr) hipHostFree(R.h_hdr);
 	R = kmx_model::RangeState();
 }
@@ -1305,8 +1308,10 @@ static int kmx_finish_impl(kmx_model *m)
 	TRY(flush_pending_commit(m));
 	TRY(kmback_flush(m));
 	unsigned long long n_rest = 0;
+	int range_ovf = 0;
 	HIPCHK(hipMemcpyAsync(m->h_stats, m->d_stats, ST_N * 8, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipMemcpyAsync(&n_rest, m->d_rest_n, 8, hipMemcpyDeviceToHost, m->stream));
+	if (m->range.on && m->range.d_ovf) HIPCHK(hipMemcpyAsync(&range_ovf, m->range.d_ovf, sizeof(int), hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipStreamSynchronize(m->stream));
 	if (m->h_stats[ST_BAD_COUNT]) {
 		m->state = ST_EMPTY;
@@ -1764,8 +1769,10 @@ static int kmx_shard_local_impl(kmx_model *m, kmx_stats *partial, void **d_rest_
 	TRY(flush_pending_commit(m));                                 // the arrays are about to be read by the caller's broadcasts
 	TRY(kmback_flush(m));
 	unsigned long long n_rest = 0;
+	int range_ovf = 0;
 	HIPCHK(hipMemcpyAsync(m->h_stats, m->d_stats, ST_N * 8, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipMemcpyAsync(&n_rest, m->d_rest_n, 8, hipMemcpyDeviceToHost, m->stream));
+	if (m->range.on && m->range.d_ovf) HIPCHK(hipMemcpyAsync(&range_ovf, m->range.d_ovf, sizeof(int), hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipStreamSynchronize(m->stream));
 	if (m->h_stats[ST_BAD_COUNT]) return fail(KMX_E_RANGE, "%llu k-mers with a count outside [ci=%d, cs=%d]", (unsigned long long)m->h_stats[ST_BAD_COUNT], m->ci, m->cs);
 	if (m->prof.on) prof_collect(m);
@@ -1774,6 +1781,7 @@ static int kmx_shard_local_impl(kmx_model *m, kmx_stats *partial, void **d_rest_
 	partial->fast_commits = m->h_stats[ST_SUCCESSES] - m->h_stats[ST_SLOW_SUCC];
 	partial->contended = m->h_stats[ST_CONTENDED]; partial->finisher_iters = m->h_stats[ST_FIN_ITERS];
 	partial->rest_entries = n_rest; partial->blocks = m->blocks; partial->rounds = m->rounds;
+	partial->reserved = range_ovf;                                // a fixed-size region of the range partition dropped words: this build is void
 	if (d_rest_kmers) *d_rest_kmers = m->d_rest_kmers;
 	if (d_rest_counts) *d_rest_counts = m->d_rest_counts;
 	return KMX_OK;
@@ -2263,9 +2271,15 @@ static int range_begin_common(kmx_model *m, int k, const uint64_t n_bf[3], uint6
 		TRY(dalloc(&R.d_oovf, (u64)KMX_MAX_NB, true, m->stream));
 		TRY(dalloc(&R.d_opcnt, (u64)KMX_MAX_NB * KMX_CL_MAXBINS * KMX_CTR_STRIDE, true, m->stream));
 		TRY(dalloc(&R.d_lver, slots * nh, false, m->stream));        // every triple of a round may come to one owner
+		TRY(dalloc(&R.d_ovf, (u64)KMX_CTR_STRIDE, true, m->stream));
+		R.cap_full = R.rd.cap;
 		R.alloc_key = key;
 	}
 	R.mailbox = mailbox;
+	R.inband = false;
+	R.rd.cap = R.cap_full;
+	R.rd.ovf = R.d_ovf;
+	HIPCHK(hipMemsetAsync(R.d_ovf, 0, sizeof(int), m->stream));
 	HIPCHK(hipMemsetAsync(R.d_oovf, 0, sizeof(int) * KMX_MAX_NB, m->stream));
 	HIPCHK(hipMemsetAsync(R.rd.n_contended, 0, sizeof(int) * KMX_MAX_NB * KMX_CTR_STRIDE, m->stream));   // (k_range_resolve leaves them zero round by round)
 	HIPCHK(hipMemsetAsync(R.d_opcnt, 0, sizeof(int) * (u64)KMX_MAX_NB * KMX_CL_MAXBINS * KMX_CTR_STRIDE, m->stream));
@@ -2399,6 +2413,8 @@ static int range_link(kmx_model **hs, int P, int d)
 		R.in.vout[q] = hs[q]->range.d_vbox + (u64)d * R.rd.cap;          // its verdicts into sender q's box
 	}
 	R.in.hdr = R.d_in_hdr;
+	R.in.hdr_stride = KMX_RANGE_HDR;
+	R.in.cap = 0;
 	R.in.world = P;
 	return KMX_OK;
 }
@@ -2407,7 +2423,10 @@ static int range_link(kmx_model **hs, int P, int d)
 static int range_read_headers(kmx_model *m, uint64_t *counts)
 {
 	auto &R = m->range;
-	HIPCHK(hipMemcpyAsync(R.h_hdr, R.d_hdr, sizeof(u32) * KMX_MAX_RANKS * KMX_RANGE_HDR, hipMemcpyDeviceToHost, m->stream));
+	if (R.inband) {
+		const u64 stride = KMX_RANGE_HDR / 2 + R.capx;
+		for (int q = 0; q < R.plan.world; q++) HIPCHK(hipMemcpyAsync(R.h_hdr + KMX_RANGE_HDR * q, R.d_send + (u64)q * stride, sizeof(u32) * KMX_RANGE_HDR, hipMemcpyDeviceToHost, m->stream));
+	} else HIPCHK(hipMemcpyAsync(R.h_hdr, R.d_hdr, sizeof(u32) * KMX_MAX_RANKS * KMX_RANGE_HDR, hipMemcpyDeviceToHost, m->stream));
 	HIPCHK(hipStreamSynchronize(m->stream));
 	for (int q = 0; q < R.plan.world; q++) {
 		counts[q] = (uint64_t)R.h_hdr[KMX_RANGE_HDR * q] + (uint64_t)R.h_hdr[KMX_RANGE_HDR * q + 1];
@@ -2425,12 +2444,12 @@ static int kmx_range_emit_dev_impl(kmx_model *m, int t, const kmx_ring_list *lis
 {
 	TRY(range_check(m, t));
 	TRY(range_caller_moved(m));
-	if (!counts || (n_lists && !lists)) return fail(KMX_E_ARG, "null argument");
 	auto &R = m->range;
-	for (int q = 0; q < 2 * R.plan.world; q++) counts[q] = 0;
+	if ((!counts && !R.inband) || (n_lists && !lists)) return fail(KMX_E_ARG, "null argument");
+	for (int q = 0; counts && q < 2 * R.plan.world; q++) counts[q] = 0;
 	if (m->km_byte_size == 0) return KMX_OK;                       // divergence D2: no arrays to insert into
 	TRY(range_list_emit(m, t, lists, n_lists));
-	return range_read_headers(m, counts);
+	return counts ? range_read_headers(m, counts) : KMX_OK;         // (fixed-size messages carry their counts: no host wait)
 }
 
 static int kmx_range_buffers_impl(kmx_model *m, void **d_send, uint64_t *cap_words, uint64_t *cell_lo)
@@ -2459,6 +2478,76 @@ static int range_in_of(kmx_model *m, const uint64_t *d_words, const uint64_t *to
 	in.world = n_src;
 	return KMX_OK;
 }
+// ... as fixed-size messages: region s = [header (KMX_RANGE_HDR u32) | capx words], the verdict bytes capx apart
+static int range_in_inband(kmx_model *m, const uint64_t *d_recv, int n_src, uint8_t *d_verdict, RangeIn &in)
+{
+	memset(&in, 0, sizeof in);
+	auto &R = m->range;
+	if (!R.inband) return fail(KMX_E_STATE, "kmx_range_inband was not called on this build");
+	if (n_src != R.plan.world) return fail(KMX_E_ARG, "%d regions for %d ranks", n_src, R.plan.world);
+	const u64 stride = KMX_RANGE_HDR / 2 + R.capx;
+	for (int s = 0; s < n_src; s++) {
+		in.reg[s] = (const u64 *)d_recv + (u64)s * stride + KMX_RANGE_HDR / 2;
+		in.vout[s] = d_verdict ? d_verdict + (u64)s * R.capx : nullptr;
+	}
+	in.hdr = (const u32 *)d_recv;
+	in.hdr_stride = (u32)(2 * stride);
+	in.cap = (u32)R.capx;
+	in.world = n_src;
+	return KMX_OK;
+}
+// Fixed-size messages for the caller-moved transport: every region becomes [header | capx words] -- capx = the mean of a round's
+// fullest exchange + 25 % + 8192, far beyond what uniformly hashed positions ever deviate -- so that a round is two equal-split
+// all-to-alls with NO count on the host.  A word that does not fit is dropped and the build marked void (kmx_shard_local reports
+// it in kmx_stats.reserved): the caller repeats it with counted messages.  Call between kmx_range_begin and the first emit.
+static int kmx_range_inband_impl(kmx_model *m, void **d_send, uint64_t *region_words, uint64_t *capx_words)
+{
+	TRY(range_check(m, 0));
+	TRY(range_caller_moved(m));
+	auto &R = m->range;
+	const u64 held = (u64)((m->nb + R.plan.world - 1) / R.plan.world);
+	const u64 mean0 = held * KMX_BUCKET * (u64)m->nh / (u64)R.plan.world;
+	u64 capx = mean0 + mean0 / 4 + 8192;
+	if (const char *e = hook_env("KMX_RANGE_CAPX")) capx = std::max<u64>(64, strtoull(e, nullptr, 10));      // (test hook: a capacity that overflows)
+	capx = std::min(capx, R.cap_full);
+	capx = (capx + 7) & ~u64(7);
+	const u64 stride = KMX_RANGE_HDR / 2 + capx;
+	if ((u64)R.plan.world * stride > (u64)R.plan.world * R.cap_full) return fail(KMX_E_STATE, "region buffer too small");     // (cannot happen: capx <= cap_full - header only when cap_full is tiny)
+	R.inband = true;
+	R.capx = capx;
+	R.rd.cap = capx;
+	HIPCHK(hipMemsetAsync(R.d_send, 0, (u64)R.plan.world * stride * 8, m->stream));       // (headers of regions nobody writes stay zero)
+	for (int q = 0; q < R.plan.world; q++) {
+		R.rd.hdr_out[q] = (u32 *)(R.d_send + (u64)q * stride);
+		R.rd.out[q] = R.d_send + (u64)q * stride + KMX_RANGE_HDR / 2;
+	}
+	if (d_send) *d_send = R.d_send;
+	if (region_words) *region_words = stride;
+	if (capx_words) *capx_words = capx;
+	return KMX_OK;
+}
+static int kmx_range_verdict_inband_dev_impl(kmx_model *m, int t, const uint64_t *d_recv, int n_src, uint8_t *d_verdict)
+{
+	TRY(range_check(m, t));
+	TRY(range_caller_moved(m));
+	if (!d_recv || !d_verdict) return fail(KMX_E_ARG, "null argument");
+	if (m->km_byte_size == 0) return KMX_OK;
+	RangeIn in;
+	TRY(range_in_inband(m, d_recv, n_src, d_verdict, in));
+	return range_owner_round(m, t, in, RANGE_ALL);
+}
+static int kmx_range_commit_inband_dev_impl(kmx_model *m, const uint64_t *d_recv, int n_src)
+{
+	TRY(range_check(m, 0));
+	TRY(range_caller_moved(m));
+	if (!d_recv) return fail(KMX_E_ARG, "null argument");
+	if (m->km_byte_size == 0) return KMX_OK;
+	RangeIn in;
+	TRY(range_in_inband(m, d_recv, n_src, nullptr, in));
+	kmxk::range_commit_apply(m->md, in, RANGE_ALL, m->stream);
+	HIPCHK(hipGetLastError());
+	return KMX_OK;
+}
 static int kmx_range_verdict_dev_impl(kmx_model *m, int t, const uint64_t *d_words, const uint64_t *totals, const uint64_t *commits, int n_src, uint8_t *d_verdict)
 {
 	TRY(range_check(m, t));
@@ -2482,7 +2571,7 @@ static int kmx_range_resolve_dev_impl(kmx_model *m, int t, const uint8_t *d_verd
 	auto &R = m->range;
 	if (m->km_byte_size == 0) return KMX_OK;
 	u64 off = 0;
-	for (int q = 0; q < R.plan.world; q++) { R.rd.vin[q] = d_verdict ? d_verdict + off : nullptr; off += R.sent_tot[q]; }
+	for (int q = 0; q < R.plan.world; q++) { R.rd.vin[q] = d_verdict ? d_verdict + off : nullptr; off += R.inband ? R.capx : R.sent_tot[q]; }
 	if (off && !d_verdict) return fail(KMX_E_ARG, "null argument");
 	TRY(range_list_apply(m, t));
 	return range_list_order(m, t);
@@ -2507,13 +2596,15 @@ static int kmx_range_flush_dev_impl(kmx_model *m, uint64_t *counts)
 {
 	TRY(range_check(m, 0));
 	TRY(range_caller_moved(m));
-	if (!counts) return fail(KMX_E_ARG, "null argument");
 	auto &R = m->range;
-	for (int q = 0; q < 2 * R.plan.world; q++) counts[q] = 0;
-	if (!R.pending || m->km_byte_size == 0) return KMX_OK;
+	if (!counts && !R.inband) return fail(KMX_E_ARG, "null argument");
+	for (int q = 0; counts && q < 2 * R.plan.world; q++) counts[q] = 0;
+	if (m->km_byte_size == 0) return KMX_OK;
+	if (!R.pending && !R.inband) return KMX_OK;                     // (fixed-size messages: the headers are sealed -- with zeros -- whatever is pending)
 	R.pending = false;
 	kmxk::range_seal(R.rd, R.plan, m->stream);
-	return range_read_headers(m, counts);
+	HIPCHK(hipGetLastError());
+	return counts ? range_read_headers(m, counts) : KMX_OK;
 }
 
 // device memory of one filter / array of this handle, for the collectives of the caller (which: as kmx_download; 3 = the
@@ -3269,6 +3360,9 @@ extern "C" int kmx_range_buffers(kmx_model *m, void **d_send, uint64_t *cap_word
 extern "C" int kmx_range_emit_dev(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists, uint64_t *counts) { return guarded([&] { return kmx_range_emit_dev_impl(m, t, lists, n_lists, counts); }); }
 extern "C" int kmx_range_verdict_dev(kmx_model *m, int t, const uint64_t *d_words, const uint64_t *totals, const uint64_t *commits, int n_src, uint8_t *d_verdict) { return guarded([&] { return kmx_range_verdict_dev_impl(m, t, d_words, totals, commits, n_src, d_verdict); }); }
 extern "C" int kmx_range_resolve_dev(kmx_model *m, int t, const uint8_t *d_verdict) { return guarded([&] { return kmx_range_resolve_dev_impl(m, t, d_verdict); }); }
+extern "C" int kmx_range_inband(kmx_model *m, void **d_send, uint64_t *region_words, uint64_t *capx_words) { return guarded([&] { return kmx_range_inband_impl(m, d_send, region_words, capx_words); }); }
+extern "C" int kmx_range_verdict_inband_dev(kmx_model *m, int t, const uint64_t *d_recv, int n_src, uint8_t *d_verdict) { return guarded([&] { return kmx_range_verdict_inband_dev_impl(m, t, d_recv, n_src, d_verdict); }); }
+extern "C" int kmx_range_commit_inband_dev(kmx_model *m, const uint64_t *d_recv, int n_src) { return guarded([&] { return kmx_range_commit_inband_dev_impl(m, d_recv, n_src); }); }
 extern "C" int kmx_range_commit_dev(kmx_model *m, const uint64_t *d_commits, uint64_t n) { return guarded([&] { return kmx_range_commit_dev_impl(m, d_commits, n); }); }
 extern "C" int kmx_range_flush_dev(kmx_model *m, uint64_t *counts) { return guarded([&] { return kmx_range_flush_dev_impl(m, counts); }); }
 extern "C" int kmx_dev_view(kmx_model *m, int which, int index, void **ptr, uint64_t *bytes) { return guarded([&] { return kmx_dev_view_impl(m, which, index, ptr, bytes); }); }

@@ -179,7 +179,10 @@ struct RangeDev {
 	u32 *hdr_out[KMX_MAX_RANKS];         // hdr_out[q][0..2]: where the header {commits, triples, bulk commits} of that region is left for owner q
 	const unsigned char *vin[KMX_MAX_RANKS];   // vin[q][off]: verdict byte of word `off` of the region for owner q
 	int *ccnt, *tcnt;        // [KMX_MAX_RANKS * KMX_CTR_STRIDE] commits / triples per destination written since the last seal
-	u64 cap;
+	u64 cap;                 // words a region takes.  The worst case of a round (nothing is ever dropped) -- or, when the regions travel as
+	                         // fixed-size messages, what the transport ships: a word beyond it is DROPPED and *ovf raised (the build is void:
+	                         // the caller repeats it with counted messages; uniform hashing makes that a once-in-never event)
+	int *ovf;
 	u32 *tidx;               // [nb*BUCKET][nh] where the triple of hash j of a slot went: destination << 28 | index in its region
 	u32 *contended;          // [nb*BUCKET] slots of the contended candidates of a list (any order)
 	int *n_contended;        // [KMX_MAX_NB * KMX_CTR_STRIDE]
@@ -197,8 +200,10 @@ enum { RANGE_ALL = 0, RANGE_BULK = 1, RANGE_LATE = 2 };
 struct RangeIn {
 	const u64 *reg[KMX_MAX_RANKS];       // region of sender s
 	unsigned char *vout[KMX_MAX_RANKS];  // vout[s][off]: where sender s reads the verdict of word `off` of its region (its own memory, possibly through a peer mapping)
-	const u32 *hdr;                      // hdr[KMX_RANGE_HDR s + 0 .. 2]: commits / triples / bulk commits of region s, in device memory (in band) -- or null and
+	const u32 *hdr;                      // hdr[hdr_stride s + 0 .. 2]: commits / triples / bulk commits of region s, in device memory (in band) -- or null and
 	u32 nc[KMX_MAX_RANKS], nt[KMX_MAX_RANKS];   // the counts by value (the caller moved the words and knows them)
+	u32 hdr_stride;                      // u32 words between the headers of consecutive regions
+	u32 cap;                             // words of a region that arrived (0: all of them): the counts of a header are cut to it
 	int world;
 };
 

@@ -59,9 +59,10 @@ __device__ __forceinline__ void range_in_stage(const RangeIn &in, RangeInLds &L,
 	if (threadIdx.x == 0) {
 		u32 c = 0, t = 0;
 		for (int s = 0; s < in.world; s++) {
-			const u32 nc = in.hdr ? in.hdr[KMX_RANGE_HDR * s] : in.nc[s], nt = in.hdr ? in.hdr[KMX_RANGE_HDR * s + 1] : in.nt[s];
+			u32 nc = in.hdr ? in.hdr[in.hdr_stride * s] : in.nc[s], nt = in.hdr ? in.hdr[in.hdr_stride * s + 1] : in.nt[s];
+			if (in.cap) { if (nc > in.cap) nc = in.cap; if (nt > in.cap - nc) nt = in.cap - nc; }     // (the sender dropped what did not fit and says so: the build is repeated)
 			// (RANGE_BULK runs while the sender is still writing: only word 2 of the header is final then)
-			const u32 nbulk = in.hdr ? in.hdr[KMX_RANGE_HDR * s + 2] : 0;
+			const u32 nbulk = in.hdr ? in.hdr[in.hdr_stride * s + 2] : 0;
 			const u32 lo = part == RANGE_LATE ? (nbulk < nc ? nbulk : nc) : 0, hi = part == RANGE_BULK ? nbulk : nc;
 			L.pc[s] = c; L.pt[s] = t; L.nc[s] = nc; L.c0[s] = lo;
 			L.reg[s] = in.reg[s]; L.vout[s] = in.vout[s];
@@ -101,7 +102,11 @@ template <int NHM> __device__ __forceinline__ void range_block_append(const Rang
 	__syncthreads();
 #pragma unroll
 	for (int j = 0; j < NHM; j++)
-		if ((valid >> j) & 1u) L.out[dest[j]][(u64)(s_base[dest[j]] + rank[j])] = word[j];
+		if ((valid >> j) & 1u) {
+			const u64 off = (u64)(s_base[dest[j]] + rank[j]);
+			if (off < rd.cap) L.out[dest[j]][off] = word[j];
+			else *rd.ovf = 1;
+		}
 	__syncthreads();
 }
 
@@ -150,8 +155,9 @@ template <int NHM> __device__ __forceinline__ void range_block_append_sorted(con
 	for (int j = 0; j < NHM; j++)
 		if ((valid >> j) & 1u) {
 			const u64 off = (u64)(s_base[dest[j]] + (s_key[key[j]] - s_key[dest[j] * KMX_CL_MAXBINS]) + rank[j]);
-			L.out[dest[j]][off] = word[j];
-			where[j] = ((u32)dest[j] << 28) | (u32)off;
+			if (off < rd.cap) L.out[dest[j]][off] = word[j];
+			else *rd.ovf = 1;
+			where[j] = ((u32)dest[j] << 28) | (u32)(off < rd.cap ? off : 0);
 		}
 	__syncthreads();
 }
@@ -163,6 +169,7 @@ __device__ __forceinline__ void range_seal_regions(const RangeDev &rd, int world
 	const int q = threadIdx.x;
 	if (q >= world) return;
 	const u32 nc = (u32)rd.ccnt[q * KMX_CTR_STRIDE], nt = (u32)rd.tcnt[q * KMX_CTR_STRIDE];
+	if ((u64)nc + nt > rd.cap) *rd.ovf = 1;
 	rd.hdr_out[q][0] = nc;
 	rd.hdr_out[q][1] = nt;
 	rd.ccnt[q * KMX_CTR_STRIDE] = 0;
@@ -411,7 +418,11 @@ template <int NHM> __device__ __forceinline__ void range_winner_commits(const Mo
 	__syncthreads();
 #pragma unroll
 	for (int j = 0; j < NHM; j++)
-		if ((valid >> j) & 1u) L.out[dest[j]][(u64)(s_cb[dest[j]] + rank[j])] = word[j];
+		if ((valid >> j) & 1u) {
+			const u64 off = (u64)(s_cb[dest[j]] + rank[j]);
+			if (off < rd.cap) L.out[dest[j]][off] = word[j];
+			else *rd.ovf = 1;
+		}
 	__syncthreads();
 }
 

@@ -188,6 +188,18 @@ class Comm:
         self.bytes_sent += (int(sum(send_splits)) - int(send_splits[self.rank])) * send.element_size() * int(np.prod(send.shape[1:], dtype=np.int64))
         return out.to(send.device) if out.device != send.device else out
 
+    def all_to_all_fixed(self, send: torch.Tensor) -> torch.Tensor:
+        """send[q] (equal pieces, one per rank) goes to rank q; returns what every rank sent here, same shape -- no split size
+        comes from the host"""
+        if self.world == 1 and self.shortcut:
+            return send
+        w = self._wire(send.contiguous())
+        out = torch.empty_like(w)
+        dist.all_to_all_single(out, w, group=self.group)
+        self.collectives += 1
+        self.bytes_sent += send.numel() * send.element_size() * (self.world - 1) // self.world
+        return out.to(send.device) if out.device != send.device else out
+
     def exchange(self, sends, recvs):
         """point-to-point hand-offs of one ring step: sends = [(tensor, dst rank)], recvs = [(tensor, src rank)]"""
         if not sends and not recvs:
@@ -350,6 +362,7 @@ class DeviceEngine:
     def range_begin(self, k, n_bf, n_total, rank, world):
         self.k, self.W = k, (k + 31) // 32
         self.m.range_begin(k, n_bf, n_total, rank, world)
+        self._world = world
         p, self._cap, self.cell_lo = self.m.range_buffers()
         self._send = dev_tensor(p, self._cap * world, torch.int64, self.device)
 
@@ -379,6 +392,27 @@ class DeviceEngine:
     def range_flush(self):
         counts = self.m.range_flush_dev()
         return self._regions(counts), counts
+
+    # fixed-size messages (kmx_range_inband): a region = [header | capx words]; no count ever reaches the host
+    def range_inband(self):
+        p, self._rw, self._capx = self.m.range_inband()
+        self._msg = dev_tensor(p, self._rw * self._world, torch.int64, self.device).view(self._world, self._rw)
+
+    def range_emit_inband(self, t, lists):
+        self.m.range_emit_nowait_dev(t, [(l["list"], l["n"], l["kmers"].data_ptr() if l["n"] else 0, l["counts"].data_ptr() if l["n"] else 0) for l in lists])
+        return self._msg
+
+    def range_verdict_inband(self, t, recv):
+        ver = torch.empty((self._world, self._capx), dtype=torch.uint8, device=self.device)
+        self.m.range_verdict_inband_dev(t, recv.data_ptr(), self._world, ver.data_ptr())
+        return ver
+
+    def range_flush_inband(self):
+        self.m.range_flush_nowait_dev()
+        return self._msg
+
+    def range_commit_inband(self, recv):
+        self.m.range_commit_inband_dev(recv.data_ptr(), self._world)
 
     def range_commit(self, commits):
         if commits.numel():
@@ -506,21 +540,33 @@ def build_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: torch.Te
     return {"n_km": n_km, "blocks": n_blocks, "bytes_sent": comm.bytes_sent - sent0, "arrays_owned": [a for a in range(nb) if own[a] == rank]}
 
 
-def build_range_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: torch.Tensor, counts: torch.Tensor, n_total: int | None = None):
+def build_range_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: torch.Tensor, counts: torch.Tensor, n_total: int | None = None, messages: str | None = None):
     """The north star's partition: "shard the bit arrays by hash-range across up to 8 GPUs with an RCCL all-to-all".  Rank q
     owns the cells [cell_lo[q], cell_lo[q+1]) of EVERY array; list i of a block lives on rank i % world, which hashes its
     k-mers, keeps the list order and reorders locally -- k-mers are routed once (the same all-to-all as the ring's, to the
     list's rank) and never move again.  A round (list i against array (i + t) % nb, kmodel.hpp:560-565) is two all-to-alls:
     64-bit words to the range owners -- the winners' commits of the round before, then this round's triples -- and one verdict
     byte per word back (`range_kernels.h` has the kernels and why the outcome is the sequential one); the last round's commits
-    are flushed by one more exchange at the end.  Every rank works in every round, whatever nb is; what the partition pays is
-    two collectives (and a split-size exchange) inside every round of the ordered chain."""
+    are flushed by one more exchange at the end.  Every rank works in every round, whatever nb is.
+
+    messages = "fixed" (the default): a region travels as [header | capx words] -- the counts are IN BAND, both all-to-alls of a
+    round have equal splits, and NO number of a round reaches the host: 2 collectives, 0 host waits per round.  capx is the mean
+    of a round's fullest exchange + 25 % + 8192 words; should a region ever overflow (uniformly hashed positions do not), the
+    words that did not fit were dropped, every rank learns it with the final statistics, and the build is repeated with
+    messages = "counted": split sizes from the host, a ragged all-to-all each way -- 3 collectives and a host wait per round."""
+    if messages is None:
+        messages = "counted" if os.environ.get("KMX_RANGE_MESSAGES") == "counted" else "fixed"
+    if messages not in ("fixed", "counted"):
+        raise ValueError(f"messages {messages!r}: fixed or counted")
+    fixed = messages == "fixed" and hasattr(eng, "range_inband")
     rank, world, dev = comm.rank, comm.world, counts.device
     sent0, coll0 = comm.bytes_sent, comm.collectives
     local_hist = eng.count_classes(counts)
     tot = comm.all_reduce_ints(local_hist + [counts.numel()], dev)
     n_bf, n_all = tot[:3], tot[3]
     eng.range_begin(k, n_bf, n_all if n_total is None else n_total, rank, world)
+    if fixed:
+        eng.range_inband()
     km_loc, cnt_loc = eng.classify(kmers, counts)
     per_rank = comm.all_gather_ints(cnt_loc.shape[0], dev)
     n_km = int(sum(per_rank))
@@ -549,22 +595,35 @@ def build_range_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: to
                     n_i = list_length(n_km, nb, b, i)
                     lists.append({"list": i, "n": n_i, "kmers": km_mine[pos:pos + n_i], "counts": cnt_mine[pos:pos + n_i]})
                     pos += n_i
+            if fixed:
+                got = comm.all_to_all_fixed(eng.range_emit_inband(t, lists))            # 1. [header | last round's commits + this round's triples] -> range owners
+                back = comm.all_to_all_fixed(eng.range_verdict_inband(t, got))          # 2. commits applied, one verdict byte per word back
+                eng.range_resolve(t, back)                                              # 3. winners decided; their commits go to the front of the regions
+                continue
             words, out_counts, out_commits = eng.range_emit(t, lists)                   # 1. last round's commits + this round's triples -> range owners
             hdr = comm.all_to_all_ints([c | (cc << 32) for c, cc in zip(out_counts, out_commits)], dev)   # the regions' headers: words | commit words in front << 32
             in_counts, in_commits = [h & 0xFFFFFFFF for h in hdr], [h >> 32 for h in hdr]
             got = comm.all_to_all_v(words, out_counts, in_counts)
             ver = eng.range_verdict(t, got, in_counts, in_commits)                      # 2. commits applied, one verdict byte per word back, same order
             back = comm.all_to_all_v(ver, in_counts, out_counts)
-            eng.range_resolve(t, back)                                                  # 3. winners decided; their commits wait for the next round's triples
+            eng.range_resolve(t, back)                                                  # 3. winners decided; their commits go to the front of the regions
     if n_blocks:                                                                        # the last round's commits
-        commits, c_out = eng.range_flush()
-        c_in = comm.all_to_all_ints(c_out, dev)
-        eng.range_commit(comm.all_to_all_v(commits, c_out, c_in))
+        if fixed:
+            eng.range_commit_inband(comm.all_to_all_fixed(eng.range_flush_inband()))
+        else:
+            commits, c_out = eng.range_flush()
+            c_in = comm.all_to_all_ints(c_out, dev)
+            eng.range_commit(comm.all_to_all_v(commits, c_out, c_in))
     st, rest_km, rest_cnt = eng.local()
+    sums = comm.all_reduce_ints([getattr(st, f) for f in STAT_FIELDS] + [int(getattr(st, "reserved", 0) != 0)], dev)
+    if fixed and sums[-1]:
+        # a region dropped words on some rank: this build is void on every rank; once more, with counted messages (exact whatever the input)
+        info = build_range_sharded(eng, comm, k, nb, bf_num, kmers, counts, n_total, messages="counted")
+        info["fixed_messages_overflowed"] = True
+        return info
     rest_counts = comm.all_gather_ints(int(st.rest_entries), dev)
     rest_km_all = comm.all_gather_v(rest_km, rest_counts)
     rest_cnt_all = comm.all_gather_v(rest_cnt, rest_counts)
-    sums = comm.all_reduce_ints([getattr(st, f) for f in STAT_FIELDS], dev)
     for f, v in zip(STAT_FIELDS, sums):
         setattr(st, f, v)
     st.blocks, st.rounds = n_blocks, n_blocks * nb
@@ -578,7 +637,7 @@ def build_range_sharded(eng, comm: Comm, k: int, nb: int, bf_num: int, kmers: to
                 comm.all_gather_ranges(v, lo)
     eng.complete(rest_km_all, rest_cnt_all, st)
     return {"n_km": n_km, "blocks": n_blocks, "bytes_sent": comm.bytes_sent - sent0, "collectives": comm.collectives - coll0,
-            "cells_owned": [int(eng.cell_lo[rank]), int(eng.cell_lo[rank + 1])], "partition": "range"}
+            "cells_owned": [int(eng.cell_lo[rank]), int(eng.cell_lo[rank + 1])], "partition": "range", "messages": "fixed" if fixed else "counted"}
 
 
 def query_replicas(model, comm: Comm, queries: torch.Tensor, k: int) -> torch.Tensor:

@@ -121,6 +121,11 @@ class RangeOracleEngine(OracleEngine):
 
     def range_resolve(self, t, verdicts):
         back = _np(verdicts)
+        if back.ndim == 2:                                          # fixed-size messages: capx bytes per destination, the first sent[q] of them answered
+            if self.overflowed:
+                back = np.zeros(len(self.order), dtype=np.uint8)    # (void build: any verdicts do)
+            else:
+                back = np.concatenate([back[q, : self._sent[q]] for q in range(self.world)])
         verdict = np.empty(len(back), dtype=np.uint8)
         verdict[self.order] = back                                  # the order the words were generated in: commits, then the triples
         verdict = verdict[self.n_commits:]
@@ -193,8 +198,66 @@ class RangeOracleEngine(OracleEngine):
             pv = p[v[msk] == 1]
             np.bitwise_or.at(val, pv >> 3, (np.uint8(0x80) >> (pv & 7).astype(np.uint8)))
 
+    # ---- fixed-size messages (kmx_range_inband): a region = [2 header words: commits | triples << 32, 0] + capx words; words beyond
+    # capx are dropped and the build is void (local() reports it) -- the product's rule, so that the orchestration's fallback
+    # to counted messages runs here too (RANGE_ENGINE_CAPX forces a small capacity)
+    def range_inband(self):
+        held = -(-self.nb // self.world)
+        mean0 = held * BUCKET * self.nh // self.world
+        self.capx = int(os.environ.get("RANGE_ENGINE_CAPX", mean0 + mean0 // 4 + 8192))
+        self.overflowed = False
+
+    def _pack(self, words, counts, commits):
+        w = _np(words)
+        msg = np.zeros((self.world, 2 + self.capx), dtype=np.int64)
+        off = 0
+        self._sent = list(counts)
+        for q, (tot, nc) in enumerate(zip(counts, commits)):
+            msg[q, 0] = nc | ((tot - nc) << 32)
+            keep = min(tot, self.capx)
+            if tot > self.capx:
+                self.overflowed = True
+            msg[q, 2: 2 + keep] = w[off: off + keep]
+            off += tot
+        return torch.from_numpy(msg)
+
+    def _unpack(self, recv):
+        r = _np(recv).reshape(self.world, 2 + self.capx)
+        totals, commits, parts = [], [], []
+        for s in range(self.world):
+            nc, nt = int(r[s, 0] & 0xFFFFFFFF), int((r[s, 0] >> 32) & 0xFFFFFFFF)
+            nc = min(nc, self.capx)
+            nt = min(nt, self.capx - nc)
+            totals.append(nc + nt); commits.append(nc); parts.append(r[s, 2: 2 + nc + nt])
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64), totals, commits
+
+    def range_emit_inband(self, t, lists):
+        words, counts, commits = self.range_emit(t, lists)
+        return self._pack(words, counts, commits)
+
+    def range_verdict_inband(self, t, recv):
+        words, totals, commits = self._unpack(recv)
+        if (words < 0).sum() != sum(commits):                       # a sender dropped words: nothing consistent can be answered (the build is void anyway)
+            return torch.zeros((self.world, self.capx), dtype=torch.uint8)
+        ver = _np(self.range_verdict(t, torch.from_numpy(words), totals, commits))
+        out = np.zeros((self.world, self.capx), dtype=np.uint8)
+        off = 0
+        for s, tot in enumerate(totals):
+            out[s, :tot] = ver[off: off + tot]
+            off += tot
+        return torch.from_numpy(out)
+
+    def range_flush_inband(self):
+        words, counts = self.range_flush()
+        return self._pack(words, counts, counts)
+
+    def range_commit_inband(self, recv):
+        words, _, _ = self._unpack(recv)
+        self.range_commit(torch.from_numpy(words[words < 0]))
+
     def local(self):
         st = _Local()
+        st.reserved = int(getattr(self, "overflowed", False))
         st.attempts, st.successes = self.attempts + self.extra_attempts, self.successes
         st.fast_commits, st.contended, st.finisher_iters = self.successes, self.n_contended, 0
         km = np.concatenate(self.rest_k) if self.rest_k else np.zeros(0, dtype=np.uint64)

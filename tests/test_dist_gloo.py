@@ -124,23 +124,32 @@ def test_single_model_protocol_with_oracle_engine(spec, world, golden, tmp_path)
     assert res[0]["occ_sha"] == g["occ_sha256"]
 
 
-@pytest.mark.parametrize("spec,world", [
-    (("synth", "tiny_k31"), 2),
-    (("synth", "k31_ci2_200k"), 3),                # three Bloom classes; 5 lists on 3 ranks
-    (("synth", "k31_multiblock_ci1"), 2),          # several blocks, the partial last one with unused rows: quirk Q1 on the ranks that hold those lists
-    (("synth", "tiny_k31"), 8),                    # a whole node: 5 lists on ranks 0-4, every rank owns an eighth of every array
-], ids=lambda v: v[1] if isinstance(v, tuple) else f"w{v}")
-def test_range_partition_protocol_with_numpy_engine(spec, world, golden, tmp_path):
-    """kmcex_amd.dist.build_sharded(partition="range") -- buffer i routed to rank i % P, split sizes, triples / verdicts / commits
-    by all-to-all, all-gather of the cell ranges -- over gloo with a numpy engine on the oracle's arrays (tests/range_engine.py):
-    every rank ends with the reference's files.  (The device engine runs the same orchestration in tests/test_gpu_dist.py.)"""
+@pytest.mark.parametrize("spec,world,messages", [
+    (("synth", "tiny_k31"), 2, "fixed"),
+    (("synth", "k31_ci2_200k"), 3, "fixed"),       # three Bloom classes; 5 lists on 3 ranks
+    (("synth", "k31_multiblock_ci1"), 2, "fixed"), # several blocks, the partial last one with unused rows: quirk Q1 on the ranks that hold those lists
+    (("synth", "tiny_k31"), 8, "fixed"),           # a whole node: 5 lists on ranks 0-4, every rank owns an eighth of every array
+    (("synth", "k31_ci2_200k"), 3, "counted"),     # split sizes from the host, ragged all-to-alls (the fallback, asked for)
+    (("synth", "k31_ci2_200k"), 2, "overflow"),    # regions far too small: words are dropped, every rank learns it, the build is repeated with counted messages
+], ids=lambda v: v[1] if isinstance(v, tuple) else str(v))
+def test_range_partition_protocol_with_numpy_engine(spec, world, messages, golden, tmp_path, monkeypatch):
+    """kmcex_amd.dist.build_sharded(partition="range") -- buffer i routed to rank i % P, triples / verdicts / commits by all-to-all
+    (fixed-size messages with in-band counts: no host wait in a round; or counted ones), all-gather of the cell ranges -- over gloo
+    with a numpy engine on the oracle's arrays (tests/range_engine.py): every rank ends with the reference's files.  (The device
+    engine runs the same orchestration in tests/test_gpu_dist.py.)"""
     from dist_workers import cpu_worker, run_ranks
     g = golden["cases"][spec[1]]
+    if messages == "counted":
+        monkeypatch.setenv("KMX_RANGE_MESSAGES", "counted")
+    if messages == "overflow":
+        monkeypatch.setenv("RANGE_ENGINE_CAPX", "20000")
     res = run_ranks(cpu_worker, world, spec, str(tmp_path), "range", timeout=900)
     for r in res:
         assert r["sha"] == {f: g["sha256"][f] for f in ("header", "km.bin", "rest.bin")}, f"rank {r['rank']} holds a different model"
         assert r["stats"][2:5] == (g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
         assert r["info"]["partition"] == "range" and r["info"]["collectives"] >= 2 * r["info"]["blocks"]
+        assert r["info"]["messages"] == ("fixed" if messages == "fixed" else "counted")
+        assert bool(r["info"].get("fixed_messages_overflowed")) == (messages == "overflow")
     assert res[0]["occ_sha"] == g["occ_sha256"]
 
 

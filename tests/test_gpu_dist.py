@@ -44,21 +44,32 @@ def test_single_model_over_ranks_is_bit_exact(spec, world, golden, tmp_path):
     assert owned == list(range(len(owned)))                        # every array has exactly one owner
 
 
-# The north star's partition: every array cut by position range, triples / verdicts / commits by all-to-all.
-@pytest.mark.parametrize("spec,world", [
-    (("synth", "tiny_k31"), 1),                    # one rank: the kernels of the partition alone, every word "sent" to itself
-    (("synth", "tiny_k31"), 2),
-    (("synth", "k31_multiblock_ci1"), 2),          # 3 lists on rank 0, 2 on rank 1; quirk Q1 on the ranks that hold the unused rows
-    (("synth", "k31_multiblock_ci1"), 3),
-    (("synth", "k31_multiblock_ci1"), 5),
-    (("synth", "k55_multiblock"), 2),              # two-word k-mers, nh 9 (16-wide templates), nb 6
-    (("synth", "k55_multiblock"), 5),
-    (("kmc2", "k31_kmc2_6bins"), 3),               # bin-major (unsorted) listing order
-    (("synth", "k31_multiblock_ci2"), 2),          # three Bloom classes
-    (("synth", "k31_nh3_nb1"), 3),                 # one list, three range owners
-], ids=lambda v: v[1] if isinstance(v, tuple) else f"w{v}")
-def test_range_partition_over_ranks_is_bit_exact(spec, world, golden, tmp_path):
+# The north star's partition: every array cut by position range, triples / verdicts / commits by all-to-all --
+# as fixed-size messages with the counts in band (no host wait in a round; the default), as counted ones, and with regions forced
+# far too small (KMX_RANGE_CAPX under KMX_TEST_HOOKS): words are dropped, every rank learns it, the build is repeated, counted.
+@pytest.mark.parametrize("spec,world,messages", [
+    (("synth", "tiny_k31"), 1, "fixed"),           # one rank: the kernels of the partition alone, every word "sent" to itself
+    (("synth", "tiny_k31"), 2, "fixed"),
+    (("synth", "k31_multiblock_ci1"), 2, "fixed"), # 3 lists on rank 0, 2 on rank 1; quirk Q1 on the ranks that hold the unused rows
+    (("synth", "k31_multiblock_ci1"), 3, "fixed"),
+    (("synth", "k31_multiblock_ci1"), 5, "fixed"),
+    (("synth", "k55_multiblock"), 2, "fixed"),     # two-word k-mers, nh 9 (16-wide templates), nb 6
+    (("synth", "k55_multiblock"), 5, "fixed"),
+    (("kmc2", "k31_kmc2_6bins"), 3, "fixed"),      # bin-major (unsorted) listing order
+    (("synth", "k31_multiblock_ci2"), 2, "fixed"), # three Bloom classes
+    (("synth", "k31_nh3_nb1"), 3, "fixed"),        # one list, three range owners
+    (("synth", "k31_multiblock_ci1"), 3, "counted"),
+    (("synth", "k55_multiblock"), 2, "counted"),
+    (("synth", "k31_multiblock_ci1"), 2, "overflow"),
+    (("synth", "k31_multiblock_ci2"), 3, "overflow"),
+], ids=lambda v: v[1] if isinstance(v, tuple) else str(v))
+def test_range_partition_over_ranks_is_bit_exact(spec, world, messages, golden, tmp_path, monkeypatch):
     g = _golden_of(golden, spec)
+    if messages == "counted":
+        monkeypatch.setenv("KMX_RANGE_MESSAGES", "counted")
+    if messages == "overflow":
+        monkeypatch.setenv("KMX_TEST_HOOKS", "1")
+        monkeypatch.setenv("KMX_RANGE_CAPX", "30000")
     res = run_ranks(gpu_worker, world, spec, str(tmp_path), None, "range")
     for r in res:
         assert r["sha"] == {f: g["sha256"][f] for f in ("header", "km.bin", "rest.bin")}, f"rank {r['rank']} holds a different model"
@@ -66,6 +77,8 @@ def test_range_partition_over_ranks_is_bit_exact(spec, world, golden, tmp_path):
         if "stats" in g:
             assert r["stats"][2:5] == (g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
         assert r["info"]["partition"] == "range" and r["info"]["collectives"] >= (2 * r["info"]["blocks"] * (len(res) > 1))
+        assert r["info"]["messages"] == ("fixed" if messages == "fixed" else "counted")
+        assert bool(r["info"].get("fixed_messages_overflowed")) == (messages == "overflow")
     cells = sorted(tuple(r["info"]["cells_owned"]) for r in res)
     assert cells[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cells, cells[1:]))       # the ranges tile every array
 
