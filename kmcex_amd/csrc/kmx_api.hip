@@ -46,7 +46,7 @@ void range_emit(const ModelDev &, const BlockDev &, const RangeDev &, const Rang
 void range_seal(const RangeDev &, const RangePlan &, hipStream_t);
 void range_verdict(const ModelDev &, const BlockDev &, int *, int, const RangeIn &, unsigned char *, int, hipStream_t);
 void range_apply(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, bool, hipStream_t);
-void range_resolve(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, hipStream_t);
+void range_resolve(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, bool, hipStream_t);
 void range_commit_apply(const ModelDev &, const RangeIn &, int, hipStream_t);
 void query(const ModelDev &, const u64 *, u64, int *, hipStream_t, KernelProf *, u64 *acct = nullptr);
 void query_ascii(const ModelDev &, int, const unsigned char *, int, u64, int *, hipStream_t);
@@ -1826,6 +1826,9 @@ static int kmx_shard_complete_impl(kmx_model *m, const uint64_t *d_rest_kmers, c
 // include/kmodel.hpp with KMX_DEVICES=0,1,...  `hs[d]` was created on the device it is to use (kmx_create_on); on return
 // EVERY handle holds the whole model (replicas, as after dist.build_sharded).  Devices may repeat (several handles on one
 // GPU: how the one-GPU pool tests the protocol).
+#ifndef KMX_RANGE_OVERLAP_DEFAULT
+#define KMX_RANGE_OVERLAP_DEFAULT 0
+#endif
 namespace {
 // The host threads only ENQUEUE (nobody waits for a device between two barriers of a round), so a barrier is crossed within
 // microseconds: spin, and give the core away only when there are more threads than cores.
@@ -1850,8 +1853,8 @@ static int range_begin_common(kmx_model *m, int k, const uint64_t n_bf[3], uint6
 static int range_link(kmx_model **hs, int P, int d);
 static int range_list_emit(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists);
 static int range_owner_round(kmx_model *m, int t, const RangeIn &in, int commits);
-static int range_list_apply(kmx_model *m, int t);
-static int range_list_order(kmx_model *m, int t);
+static int range_list_apply(kmx_model *m, int t, bool seal_bulk = false);
+static int range_list_order(kmx_model *m, int t, bool seal_all = false);
 static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *db_prefix, int partition)
 {
 	if (!hs || !db_prefix || P < 1) return fail(KMX_E_ARG, "null argument");
@@ -2001,15 +2004,14 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 		// only enqueue, nothing here waits for a device
 		u64 pos = 0;
 		if (by_range) {
-			// The BULK of a round's commits (the uncontended winners': 99.6 %) is complete when k_range_apply ends: the owners CAN set
-			// those bits on a side stream while the list ranks still order their contended candidates, reorder and hash the next
-			// round's triples; what the resolver adds is applied in front of the next verdicts.  Measured on one GPU (1 and 2
-			// handles, profiles/r05_range_cxx_overlap_ab.txt) it buys nothing: under the atomics k_range_resolve takes 67 us
-			// instead of 35 and k_reorder 20 instead of 6.6 -- the ordered chain stretches by what the overlap hides -- so it is
-			// OFF unless KMX_RANGE_OVERLAP=1 (under KMX_TEST_HOOKS) asks for it; a node where every GPU applies 1/P of the commits
-			// is where to try it again.
+			// A round's commits can be set by the owners on a SIDE stream, beside what the list ranks do next, instead of in front of
+			// the next verdicts.  KMX_RANGE_OVERLAP (under KMX_TEST_HOOKS) picks from where: 1 -- from the end of k_range_apply (the
+			// uncontended winners': 99.6 % of them; the resolver's follow in front of the verdicts): measured on one GPU it buys
+			// nothing, k_range_resolve takes 67 us instead of 35 under the atomics and k_reorder 20 instead of 6.6 -- the ordered
+			// chain stretches by what the overlap hides; 2 -- from the end of k_reorder: ALL commits, beside the hashing of the
+			// next round's triples (k_range_emit: ALU and streaming stores, not slowed by the atomics); 0 -- none.
 			const char *ov = hook_env("KMX_RANGE_OVERLAP");
-			const bool overlap = ov && ov[0] == '1';
+			const int overlap = ov ? atoi(ov) : KMX_RANGE_OVERLAP_DEFAULT;
 			enum { EV_EMIT = 0, EV_VER, EV_BULK, EV_BULK_DONE };
 			auto wait_all = [&](hipStream_t on, int which, bool self) {
 				for (int q = 0; q < P; q++)
@@ -2043,8 +2045,7 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 						hip_ok(hipEventRecord(r.ev[EV_VER], st), "event");
 					}
 					bar.wait();
-					if (!err) { wait_all(st, EV_VER, false); note(range_list_apply(m, t)); }       // 3. failures, winners: the bulk of the commits is in the owners' inboxes
-					if (overlap) {
+					auto commits_aside = [&] {                                                      // what the headers call the bulk, on the side stream
 						if (!err) hip_ok(hipEventRecord(r.ev[EV_BULK], st), "event");
 						bar.wait();
 						if (!err) {
@@ -2053,8 +2054,11 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 							hip_ok(hipEventRecord(r.ev[EV_BULK_DONE], r.side), "event");
 						}
 						bulk_ahead = true;
-					}
-					if (!err) note(range_list_order(m, t));                                        //    ... the contended in list order, reorder
+					};
+					if (!err) { wait_all(st, EV_VER, false); note(range_list_apply(m, t, overlap == 1)); }   // 3. failures, winners: the bulk of the commits is in the owners' inboxes
+					if (overlap == 1) commits_aside();
+					if (!err) note(range_list_order(m, t, overlap == 2));                          //    ... the contended in list order, reorder
+					if (overlap == 2) commits_aside();
 				}
 			}
 			if (n_blocks) {                                                   // the last round's commits
@@ -2351,19 +2355,19 @@ static int range_owner_round(kmx_model *m, int t, const RangeIn &in, int commits
 }
 // step 3, list rank: verdicts -> failures and winners; the uncontended winners' commits (the bulk) are in front of the regions
 // and their count in the headers when this launch ends
-static int range_list_apply(kmx_model *m, int t)
+static int range_list_apply(kmx_model *m, int t, bool seal_bulk)
 {
-	kmxk::range_apply(m->md, m->bd, m->range.rd, m->range.plan, t, m->pp, m->range.mailbox, m->stream);   // (mailbox: + the bulk count into the owners' headers)
+	kmxk::range_apply(m->md, m->bd, m->range.rd, m->range.plan, t, m->pp, seal_bulk, m->stream);
 	HIPCHK(hipGetLastError());
 	return KMX_OK;
 }
 // ... then the contended in list order (their commits behind the bulk); reorder_buffer (:529-540); after the last round km_back
 // and the rest table
-static int range_list_order(kmx_model *m, int t)
+static int range_list_order(kmx_model *m, int t, bool seal_all)
 {
 	auto &R = m->range;
 	const int nb = m->nb, pp = m->pp;
-	kmxk::range_resolve(m->md, m->bd, R.rd, R.plan, t, pp, m->stream);
+	kmxk::range_resolve(m->md, m->bd, R.rd, R.plan, t, pp, seal_all, m->stream);
 	R.pending = true;
 	HIPCHK(hipGetLastError());
 	m->pp ^= 1;

@@ -706,10 +706,13 @@ void range_apply(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, con
 	if (seal_bulk) hipLaunchKernelGGL(k_range_seal_bulk, dim3(1), dim3(64), 0, st, rd, pl.world);
 }
 // ... then the contended in list order (their commits behind the bulk) and reorder_buffer
-void range_resolve(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangePlan &pl, int t, int pp, hipStream_t st)
+// (seal_all: every commit of the round is in the regions now: their count goes to the owners' headers -- as the "bulk" --, so that
+// the owners can set the bits while this rank reorders and hashes the next round)
+void range_resolve(const ModelDev &md, const BlockDev &bd, const RangeDev &rd, const RangePlan &pl, int t, int pp, bool seal_all, hipStream_t st)
 {
 	if (md.nh <= 8) hipLaunchKernelGGL((k_range_resolve<8>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl, t, pp);
 	else hipLaunchKernelGGL((k_range_resolve<16>), dim3(md.nb), dim3(1024), 0, st, md, bd, rd, pl, t, pp);
+	if (seal_all) hipLaunchKernelGGL(k_range_seal_bulk, dim3(1), dim3(64), 0, st, rd, pl.world);
 	DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_reorder<W, NHM>), dim3(KMX_NTILES + KMX_APPLY_WGS, md.nb), dim3(256), 0, st, md, bd, t, pp, 0));   // (no REC_WON records here: Un stays 0)
 }
 // the commit words of a last exchange
