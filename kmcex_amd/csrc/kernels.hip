@@ -2559,9 +2559,35 @@ static inline int round_gx(int t) { return (int)(KMX_BUCKET / 256) >> (t < 4 ? t
 // round, or calls commit_flush.  The single-workgroup finisher decides whatever the sub-rounds leave (everything when
 // nsub == 0), so nsub only trades launches for finisher iterations; the host picks it from the contention it has observed.
 // t_prev: the round index of the pending commit (t - 1, or nb - 1 of the previous block).
-void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 *epoch, int flags, hipStream_t st, KernelProf *prof, const KmbackJob *job, const BitScatter *kmb)
+// PROBE (KMX_PREGATHER_PROBE under KMX_TEST_HOOKS; never in a product build's path): how much of the next round's gathers could hide
+// under this round's ordered chain?  The k-mers that a round's check has just failed on a set tag -- ~95 % of the next round's
+// attempts -- could fetch their next array's cells while detect -> file -> finisher -> reorder leave the memory system idle.
+// This kernel only IMITATES that traffic: as many random 4-byte loads on the next array as those k-mers would issue (nh * 13/16,
+// the staged fetch stops early), on a side stream beside the chain, results discarded.  If a build takes no longer with it, the
+// real thing would take the same loads out of the fused launches; if the build grows by what the kernel takes, nothing can hide.
+__global__ __launch_bounds__(256) void k_probe_pregather(ModelDev md, BlockDev bd, int t, int pp, u64 ncells, u32 *sink)
+{
+	__shared__ int s_sum;
+	const int i = blockIdx.y;
+	if (threadIdx.x == 0) s_sum = 0;
+	__syncthreads();
+	if (threadIdx.x < (int)KMX_NTILES) atomicAdd(&s_sum, bd.tile_cnt[pp][i * KMX_NTILES + threadIdx.x]);     // the failures counted so far in this round
+	__syncthreads();
+	const u64 total = (u64)s_sum * (u64)md.nh * 13 / 16;
+	const cell_t *cells = md.cells[(i + t + 1) % md.nb];
+	u32 acc = 0;
+	for (u64 g = (u64)blockIdx.x * 256 + threadIdx.x; g < total; g += (u64)gridDim.x * 256) {
+		u64 z = (g + ((u64)i << 40) + ((u64)t << 48)) * 0x9E3779B97F4A7C15ULL;
+		z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 32;
+		acc ^= cells[z % ncells];
+	}
+	if (acc == 0x12345u) sink[0] = acc;                               // (keeps the loads)
+}
+
+void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 *epoch, int flags, hipStream_t st, KernelProf *prof, const KmbackJob *job, const BitScatter *kmb, const RoundProbe *probe)
 {
 	const int nb = md.nb;
+	if (probe && probe->on) hipStreamWaitEvent(st, probe->done, 0);   // the imitation of the last round's pre-gather ends before this round's check starts
 	if (nsub < 0) nsub = 0;
 	if (nsub > KMX_MAX_NSUB) nsub = KMX_MAX_NSUB;
 	const int gx = round_gx(t);
@@ -2578,6 +2604,12 @@ void round(const ModelDev &md, const BlockDev &bd, int t, int pp, int nsub, u64 
 		KPROF_BEGIN(prof, KC_CHECK_CLAIM, st);
 		DISPATCH_W_NH(words(md), md.nh, hipLaunchKernelGGL((k_round_check_emit<W, NHM>), grid, blk, 0, st, md, bd, t, pp));
 		KPROF_END(prof, st);
+	}
+	if (probe && probe->on) {
+		hipEventRecord(probe->fork, st);
+		hipStreamWaitEvent(probe->side, probe->fork, 0);
+		hipLaunchKernelGGL(k_probe_pregather, dim3(256, nb), dim3(256), 0, probe->side, md, bd, t, pp, (u64)((md.km_mod.d + 15) / 16), probe->sink);
+		hipEventRecord(probe->done, probe->side);
 	}
 	KPROF_BEGIN(prof, KC_DETECT, st);
 	const int keep_own = (flags & KMX_ROUND_KEEP) ? 1 : 0;

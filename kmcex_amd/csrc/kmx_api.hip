@@ -34,7 +34,7 @@ int classify_tiles(u64 n);
 void classify_count(const ModelDev &, const u64 *, const u32 *, u64, u64, int *, int *, int *, u64 *, const BitScatter &, int, hipStream_t, KernelProf *);
 void classify_scatter(const ModelDev &, const u64 *, const u32 *, u64, const int *, u64 *, u32 *, u64, hipStream_t);
 void block_init(const BlockDev &, int, int, int, hipStream_t);
-void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *, const KmbackJob *, const BitScatter *);
+void round(const ModelDev &, const BlockDev &, int, int, int, u64 *, int, hipStream_t, KernelProf *, const KmbackJob *, const BitScatter *, const RoundProbe *probe = nullptr);
 void commit_flush(const ModelDev &, const BlockDev &, int, int, hipStream_t, KernelProf *);
 void rest_append(const ModelDev &, const BlockDev &, int, int, int, u64 *, int *, unsigned long long *, u64 *, int *, u64 *, hipStream_t, int istride = 1);
 void kmback_emit(const ModelDev &, const BlockDev &, const u64 *, const unsigned char *, int, int, int, int, int, const BitScatter &, hipStream_t, int istride = 1);
@@ -289,6 +289,7 @@ struct kmx_model {
 		u64 alloc_key = 0;                                         // nb, nh, world, transport the buffers were sized for
 		int n0[KMX_MAX_NB] = {};                                   // entries of the held lists when the block came in (km_back is emitted once per block)
 	} range;
+	RoundProbe probe = {false, nullptr, nullptr, nullptr, nullptr};   // KMX_PREGATHER_PROBE=1 (test hook): kernels.hip k_probe_pregather
 	bool ring = false;                                         // built by several GPUs (kmx_shard_begin): this handle holds ONE rank's share
 	int ring_rank = 0, ring_world = 1;
 	int nsub = 1;                                              // grid-wide ordered passes in round 0 (see process_block)
@@ -541,6 +542,7 @@ static int kmx_destroy_impl(kmx_model *m)
 	free_feed(m);
 	free_query_feed(m);
 	free_range(m);
+	if (m->probe.side) { hipStreamSynchronize(m->probe.side); hipStreamDestroy(m->probe.side); hipEventDestroy(m->probe.fork); hipEventDestroy(m->probe.done); hipFree(m->probe.sink); }
 	for (hipEvent_t e : m->prof_events) hipEventDestroy(e);
 	delete m;
 	return KMX_OK;
@@ -906,6 +908,18 @@ static int kmx_begin_impl(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t 
 	}
 	m->t_insert_kernels = 0; m->t_total = 0;
 	memset(m->h_stats, 0, sizeof m->h_stats);
+	{
+		const char *pe = hook_env("KMX_PREGATHER_PROBE");
+		const bool want = pe && pe[0] == '1';
+		if (want && !m->probe.side) {
+			HIPCHK(hipStreamCreateWithFlags(&m->probe.side, hipStreamNonBlocking));
+			HIPCHK(hipEventCreateWithFlags(&m->probe.fork, hipEventDisableTiming));
+			HIPCHK(hipEventCreateWithFlags(&m->probe.done, hipEventDisableTiming));
+			HIPCHK(hipMalloc((void **)&m->probe.sink, 256));
+		}
+		if (want) HIPCHK(hipEventRecord(m->probe.done, m->probe.side));
+		m->probe.on = want;
+	}
 	m->ring = false; m->ring_rank = 0; m->ring_world = 1;
 	m->state = ST_BUILDING;
 	return KMX_OK;
@@ -993,7 +1007,7 @@ static int run_round(kmx_model *m, int t, bool defer, const KmbackJob *job)
 	const u64 late_bin = ((volatile u64 *)m->h_feedback)[2];
 	const bool small_detect = m->dbg_small_detect >= 0 ? m->dbg_small_detect != 0 : late_bin <= 2048;
 	const int flags = m->dbg_flags | (m->pending ? KMX_ROUND_PENDING : 0) | (defer ? KMX_ROUND_KEEP : 0) | (small_detect ? KMX_ROUND_SMALL_DETECT : 0);
-	kmxk::round(m->md, m->bd, t, m->pp, passes_of_round(m, t), &m->epoch, flags, m->stream, &m->prof, job, &m->kmb);
+	kmxk::round(m->md, m->bd, t, m->pp, passes_of_round(m, t), &m->epoch, flags, m->stream, &m->prof, job, &m->kmb, m->probe.on ? &m->probe : nullptr);
 	m->pending = true; m->pending_t = t;
 	m->pp ^= 1;
 	m->rounds++;

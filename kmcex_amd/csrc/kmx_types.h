@@ -207,6 +207,14 @@ struct RangeIn {
 	int world;
 };
 
+// the pre-gather probe of kmxk::round (test hook)
+struct RoundProbe {
+	bool on;
+	hipStream_t side;
+	hipEvent_t fork, done;
+	u32 *sink;
+};
+
 enum { SLOT_UNDECIDED = 0, SLOT_FAILED = 1, SLOT_INSERTED = 2, SLOT_CONTENDED = 3 };
 
 // Optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
