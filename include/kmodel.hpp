@@ -100,7 +100,8 @@ public:
 		if (const char *e = std::getenv("KMX_PARTITION")) {
 			const std::string v(e);
 			if (v == "range") partition = KMX_PARTITION_RANGE;
-			else if (v != "ring" && !v.empty()) { std::cout << "KMX_PARTITION=" << v << ": ring or range" << std::endl; exit(1); }
+			else if (v == "range-rccl") partition = KMX_PARTITION_RANGE_RCCL;     // the same partition, the words as fixed-size RCCL messages (one device per entry of KMX_DEVICES)
+			else if (v != "ring" && !v.empty()) { std::cout << "KMX_PARTITION=" << v << ": ring, range or range-rccl" << std::endl; exit(1); }
 		}
 		if (devs.empty()) { check(kmx_build_from_kmc(h_, db_file.c_str())); return; }
 		kmx_stats st;

@@ -91,6 +91,12 @@ int kmx_build_from_kmc_multi(kmx_model **models, int n_models, const char *db_pr
  * alone).  On return every handle holds the whole model.                                                                       */
 #define KMX_PARTITION_RING  0
 #define KMX_PARTITION_RANGE 1
+/* the same partition with the words of a round as fixed-size RCCL messages instead of peer-mapped stores: one communicator per
+ * handle (ncclCommInitAll: the handles must sit on DIFFERENT devices), every region = [header with the counts | capx words]
+ * (kmx_range_inband below), a round = two groups of ncclSend / ncclRecv on each handle's stream, nothing of it on the host.
+ * librccl.so is opened with dlopen when this is asked for (libkmx.so does not link it).  Should a region overflow, the build
+ * is repeated with KMX_PARTITION_RANGE.                                                                                       */
+#define KMX_PARTITION_RANGE_RCCL 2
 int kmx_build_from_kmc_multi_ex(kmx_model **models, int n_models, const char *db_prefix, int partition);
 /* KModel::init(db_file): two passes over the KMC listing + rest build      kmodel.hpp:57-86   */
 int kmx_build_from_kmc(kmx_model *m, const char *db_prefix);

@@ -498,7 +498,7 @@ class KModel:
             pass
 
 
-PARTITIONS = {"ring": 0, "range": 1}                                # KMX_PARTITION_* of include/kmx.h
+PARTITIONS = {"ring": 0, "range": 1, "range-rccl": 2}                                # KMX_PARTITION_* of include/kmx.h
 
 
 def init_multi(models, db_file: str, partition: str = "ring") -> None:

@@ -46,7 +46,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     failed = [c for c, p in zip(cmds, procs) if p.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, failed[0])
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

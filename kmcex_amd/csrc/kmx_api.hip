@@ -23,7 +23,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <dlfcn.h>
 #include <fcntl.h>
+#include <rccl/rccl.h>                                             // types and prototypes only: librccl.so is opened with dlopen when the RCCL transport is asked for
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -44,7 +46,7 @@ void ring_export(const ModelDev &, const BlockDev &, int, const RingLists &, u64
 void or_words(u32 *, const u32 *, u64, hipStream_t);
 void range_emit(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, bool, hipStream_t);
 void range_seal(const RangeDev &, const RangePlan &, hipStream_t);
-void range_verdict(const ModelDev &, const BlockDev &, int *, int, const RangeIn &, unsigned char *, int, hipStream_t);
+void range_verdict(const ModelDev &, const BlockDev &, int *, int, const RangeIn &, unsigned char *, int, bool, hipStream_t);
 void range_apply(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, bool, hipStream_t);
 void range_resolve(const ModelDev &, const BlockDev &, const RangeDev &, const RangePlan &, int, int, bool, hipStream_t);
 void range_commit_apply(const ModelDev &, const RangeIn &, int, hipStream_t);
@@ -1865,6 +1867,44 @@ static int owner_of_array_ring(int a, int nb, int world) { return a * std::min(w
 
 static int range_begin_common(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world, bool mailbox);
 static int range_link(kmx_model **hs, int P, int d);
+static int kmx_range_inband_impl(kmx_model *m, void **d_send, uint64_t *region_words, uint64_t *capx_words);
+static int range_in_inband(kmx_model *m, const uint64_t *d_recv, int n_src, uint8_t *d_verdict, RangeIn &in);
+namespace {
+// RCCL, bound at run time: libkmx.so does not link it (a one-GPU host needs no collective library), the range partition's RCCL
+// transport opens it on demand
+struct Rccl {
+	void *lib = nullptr;
+	decltype(&ncclCommInitAll) CommInitAll = nullptr;
+	decltype(&ncclCommDestroy) CommDestroy = nullptr;
+	decltype(&ncclSend) Send = nullptr;
+	decltype(&ncclRecv) Recv = nullptr;
+	decltype(&ncclGroupStart) GroupStart = nullptr;
+	decltype(&ncclGroupEnd) GroupEnd = nullptr;
+	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	bool load(std::string &why)
+	{
+		if (lib) return true;
+		for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+			lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+			if (lib) break;
+		}
+		if (!lib) { why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return false; }
+		auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) why = std::string("librccl.so lacks ") + n; return p; };
+		CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+		CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+		Send = (decltype(Send))sym("ncclSend");
+		Recv = (decltype(Recv))sym("ncclRecv");
+		GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+		GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+		GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+		if (CommInitAll && CommDestroy && Send && Recv && GroupStart && GroupEnd && GetErrorString) return true;
+		dlclose(lib); lib = nullptr;
+		return false;
+	}
+};
+static Rccl g_rccl;
+static std::mutex g_rccl_mu;
+}   // namespace
 static int range_list_emit(kmx_model *m, int t, const kmx_ring_list *lists, int n_lists);
 static int range_owner_round(kmx_model *m, int t, const RangeIn &in, int commits);
 static int range_list_apply(kmx_model *m, int t, bool seal_bulk = false);
@@ -1872,8 +1912,27 @@ static int range_list_order(kmx_model *m, int t, bool seal_all = false);
 static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *db_prefix, int partition)
 {
 	if (!hs || !db_prefix || P < 1) return fail(KMX_E_ARG, "null argument");
-	if (partition != KMX_PARTITION_RING && partition != KMX_PARTITION_RANGE) return fail(KMX_E_ARG, "partition %d: KMX_PARTITION_RING or KMX_PARTITION_RANGE", partition);
-	const bool by_range = partition == KMX_PARTITION_RANGE;
+	if (partition != KMX_PARTITION_RING && partition != KMX_PARTITION_RANGE && partition != KMX_PARTITION_RANGE_RCCL) return fail(KMX_E_ARG, "partition %d: KMX_PARTITION_RING, KMX_PARTITION_RANGE or KMX_PARTITION_RANGE_RCCL", partition);
+	const bool by_range = partition != KMX_PARTITION_RING, over_rccl = partition == KMX_PARTITION_RANGE_RCCL;
+	// ---- the RCCL transport: one communicator per handle (ncclCommInitAll: one rank per DEVICE), fixed-size messages with in-band
+	// counts, ncclSend / ncclRecv fused in a group on each handle's stream -- nothing of a round passes through the host
+	std::vector<ncclComm_t> comms;
+	auto drop_comms = [&] { for (ncclComm_t c : comms) if (c) g_rccl.CommDestroy(c); comms.clear(); };
+	auto comm_guard = scope_exit(drop_comms);
+	if (over_rccl) {
+		std::vector<int> devs((size_t)P);
+		for (int d = 0; d < P; d++) {
+			if (!hs[d]) return fail(KMX_E_ARG, "null model");
+			devs[(size_t)d] = hs[d]->device;
+			for (int e = 0; e < d; e++) if (devs[(size_t)e] == devs[(size_t)d]) return fail(KMX_E_ARG, "the RCCL transport takes one handle per device (device %d appears twice): use KMX_PARTITION_RANGE there", devs[(size_t)d]);
+		}
+		std::lock_guard<std::mutex> lk(g_rccl_mu);
+		std::string why;
+		if (!g_rccl.load(why)) return fail(KMX_E_NODEVICE, "RCCL transport: %s", why.c_str());
+		comms.assign((size_t)P, nullptr);
+		const ncclResult_t rc = g_rccl.CommInitAll(comms.data(), P, devs.data());
+		if (rc != ncclSuccess) { comms.clear(); return fail(KMX_E_NODEVICE, "ncclCommInitAll: %s", g_rccl.GetErrorString(rc)); }
+	}
 	if (by_range && P > KMX_MAX_RANKS) return fail(KMX_E_ARG, "the range partition takes up to %d handles", KMX_MAX_RANKS);
 	for (int d = 0; d < P; d++) {
 		if (!hs[d]) return fail(KMX_E_ARG, "null model");
@@ -1907,6 +1966,9 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 		hipEvent_t ev_round = nullptr, ev_copied = nullptr;     // ring: the round is enqueued / the hand-offs are
 		hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // range: the regions are sealed / the verdicts shipped / the bulk of the commits is out / ... is applied
 		hipStream_t side = nullptr;                               // range: the owner's stream for the bulk of the commits
+		u64 *x_recv = nullptr;                                    // RCCL transport: what the senders' regions arrive in, the verdict bytes
+		unsigned char *x_ver = nullptr, *x_back = nullptr;        // this rank answers with / gets back
+		u64 x_stride = 0, x_capx = 0;
 		kmx_stats st;
 		void *rest_k = nullptr, *rest_c = nullptr;
 	};
@@ -1924,6 +1986,7 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 	std::vector<u64> offs((size_t)P + 1, 0), rest_off((size_t)P + 1, 0);
 	kmx_stats totals;
 	memset(&totals, 0, sizeof totals);
+	bool overflowed = false;
 	auto list_len = [&](u64 b, int i) { const u64 lo = (b * (u64)nb + (u64)i) * KMX_BUCKET; return (int)std::min<u64>(n_km > lo ? n_km - lo : 0, KMX_BUCKET); };
 	const bool trace = getenv("KMX_INIT_TRACE") != nullptr;          // wall-clock phase times of handle 0 on stderr; the rounds are bracketed by a stream synchronisation only when tracing
 	const auto t_start = std::chrono::steady_clock::now();
@@ -1973,7 +2036,14 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 			mark(d, "  slice read and enqueued");
 		}
 		// ---- sizes from the whole database (kmodel.hpp:402-456), front end on the slice (partial Bloom filters), the coupled class in order
-		if (!err) note(by_range ? range_begin_common(m, k, nbf_all, db.kmer_count(), d, P, true) : kmx_shard_begin_impl(m, k, nbf_all, db.kmer_count(), d, P));
+		if (!err) note(by_range ? range_begin_common(m, k, nbf_all, db.kmer_count(), d, P, !over_rccl) : kmx_shard_begin_impl(m, k, nbf_all, db.kmer_count(), d, P));
+		if (!err && over_rccl) {
+			uint64_t stride = 0, capx = 0;
+			if (!note(kmx_range_inband_impl(m, nullptr, &stride, &capx))) {
+				r.x_stride = stride; r.x_capx = capx;
+				hip_ok(hipMalloc((void **)&r.x_recv, (u64)P * stride * 8), "hipMalloc") && hip_ok(hipMalloc((void **)&r.x_ver, (u64)P * capx), "hipMalloc") && hip_ok(hipMalloc((void **)&r.x_back, (u64)P * capx), "hipMalloc");
+			}
+		}
 		if (!err) { uint64_t nc = 0; if (!note(kmx_shard_classify_dev_impl(m, (const uint64_t *)r.d_km, r.d_cnt, r.n, (uint64_t *)r.d_ck, r.d_cc, &nc))) r.n_c = nc; }
 		if (!err) hip_ok(hipStreamSynchronize(st), "classify");
 		mark(d, "  begin + classify");
@@ -2002,7 +2072,8 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 					}
 					at += g1 - g0;
 				}
-			if (by_range) { if (ok) note(range_link(hs, P, d)); }          // (every handle allocated its inbox in range_begin, two barriers ago)
+			if (by_range && !over_rccl) { if (ok) note(range_link(hs, P, d)); }          // (every handle allocated its inbox in range_begin, two barriers ago)
+			else if (by_range) { /* RCCL: the regions stay local, ncclSend / ncclRecv move them */ }
 			else {
 				try { r.msg.assign((size_t)nb * 2, nullptr); } catch (...) { fail(KMX_E_NOMEM, "out of memory"); note(KMX_E_NOMEM); ok = false; }
 				for (auto &p : r.msg) if (ok) { ok = hip_ok(hipMalloc((void **)&p, msg_words * 8), "hipMalloc") && hip_ok(hipMemsetAsync(p, 0, msg_words * 8, st), "memset"); }
@@ -2017,7 +2088,60 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 		// verdict bytes straight into the senders' boxes, and two events per rank order the three steps -- the host threads
 		// only enqueue, nothing here waits for a device
 		u64 pos = 0;
-		if (by_range) {
+		if (over_rccl) {
+			// ---- the same rounds over RCCL: every region is a fixed-size message [header | capx words] (kmx_range_inband: the counts
+			// travel in band), a round is two groups of ncclSend / ncclRecv on this handle's stream -- words out, verdict bytes back --
+			// and RCCL orders the devices: no event, no barrier, no number on the host.  A region that overflows (uniformly hashed
+			// positions do not) voids the build; it is then repeated through the inboxes (below), which take any round whole.
+			ncclComm_t comm = comms[(size_t)d];
+			const u64 stride = r.x_stride, capx = r.x_capx;
+			auto nccl_ok = [&](ncclResult_t rc, const char *what) { if (rc != ncclSuccess) { fail(KMX_E_NODEVICE, "%s: %s", what, g_rccl.GetErrorString(rc)); note(KMX_E_NODEVICE); return false; } return true; };
+			auto exchange = [&](const void *out, void *in, u64 count, ncclDataType_t ty, u64 elem) {
+				bool ok = nccl_ok(g_rccl.GroupStart(), "ncclGroupStart");
+				for (int q = 0; ok && q < P; q++)
+					ok = nccl_ok(g_rccl.Send((const char *)out + (u64)q * count * elem, count, ty, q, comm, st), "ncclSend") &&
+					     nccl_ok(g_rccl.Recv((char *)in + (u64)q * count * elem, count, ty, q, comm, st), "ncclRecv");
+				const bool ended = nccl_ok(g_rccl.GroupEnd(), "ncclGroupEnd");      // (always closed: an open group would swallow the next build's calls)
+				return ok && ended;
+			};
+			for (u64 b = 0; b < n_blocks; b++) {
+				const u64 n_in_block = std::min<u64>(blk, n_km - b * blk);
+				if (!err && n_in_block < blk && b > 0) {                     // quirk Q1 (kmodel.hpp:520-527), on the rank that holds the list
+					const int row = (int)((n_in_block - 1) / KMX_BUCKET);
+					if (row + 1 < nb) note(kmx_ring_stale_dup_dev_impl(m, row + 1));
+				}
+				for (int t = 0; t < nb; t++) {
+					kmx_ring_list lists[KMX_MAX_NB];
+					int n_lists = 0;
+					if (t == 0)
+						for (int i = d; i < nb; i += P) {
+							kmx_ring_list &l = lists[n_lists++];
+							memset(&l, 0, sizeof l);
+							l.list = i; l.n_host = list_len(b, i);
+							l.src_kmers = r.d_rk + pos * W; l.src_counts = r.d_rc + pos;
+							pos += (u64)l.n_host;
+						}
+					// (every rank makes every call of a round whatever happened to it: a rank that left out a group would hang the others)
+					hip_ok(hipSetDevice(m->device), "hipSetDevice");
+					if (!err) note(range_list_emit(m, t, lists, n_lists));                          // 1. [header | commits of the round before + this round's triples] per owner
+					exchange(m->range.d_send, r.x_recv, stride, ncclUint64, 8);
+					RangeIn in;
+					if (!err && !note(range_in_inband(m, (const uint64_t *)r.x_recv, P, r.x_ver, in))) note(range_owner_round(m, t, in, RANGE_ALL));   // 2. commits applied, one verdict byte per word
+					exchange(r.x_ver, r.x_back, capx, ncclUint8, 1);
+					if (!err) {                                                                     // 3. winners decided; their commits go to the front of the regions
+						for (int q = 0; q < P; q++) m->range.rd.vin[q] = r.x_back + (u64)q * capx;
+						note(range_list_apply(m, t));
+						if (!err) note(range_list_order(m, t));
+					}
+				}
+			}
+			if (n_blocks) {                                                   // the last round's commits
+				if (!err) { kmxk::range_seal(m->range.rd, m->range.plan, st); m->range.pending = false; }
+				exchange(m->range.d_send, r.x_recv, stride, ncclUint64, 8);
+				RangeIn in;
+				if (!err && !note(range_in_inband(m, (const uint64_t *)r.x_recv, P, nullptr, in))) { kmxk::range_commit_apply(m->md, in, RANGE_ALL, st); hip_ok(hipGetLastError(), "commit"); }
+			}
+		} else if (by_range) {
 			// A round's commits can be set by the owners on a SIDE stream, beside what the list ranks do next, instead of in front of
 			// the next verdicts.  KMX_RANGE_OVERLAP (under KMX_TEST_HOOKS) picks from where: 1 -- from the end of k_range_apply (the
 			// uncontended winners': 99.6 % of them; the resolver's follow in front of the verdicts): measured on one GPU it buys
@@ -2136,6 +2260,7 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 		if (d == 0) {
 			for (int q = 0; q < P; q++) {
 				const kmx_stats &s2 = R[(size_t)q].st;
+				if (s2.reserved) overflowed = true;                              // a fixed-size region dropped words: the build is void
 				rest_off[(size_t)q + 1] = rest_off[(size_t)q] + s2.rest_entries;
 				totals.attempts += s2.attempts; totals.successes += s2.successes; totals.fast_commits += s2.fast_commits;
 				totals.contended += s2.contended; totals.finisher_iters += s2.finisher_iters;
@@ -2204,7 +2329,7 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 		bar.wait();                                                         // nobody frees what a peer may still be reading
 		mark(d, "merged and complete");
 		hipFree(r.d_km); hipFree(r.d_cnt); hipFree(r.d_ck); hipFree(r.d_cc); hipFree(r.d_rk); hipFree(r.d_rc); hipFree(r.d_allk); hipFree(r.d_allc);
-		hipFree(r.d_tmp);
+		hipFree(r.d_tmp); hipFree(r.x_recv); hipFree(r.x_ver); hipFree(r.x_back);
 		for (u64 *p : r.msg) hipFree(p);
 		if (r.ev_round) hipEventDestroy(r.ev_round);
 		if (r.ev_copied) hipEventDestroy(r.ev_copied);
@@ -2232,6 +2357,11 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 	body(0);
 	for (auto &x : th) x.join();
 	if (err) { snprintf(g_err, sizeof g_err, "%s", err_msg.c_str()); for (int d = 0; d < P; d++) if (hs[d]->state == ST_BUILDING) hs[d]->state = ST_EMPTY; return err; }
+	if (overflowed) {                                                   // (the merge ran on void arrays: harmless, everything is rebuilt)
+		if (getenv("KMX_INIT_TRACE")) fprintf(stderr, "[kmx multi] a fixed-size region overflowed: the build is repeated through the inboxes\n");
+		drop_comms();
+		return kmx_build_from_kmc_multi_ex_impl(hs, P, db_prefix, KMX_PARTITION_RANGE);
+	}
 	return KMX_OK;
 }
 
@@ -2363,7 +2493,9 @@ static int range_list_emit(kmx_model *m, int t, const kmx_ring_list *lists, int 
 // (commits: RANGE_ALL, or RANGE_LATE when the bulk of them was applied ahead, on the side stream)
 static int range_owner_round(kmx_model *m, int t, const RangeIn &in, int commits)
 {
-	kmxk::range_verdict(m->md, m->range.obd, m->range.d_opcnt, t, in, m->range.d_lver, commits, m->stream);
+	const u64 late_bin = ((volatile u64 *)m->h_feedback)[2];      // (a launch-shape heuristic like run_round's: never changes the result)
+	const bool small_late = m->dbg_small_detect >= 0 ? m->dbg_small_detect != 0 : late_bin <= 2048;
+	kmxk::range_verdict(m->md, m->range.obd, m->range.d_opcnt, t, in, m->range.d_lver, commits, small_late, m->stream);
 	HIPCHK(hipGetLastError());
 	return KMX_OK;
 }

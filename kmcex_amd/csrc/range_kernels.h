@@ -682,18 +682,23 @@ void range_seal(const RangeDev &rd, const RangePlan &pl, hipStream_t st) { hipLa
 // step 2, owner.  obd: the owner's view (its own overflow flags and padded bin counters; the claim bins of the handle, unused by the
 // list side here); lver: one byte per triple received
 // commits: which commit words are still to be applied (RANGE_ALL, or RANGE_LATE when the bulk went ahead on another stream)
-void range_verdict(const ModelDev &md, const BlockDev &obd_, int *pcnt, int t, const RangeIn &in, unsigned char *lver, int commits, hipStream_t st)
+void range_verdict(const ModelDev &md, const BlockDev &obd_, int *pcnt, int t, const RangeIn &in, unsigned char *lver, int commits, bool small_late, hipStream_t st)
 {
 	BlockDev obd = obd_;
 	obd.rverdict = lver;
 	const unsigned g = range_grid(md);
 	hipLaunchKernelGGL(k_range_commit_apply, dim3(commits == RANGE_LATE ? 64u : g), dim3(256), 0, st, md, in, obd.cl_ovf, commits);      // the previous round's winners first
+	const int late = t >= 2 ? 1 : 0;                                    // (reports the fullest late bin: ST_MAX_LATE_BIN, like the single-GPU rounds)
 	if (md.nh <= 8) {
 		hipLaunchKernelGGL((k_range_verdict<8>), dim3(g), dim3(256), 0, st, md, obd, pcnt, t, in, lver);
-		hipLaunchKernelGGL((k_round_detect<8, 1024, KMX_CL_TBITS(8), true>), dim3(KMX_CL_BINS(8), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, 0);
+		// late rounds: a few hundred claims per bin -- the small tables (16 KB, 256 threads: every bin resident at once); a bin that does
+		// not fit sends its list down the ordered path (cl_ovf), exact like any other overflow
+		if (late && small_late) hipLaunchKernelGGL((k_round_detect<8, 256, KMX_CL_TBITS_SMALL, true>), dim3(KMX_CL_BINS(8), md.nb), dim3(256), 0, st, obd, md.nb, 0, 0, 0, late);
+		else hipLaunchKernelGGL((k_round_detect<8, 1024, KMX_CL_TBITS(8), true>), dim3(KMX_CL_BINS(8), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, late);
 	} else {
 		hipLaunchKernelGGL((k_range_verdict<16>), dim3(g), dim3(256), 0, st, md, obd, pcnt, t, in, lver);
-		hipLaunchKernelGGL((k_round_detect<16, 1024, KMX_CL_TBITS(16), true>), dim3(KMX_CL_BINS(16), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, 0);
+		if (late && small_late) hipLaunchKernelGGL((k_round_detect<16, 256, KMX_CL_TBITS_SMALL, true>), dim3(KMX_CL_BINS(16), md.nb), dim3(256), 0, st, obd, md.nb, 0, 0, 0, late);
+		else hipLaunchKernelGGL((k_round_detect<16, 1024, KMX_CL_TBITS(16), true>), dim3(KMX_CL_BINS(16), md.nb), dim3(1024), 0, st, obd, md.nb, 0, 0, 0, late);
 	}
 	hipLaunchKernelGGL(k_range_ship, dim3(std::min(g, 1024u)), dim3(256), 0, st, obd, md.nb, in, (const unsigned char *)lver);
 }

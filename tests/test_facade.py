@@ -38,7 +38,7 @@ def test_driver_reproduces_reference_model_files(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices,partition", [("0,0", "ring"), ("0,0,0", "ring"), ("0,0,0,0,0", "ring"), ("0", "range"), ("0,0", "range"), ("0,0,0", "range"), ("0,0,0,0,0,0,0,0", "range")])
+@pytest.mark.parametrize("devices,partition", [("0,0", "ring"), ("0,0,0", "ring"), ("0,0,0,0,0", "ring"), ("0", "range"), ("0,0", "range"), ("0,0,0", "range"), ("0,0,0,0,0,0,0,0", "range"), ("0", "range-rccl")])
 def test_driver_on_several_devices_reproduces_reference_model_files(tmp_path, devices, partition):
     """KMX_DEVICES + KMX_PARTITION: KModel::init from C++ on several handles (all on device 0 here: the pool has one GPU) -- one
     host thread per handle; the ring of whole arrays with hipMemcpyPeerAsync hand-offs, or the north star's position-range

@@ -522,6 +522,39 @@ def test_init_by_several_handles_from_cxx(name, handles, partition, golden, tmp_
         m.close()
 
 
+@pytest.mark.parametrize("name,capx", [("k31_multiblock_ci1", None), ("k55_multiblock", None), ("k31_multiblock_ci2", None), ("k31_multiblock_ci1", "20000")])
+def test_init_over_rccl_with_the_one_rank_this_box_allows(name, capx, golden, tmp_path, monkeypatch):
+    """KMX_PARTITION_RANGE_RCCL: the range partition's rounds as fixed-size RCCL messages (ncclSend / ncclRecv in a group on the
+    handle's stream, counts in band, librccl.so opened on demand).  RCCL wants one rank per device, so this box runs it with ONE
+    handle -- every message goes to itself through RCCL; the reference's files must come out.  capx: regions forced far too small
+    (test hook) -- words are dropped, the build is void and is repeated through the inboxes: the files are still the reference's.
+    Two handles on one device are refused with a message."""
+    from kmcex_amd import api
+    _, k, ci, cs, nh, nb, n = CASE[name]
+    g = golden["cases"][name]
+    km, cnt = synth.make_stream(n, k, ci, cs)
+    db = str(tmp_path / "db")
+    kmcdb.write_kmc1(db, km, cnt, k, ci, cs)
+    if capx:
+        monkeypatch.setenv("KMX_TEST_HOOKS", "1")
+        monkeypatch.setenv("KMX_RANGE_CAPX", capx)
+    m = KModel(ci, cs, nh, nb)
+    api.init_multi([m], db, "range-rccl")
+    out = str(tmp_path / "m")
+    os.makedirs(out)
+    m.save(out)
+    for f in ("header", "km.bin", "rest.bin"):
+        assert sha_file(os.path.join(out, f)) == g["sha256"][f], f
+    st = m.stats()
+    assert (st.attempts, st.successes, st.rest_entries) == (g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
+    assert sha_occ(m.kmer_to_occ_packed(query_set(km, k))) == g["occ_sha256"]
+    m2 = KModel(ci, cs, nh, nb)
+    with pytest.raises(api.KmxError, match="one handle per device"):
+        api.init_multi([m, m2], db, "range-rccl")
+    m.close()
+    m2.close()
+
+
 @pytest.mark.parametrize("partition", ["ring", "range"])
 def test_init_by_several_handles_unsorted_listing(partition, golden, tmp_path):
     """the same on a KMC2-layout database (bin-major listing): the slices of the ranks follow the listing, not the sorted order"""
