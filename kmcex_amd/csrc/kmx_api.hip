@@ -1881,6 +1881,8 @@ struct Rccl {
 	decltype(&ncclGroupStart) GroupStart = nullptr;
 	decltype(&ncclGroupEnd) GroupEnd = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	std::vector<int> devs;                                           // the devices the communicators below were made for
+	std::vector<ncclComm_t> comms;
 	bool load(std::string &why)
 	{
 		if (lib) return true;
@@ -1916,9 +1918,10 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 	const bool by_range = partition != KMX_PARTITION_RING, over_rccl = partition == KMX_PARTITION_RANGE_RCCL;
 	// ---- the RCCL transport: one communicator per handle (ncclCommInitAll: one rank per DEVICE), fixed-size messages with in-band
 	// counts, ncclSend / ncclRecv fused in a group on each handle's stream -- nothing of a round passes through the host
+	// (Creating the communicators costs ~350 ms: they are kept for the next build on the same devices; one RCCL build at a time
+	// per process uses them -- the lock is held for the whole build.)
 	std::vector<ncclComm_t> comms;
-	auto drop_comms = [&] { for (ncclComm_t c : comms) if (c) g_rccl.CommDestroy(c); comms.clear(); };
-	auto comm_guard = scope_exit(drop_comms);
+	std::unique_lock<std::mutex> rccl_lock(g_rccl_mu, std::defer_lock);
 	if (over_rccl) {
 		std::vector<int> devs((size_t)P);
 		for (int d = 0; d < P; d++) {
@@ -1926,14 +1929,19 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 			devs[(size_t)d] = hs[d]->device;
 			for (int e = 0; e < d; e++) if (devs[(size_t)e] == devs[(size_t)d]) return fail(KMX_E_ARG, "the RCCL transport takes one handle per device (device %d appears twice): use KMX_PARTITION_RANGE there", devs[(size_t)d]);
 		}
-		std::lock_guard<std::mutex> lk(g_rccl_mu);
+		rccl_lock.lock();
 		std::string why;
 		if (!g_rccl.load(why)) return fail(KMX_E_NODEVICE, "RCCL transport: %s", why.c_str());
-		comms.assign((size_t)P, nullptr);
-		const ncclResult_t rc = g_rccl.CommInitAll(comms.data(), P, devs.data());
-		if (rc != ncclSuccess) { comms.clear(); return fail(KMX_E_NODEVICE, "ncclCommInitAll: %s", g_rccl.GetErrorString(rc)); }
+		if (g_rccl.devs != devs) {
+			for (ncclComm_t c : g_rccl.comms) if (c) g_rccl.CommDestroy(c);
+			g_rccl.comms.assign((size_t)P, nullptr);
+			g_rccl.devs.clear();
+			const ncclResult_t rc = g_rccl.CommInitAll(g_rccl.comms.data(), P, devs.data());
+			if (rc != ncclSuccess) { g_rccl.comms.clear(); return fail(KMX_E_NODEVICE, "ncclCommInitAll: %s", g_rccl.GetErrorString(rc)); }
+			g_rccl.devs = devs;
+		}
+		comms = g_rccl.comms;
 	}
-	if (by_range && P > KMX_MAX_RANKS) return fail(KMX_E_ARG, "the range partition takes up to %d handles", KMX_MAX_RANKS);
 	for (int d = 0; d < P; d++) {
 		if (!hs[d]) return fail(KMX_E_ARG, "null model");
 		if (hs[d]->ci != hs[0]->ci || hs[d]->cs != hs[0]->cs || hs[d]->nh != hs[0]->nh || hs[d]->nb != hs[0]->nb) return fail(KMX_E_ARG, "the handles of one model must share ci, cs, nh, nb");
@@ -2359,7 +2367,7 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 	if (err) { snprintf(g_err, sizeof g_err, "%s", err_msg.c_str()); for (int d = 0; d < P; d++) if (hs[d]->state == ST_BUILDING) hs[d]->state = ST_EMPTY; return err; }
 	if (overflowed) {                                                   // (the merge ran on void arrays: harmless, everything is rebuilt)
 		if (getenv("KMX_INIT_TRACE")) fprintf(stderr, "[kmx multi] a fixed-size region overflowed: the build is repeated through the inboxes\n");
-		drop_comms();
+		if (rccl_lock.owns_lock()) rccl_lock.unlock();
 		return kmx_build_from_kmc_multi_ex_impl(hs, P, db_prefix, KMX_PARTITION_RANGE);
 	}
 	return KMX_OK;

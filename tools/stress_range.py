@@ -5,8 +5,11 @@ commit kernels run alone on configurations biased to heavy contention -- tiny ar
 With `world=N` (or `world=rand`) the N ranks are threads of this process (tests/thread_comm.py) that share the GPU: the lists are spread
 over the ranks, every rank owns a range of every array, the words really travel between the handles, and EVERY rank's model is
 compared with the oracle.
-usage: python tools/stress_range.py [seconds] [seed] [big] [world=N|world=rand] [part=range|ring]"""
-import os, sys, time
+With `cxx` the build goes through the C++ entry instead (kmx_build_from_kmc_multi_ex on a KMC1 database written for the case: world
+handles on cuda:0, host threads, the words of a round through the peer-mapped inboxes -- part=range -- or whole arrays -- part=ring);
+`msg=counted` asks the Python path for counted messages instead of the fixed-size ones.
+usage: python tools/stress_range.py [seconds] [seed] [big] [world=N|world=rand] [part=range|ring] [cxx] [msg=fixed|counted]"""
+import os, shutil, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -17,7 +20,13 @@ from kmcex_amd import dist as kd
 
 from thread_comm import run_threads
 world_arg = next((a.split("=")[1] for a in sys.argv if a.startswith("world=")), None)
-part = next((a.split("=")[1] for a in sys.argv if a.startswith("part=")), "range")      # part=ring: the ring of whole arrays through the same harness
+part = next((a.split("=")[1] for a in sys.argv if a.startswith("part=")), "range")
+cxx = "cxx" in sys.argv
+msg = next((a.split("=")[1] for a in sys.argv if a.startswith("msg=")), None)
+if msg:
+    os.environ["KMX_RANGE_MESSAGES"] = msg
+from kmcex_amd import api, kmcdb
+tmpdir = tempfile.mkdtemp(prefix="kmx_stress_", dir="/dev/shm" if os.access("/dev/shm", os.W_OK) else None)      # part=ring: the ring of whole arrays through the same harness
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4321)
 SIZES = [600000, 1500000, 3000000] if "big" in sys.argv else [40, 300, 3000, 30000, 120000, 300000, 700000]
@@ -43,7 +52,20 @@ while time.time() - t0 < budget:
     tc = torch.from_numpy(np.ascontiguousarray(cnt, dtype=np.uint32).view(np.int32)).to(dev)
     world = 1 if world_arg is None else (int(rng.integers(2, 17)) if world_arg == "rand" else int(world_arg))
     tag = (k, ci, cs, nh, nb, n, seed, world)
-    if world > 1:
+    if cxx:
+        db = os.path.join(tmpdir, "db")
+        kmcdb.write_kmc1(db, km, cnt, k, ci, cs, total_override=total)
+        models = [KModel(ci, cs, nh, nb) for _ in range(world)]
+        api.init_multi(models, db, part)
+        m = models[0]
+        for r, mr in enumerate(models[1:], 1):
+            for a in range(nb):
+                assert np.array_equal(mr.download("tag", a), m.download("tag", a)) and np.array_equal(mr.download("value", a), m.download("value", a)), ("handle", r, "array", a, tag)
+            assert np.array_equal(mr.download("km_back"), m.download("km_back")), ("handle", r, "km_back", tag)
+            sr, s0 = mr.stats(), m.stats()
+            assert (sr.attempts, sr.successes, sr.rest_entries) == (s0.attempts, s0.successes, s0.rest_entries), ("handle", r, "stats", tag)
+            mr.close()
+    elif world > 1:
         def rank_body(rank, comm):
             lo, hi = kd.split_batch(len(cnt), world, rank)
             mr = KModel(ci, cs, nh, nb)
@@ -75,4 +97,5 @@ while time.time() - t0 < budget:
     m.close(); del m
     done += 1
     if done % (5 if "big" in sys.argv else 20) == 0: print(f"[{time.time()-t0:.0f}s] {done} configurations, {contended} contended k-mers decided in list order, all bit-exact", flush=True)
-print(f"{part.upper()} STRESS OK (world {world_arg or 1}): {done} configurations, {contended} contended k-mers, {time.time()-t0:.0f}s")
+shutil.rmtree(tmpdir, ignore_errors=True)
+print(f"{part.upper()}{' (C++ entry)' if cxx else ''} STRESS OK (world {world_arg or 1}): {done} configurations, {contended} contended k-mers, {time.time()-t0:.0f}s")
