@@ -376,6 +376,8 @@ def single_model_leg(a, m, km, cnt, q, out, rank, world, dev, rehearsal, distrib
     owns = 1 if (a.partition == "range" or info.get("arrays_owned")) else 0
     (t_b, t_qq), (n_all, nq_all, sent, working) = kd.reduce_job([t_b, t_qq], [km.numel(), q.numel(), info["bytes_sent"], owns], device="cpu" if rehearsal else dev)
     layout = ({"partition": "range", "cells_owned_rank0": info.get("cells_owned"), "all_to_alls_per_build": info.get("collectives"),
+               "messages": info.get("messages"), "fixed_messages_overflowed": bool(info.get("fixed_messages_overflowed")),
+               "host_waits_per_round": 0 if info.get("messages") == "fixed" else 1,
                "ranks_holding_lists": min(world, a.nb)} if a.partition == "range" else
               {"partition": "ring", "arrays_owned_rank0": info.get("arrays_owned"), "array_owners": min(world, a.nb),
                "ring_hops_per_build": info["blocks"] * a.nb * sum(1 for x in range(a.nb) if kd.owner_of_array(x, a.nb, world) != kd.owner_of_array((x + 1) % a.nb, a.nb, world))})
