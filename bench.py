@@ -158,10 +158,32 @@ def init_db_leg(a, km, cnt, reps=3, layout="kmc1"):
         st = m.stats()
         m.close()
         best, mean = min(ts[1:]), sum(ts[1:]) / reps
+        multi = {}
+        if layout == "kmc1":
+            # the same database through the C++ multi-GPU entry with the ONE handle this box has: the north star's position-range
+            # partition alone (every word "sent" to itself) -- through the peer-mapped inboxes and through RCCL messages
+            from kmcex_amd import api
+            for part, key in (("range", "init_db_range_cxx"), ("range-rccl", "init_db_range_rccl_cxx")):
+                try:
+                    mm = KModel(a.ci, a.cs, a.nh, a.nb)
+                    tt = []
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        api.init_multi([mm], db, part)
+                        tt.append(time.perf_counter() - t0)
+                    ok = mm.stats().attempts == st.attempts
+                    mm.close()
+                    multi[f"{key}_1_handle_ms"] = min(tt[1:]) * 1e3
+                    multi[f"{key}_1_handle_value"] = km.numel() / min(tt[1:])
+                    multi[f"{key}_same_attempts"] = ok
+                except Exception as e:  # noqa: BLE001
+                    multi[f"{key}_error"] = repr(e)
+            multi["init_db_range_cxx_what"] = ("kmx_build_from_kmc_multi_ex(KMX_PARTITION_RANGE / _RANGE_RCCL) with one handle: KModel::init(db) through the range "
+                                               "partition's kernels and transports alone; N handles need N GPUs (tests run 1-8 handles on one)")
         what = ("KModel::init(database in tmpfs): KMC listing decode + pinned hipMemcpyAsync + insert + rest build, wall clock" if layout == "kmc1" else
                 "the same on a KMC2-layout database (what KMC 3 writes): 512 bins listed bin by bin, unsorted insert order")
         return {f"{tag}_value": km.numel() / mean, f"{tag}_ms": mean * 1e3, f"{tag}_best_ms": best * 1e3, f"{tag}_reps": reps,
-                f"{tag}_what": what, f"{tag}_attempts": st.attempts, f"{tag}_bytes": os.path.getsize(db + ".kmc_suf")}
+                f"{tag}_what": what, f"{tag}_attempts": st.attempts, f"{tag}_bytes": os.path.getsize(db + ".kmc_suf"), **multi}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

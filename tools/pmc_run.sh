@@ -10,7 +10,7 @@ out=$root/gpurun_out/pmc_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d "$out/pmc_$C" -- python "$root/bench.py" --steps 1 --warmup 0 --no-roofline --no-init-db --no-query-strings --cpu-sample 0 --no-single-model > "$out/bench_$C.json" 2> "$out/bench_$C.err"
+  rocprofv3 --pmc $C --output-format csv -d "$out/pmc_$C" -- python "$root/bench.py" --steps 1 --warmup 0 --no-roofline --no-init-db --no-query-strings --cpu-sample 0 --no-single-model --genome-bases 0 > "$out/bench_$C.json" 2> "$out/bench_$C.err"
   echo "bench under $C done"
   rocprofv3 --pmc $C --output-format csv -d "$out/pmcmicro_$C" -- python "$root/tools/microbench_pmc.py" > "$out/micro_$C.log" 2>&1
   echo "microbench under $C done"

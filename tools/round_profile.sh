@@ -10,7 +10,7 @@ python tools/show_bench.py gpurun_out/${tag}_bench100m.json > gpurun_out/${tag}_
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python "$root/bench.py" --steps 1 --warmup 1 --no-init-db --no-query-strings --cpu-sample 0 --no-single-model > "$root/gpurun_out/${tag}_rocprof_run.json" 2> "$root/gpurun_out/${tag}_rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python "$root/bench.py" --steps 1 --warmup 1 --no-init-db --no-query-strings --cpu-sample 0 --no-single-model --genome-bases 0 > "$root/gpurun_out/${tag}_rocprof_run.json" 2> "$root/gpurun_out/${tag}_rocprof.err"
 cd "$root"
 python tools/trace_rounds.py "$out" 5 k_round_detect > "gpurun_out/${tag}_round_timings.txt" 2>&1 || true
 python tools/trace_block.py "$out" 167 > "gpurun_out/${tag}_block_timeline.txt" 2>&1 || true
