@@ -415,6 +415,18 @@ def single_model_leg(a, m, km, cnt, q, out, rank, world, dev, rehearsal, distrib
             "stats": {"n_km": st.n_km, "attempts": st.attempts, "successes": st.successes, "rest_entries": st.rest_entries}}
 
 
+_REAL_STDOUT = None
+
+
+def emit_line(line):
+    data = (json.dumps(line) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def main():
     a = parse()
     if a.single_model_steps <= 0:
@@ -429,6 +441,12 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+    # ONE JSON line on stdout, whatever the libraries underneath print there (RCCL announces its version on stdout when a
+    # communicator is made): file descriptor 1 becomes stderr for the run, the line goes to the real stdout at the end
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     from kmcex_amd import dist as kd
     rank, local, world = kd.env_world()
     distributed = world > 1
@@ -624,7 +642,7 @@ def main():
                 partial["single_model"] = {"error": "no result within the watchdog limit: exchange presumed hung"}
                 if world > 1:
                     partial["replica_value"], partial["value"] = partial["value"], None     # the headline (one model) was NOT measured
-                print(json.dumps(partial), flush=True)
+                emit_line(partial)
             os._exit(3)                                                 # a hung exchange is a failed run on every rank
         partial = {}
         if rank == 0:
@@ -658,7 +676,7 @@ def main():
     failed = world > 1 and single is not None and "value" not in single
     if rank == 0:
         line = headline(a, world, n, q, n_all, nq_all, t_ins, t_q, st, roof, cpu, extra, init_db)
-        print(json.dumps(promote_single_model(line, single, world)), flush=True)
+        emit_line(promote_single_model(line, single, world))
     if distributed:
         dist.barrier()                      # rank 0 may still have been in its roofline leg: leave together
         dist.destroy_process_group()
