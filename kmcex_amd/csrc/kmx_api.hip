@@ -1999,7 +1999,7 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 	const bool trace = getenv("KMX_INIT_TRACE") != nullptr;          // wall-clock phase times of handle 0 on stderr; the rounds are bracketed by a stream synchronisation only when tracing
 	const auto t_start = std::chrono::steady_clock::now();
 	auto mark = [&](int d, const char *what) {
-		if (trace && d == 0) fprintf(stderr, "[kmx multi %s P=%d] %-28s %8.2f ms\n", by_range ? "range" : "ring", P, what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+		if (trace && d == 0) fprintf(stderr, "[kmx multi %s P=%d] %-28s %8.2f ms\n", over_rccl ? "range-rccl" : (by_range ? "range" : "ring"), P, what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
 	};
 	auto body = [&](int d) {
 		kmx_model *m = hs[d];
