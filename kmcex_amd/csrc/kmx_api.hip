@@ -1500,6 +1500,45 @@ static int kmx_build_from_kmc_impl(kmx_model *m, const char *db_prefix)
 	const size_t rb = db.record_bytes();
 	HIPCHK(hipSetDevice(m->device));
 	lap("database open");
+	// ONE PASS (KMX_ONE_PASS=1 under KMX_TEST_HOOKS): the whole listing is streamed to the device and decoded there
+	// once -- pread of batch b + 1 under copy + decode of batch b --, the classes are counted ON the device (k_histogram), and the
+	// build runs on the resident listing (build_common = kmx_build_dev).  No host scan; but no insert can start before the last
+	// batch has arrived (every length is a function of the class counts), so the stream is not hidden under the rounds any more:
+	// measured 10^8 31-mers, same box, profiles/r05_one_pass_ab.txt.  Needs N * (8 W + 4) bytes of HBM beside the model; records
+	// outside the header's count range (KMC never writes them) are not skipped here -- the two-pass path below is the product.
+	if (const char *op = hook_env("KMX_ONE_PASS")) if (op[0] == '1') {
+		const u64 N = db.records();
+		if (!feed_alloc(m, B, rb, W, db)) return fail(KMX_E_NOMEM, "pinned / device buffers for the listing feed could not be allocated");
+		DevMem all_k, all_c;
+		HIPCHK(all_k.alloc(std::max<u64>(N, 1) * W * 8));
+		HIPCHK(all_c.alloc(std::max<u64>(N, 1) * 4));
+		auto &F = m->feed;
+		hipStream_t st = m->stream;
+		KmcDecode kd;
+		kd.lut = F.d_lut; kd.n_lut = db.lut_entries() - 1; kd.prefix_mask = db.prefix_mask();
+		kd.rec_bytes = (u32)rb; kd.suf_bytes = db.suffix_bytes(); kd.cnt_bytes = db.counter_bytes();
+		HIPCHK(hipEventRecord(F.ev_free[0], st)); HIPCHK(hipEventRecord(F.ev_free[1], st));
+		HIPCHK(hipEventRecord(F.ev_copied[0], F.copy)); HIPCHK(hipEventRecord(F.ev_copied[1], F.copy));
+		int s2 = 0;
+		for (u64 done = 0; done < N; done += B, s2 ^= 1) {
+			const u64 c = std::min<u64>(B, N - done);
+			HIPCHK(hipEventSynchronize(F.ev_copied[s2]));                     // the pinned slot has been read (two batches ago)
+			db.copy_records(done, c, F.raw[s2]);
+			HIPCHK(hipStreamWaitEvent(F.copy, F.ev_free[s2], 0));
+			HIPCHK(hipMemcpyAsync(F.draw[s2], F.raw[s2], c * rb, hipMemcpyHostToDevice, F.copy));
+			HIPCHK(hipEventRecord(F.ev_copied[s2], F.copy));
+			HIPCHK(hipStreamWaitEvent(st, F.ev_copied[s2], 0));
+			kd.recs = F.draw[s2];
+			kmxk::kmc_decode(kd, W, done, c, (u64 *)all_k.p + done * W, (u32 *)all_c.p + done, st);
+			HIPCHK(hipEventRecord(F.ev_free[s2], st));
+		}
+		if (db.io_failed()) return fail(KMX_E_IO, "reading %s.kmc_suf failed", db_prefix);
+		lap("listing enqueued (one pass)");
+		const int rc1 = build_common(m, k, (const u64 *)all_k.p, (const u32 *)all_c.p, N, db.kmer_count());
+		lap("finish returned");
+		hipStreamSynchronize(st);
+		return rc1;
+	}
 	const char *force_host = hook_env("KMX_KMC_HOST_DECODE");
 	bool gpu_decode = !(force_host && atoi(force_host));
 	FeedSlot slot[2];

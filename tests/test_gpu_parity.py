@@ -522,6 +522,30 @@ def test_init_by_several_handles_from_cxx(name, handles, partition, golden, tmp_
         m.close()
 
 
+@pytest.mark.parametrize("name", ["k31_multiblock_ci1", "k55_multiblock", "k31_multiblock_ci2"])
+def test_init_in_one_pass_gives_the_reference_files(name, golden, tmp_path, monkeypatch):
+    """KMX_ONE_PASS=1 (test hook; SURVEY 7 step 7, row f4): KModel::init(db) without the host's pass 1 -- the listing is streamed to
+    the device once, the classes are counted there, the build runs on the resident listing.  Same files, statistics and answers."""
+    _, k, ci, cs, nh, nb, n = CASE[name]
+    g = golden["cases"][name]
+    km, cnt = synth.make_stream(n, k, ci, cs)
+    db = str(tmp_path / "db")
+    kmcdb.write_kmc1(db, km, cnt, k, ci, cs)
+    monkeypatch.setenv("KMX_TEST_HOOKS", "1")
+    monkeypatch.setenv("KMX_ONE_PASS", "1")
+    m = KModel(ci, cs, nh, nb)
+    m.init(db)
+    out = str(tmp_path / "m")
+    os.makedirs(out)
+    m.save(out)
+    for f in ("header", "km.bin", "rest.bin"):
+        assert sha_file(os.path.join(out, f)) == g["sha256"][f], f
+    st = m.stats()
+    assert (st.attempts, st.successes, st.rest_entries) == (g["stats"]["attempts"], g["stats"]["successes"], g["stats"]["rest_entries"])
+    assert sha_occ(m.kmer_to_occ_packed(query_set(km, k))) == g["occ_sha256"]
+    m.close()
+
+
 @pytest.mark.parametrize("name,capx", [("k31_multiblock_ci1", None), ("k55_multiblock", None), ("k31_multiblock_ci2", None), ("k31_multiblock_ci1", "20000")])
 def test_init_over_rccl_with_the_one_rank_this_box_allows(name, capx, golden, tmp_path, monkeypatch):
     """KMX_PARTITION_RANGE_RCCL: the range partition's rounds as fixed-size RCCL messages (ncclSend / ncclRecv in a group on the
