@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-single-model", action="store_true", help="skip the one-model-over-all-ranks leg")
     ap.add_argument("--single-model-steps", type=int, default=0, help="0: --steps when N > 1 (it is the headline there), 2 at N = 1")
     ap.add_argument("--no-other-partition", action="store_true", help="N > 1: do not also time the partition that was not selected")
+    ap.add_argument("--no-cxx-multi", action="store_true", help="N > 1: skip the C++ multi-GPU entry (kmx_build_from_kmc_multi_ex driven from rank 0's process)")
     ap.add_argument("--partition", choices=("ring", "range"), default="ring",
                     help="how ONE model is spread over the ranks: ring = arrays owned whole, lists travel (send/recv); range = every array cut by "
                          "position range, commits + triples out and verdicts back by all-to-all (the north star's partition, SURVEY.md 8e(1))")
@@ -241,6 +242,41 @@ def genome_leg(a, dev, n_bases, reps=2):
             "genome_attempts_per_kmer": st.attempts / max(st.n_km, 1),
             "genome_what": f"all overlapping {k}-mers of a random {n_bases}-base sequence, canonical, distinct, D1 counts: insert (kmx_build_dev), "
                            "kmer_to_occ of the stored k-mers and of their successors, resident in HBM; neighbour_path_fraction from an accounting pass"}
+
+
+def cxx_multi_leg(a, km, cnt, world, reps=3, devices=None):
+    """KModel::init(db) by `world` handles, one per GPU, from THIS process (include/kmx.h kmx_build_from_kmc_multi_ex; what
+    KMX_DEVICES=0,1,... KMX_PARTITION=... gives a caller of the reference's API): ms per build of rank 0's stream."""
+    import shutil
+    from kmcex_amd import KModel, api
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="kmx_bench_multi_", dir=base)
+    out = {"kmers": int(km.numel()), "handles": world, "devices": devices or list(range(world)), "scaling": "strong (one stream of kmers_per_gpu k-mers built by all GPUs)",
+           "what": "kmx_build_from_kmc_multi_ex from one process, one handle per GPU: wall clock of KModel::init(database in tmpfs), best of the timed builds"}
+    try:
+        db = os.path.join(tmp, "db")
+        write_kmc1_from_device(db, km, cnt, a.k, a.ci, a.cs)
+        ref = None
+        for part in ("range", "range-rccl", "ring"):
+            try:
+                ms = [KModel(a.ci, a.cs, a.nh, a.nb, device=d) for d in (devices or list(range(world)))]
+                ts = []
+                for _ in range(reps + 1):
+                    t0 = time.perf_counter()
+                    api.init_multi(ms, db, part)
+                    ts.append(time.perf_counter() - t0)
+                st = ms[-1].stats()
+                sig = (st.attempts, st.successes, st.rest_entries)
+                ref = ref or sig
+                out[part] = {"ms_per_build": min(ts[1:]) * 1e3, "value": km.numel() / min(ts[1:]), "all_ms": [t * 1e3 for t in ts[1:]], "same_model": sig == ref}
+                for m in ms:
+                    m.close()
+            except Exception as e:  # noqa: BLE001
+                out[part] = {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    torch.cuda.set_device(0)
+    return out
 
 
 def source_digest():
@@ -665,6 +701,17 @@ def main():
                 single["other_partition"] = {k: o[k] for k in o if k not in ("what", "stats")}
             except Exception as e:  # noqa: BLE001
                 single["other_partition"] = {"partition": b.partition, "error": repr(e)}
+        # N > 1: the C++ entry too -- ONE process (rank 0's) drives all N GPUs with kmx_build_from_kmc_multi_ex while the other ranks
+        # wait: KModel::init on rank 0's stream as a KMC database (strong scaling: the same 1e8 k-mers whatever N is), through the
+        # peer-mapped inboxes, through RCCL messages, and as the ring -- the transports this pool's one GPU cannot time
+        # (rehearsal on one GPU: only with KMX_BENCH_CXX_MULTI=1, every handle on cuda:0 -- the code path, not a rate)
+        if world > 1 and (not rehearsal or os.environ.get("KMX_BENCH_CXX_MULTI") == "1") and not a.no_cxx_multi and single is not None and a.k <= 31:
+            if rank == 0:
+                try:
+                    single["cxx_multi"] = cxx_multi_leg(a, km, cnt, world, devices=[0] * world if rehearsal else list(range(world)))
+                except Exception as e:  # noqa: BLE001
+                    single["cxx_multi"] = {"error": repr(e)}
+            dist.barrier()
         done.set()
         wd.cancel()
     cpu = None

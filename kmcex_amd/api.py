@@ -253,11 +253,15 @@ class KModel:
 
     DL = {"bf": 0, "bf_back": 1, "km_back": 2, "value": 3, "tag": 4, "claims": 5}
 
-    def __init__(self, ci: int = 1, cs: int = 1023, num_hash: int = 7, num_bit: int = 5, _handle=None):
+    def __init__(self, ci: int = 1, cs: int = 1023, num_hash: int = 7, num_bit: int = 5, _handle=None, device=None):
+        """device: the HIP device of the handle (kmx_create_on); None = the calling thread's current device (kmx_create)"""
         self.L = load_library()
         if _handle is None:
             h = C.c_void_p()
-            _chk(self.L.kmx_create(ci, cs, num_hash, num_bit, C.byref(h)))
+            if device is None:
+                _chk(self.L.kmx_create(ci, cs, num_hash, num_bit, C.byref(h)))
+            else:
+                _chk(self.L.kmx_create_on(int(device), ci, cs, num_hash, num_bit, C.byref(h)))
             _handle = h
         self.h = _handle
 
