@@ -1881,6 +1881,7 @@ static int kmx_shard_complete_impl(kmx_model *m, const uint64_t *d_rest_kmers, c
 // include/kmodel.hpp with KMX_DEVICES=0,1,...  `hs[d]` was created on the device it is to use (kmx_create_on); on return
 // EVERY handle holds the whole model (replicas, as after dist.build_sharded).  Devices may repeat (several handles on one
 // GPU: how the one-GPU pool tests the protocol).
+#define KMX_MAX_RANKS_ANY 64                     // handles of one multi-GPU build (the ring takes any number; the range partition KMX_MAX_RANKS)
 #ifndef KMX_RANGE_OVERLAP_DEFAULT
 #define KMX_RANGE_OVERLAP_DEFAULT 0
 #endif
@@ -1906,6 +1907,18 @@ static int owner_of_array_ring(int a, int nb, int world) { return a * std::min(w
 
 static int range_begin_common(kmx_model *m, int k, const uint64_t n_bf[3], uint64_t n_total, int rank, int world, bool mailbox);
 static int range_link(kmx_model **hs, int P, int d);
+// the calling thread's current device `from` may map the memory of device `to` (hipDeviceEnablePeerAccess, once per pair)
+static int peer_access(int from, int to)
+{
+	if (from == to) return KMX_OK;
+	int can = 0;
+	HIPCHK(hipDeviceCanAccessPeer(&can, from, to));
+	if (!can) return fail(KMX_E_NODEVICE, "device %d cannot map the memory of device %d: no peer access", from, to);
+	const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+	if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(KMX_E_NODEVICE, "hipDeviceEnablePeerAccess(%d): %s", to, hipGetErrorString(e));
+	(void)hipGetLastError();
+	return KMX_OK;
+}
 static int kmx_range_inband_impl(kmx_model *m, void **d_send, uint64_t *region_words, uint64_t *capx_words);
 static int range_in_inband(kmx_model *m, const uint64_t *d_recv, int n_src, uint8_t *d_verdict, RangeIn &in);
 namespace {
@@ -2123,6 +2136,7 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 			else if (by_range) { /* RCCL: the regions stay local, ncclSend / ncclRecv move them */ }
 			else {
 				try { r.msg.assign((size_t)nb * 2, nullptr); } catch (...) { fail(KMX_E_NOMEM, "out of memory"); note(KMX_E_NOMEM); ok = false; }
+				for (int q = 0; ok && q < P; q++) if (note(peer_access(m->device, hs[q]->device))) ok = false;      // k_ring_export stores into the next owner's buffer
 				for (auto &p : r.msg) if (ok) { ok = hip_ok(hipMalloc((void **)&p, msg_words * 8), "hipMalloc") && hip_ok(hipMemsetAsync(p, 0, msg_words * 8, st), "memset"); }
 			}
 			if (ok) hip_ok(hipStreamSynchronize(st), "routing");
@@ -2257,47 +2271,43 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 				}
 			}
 		} else
-		// ---- the rounds, ring: this rank attempts the lists whose array it owns; survivors travel as messages
+		// ---- the rounds, ring: this rank attempts the lists whose array it owns.  The survivors of a list are written by k_ring_export
+		// STRAIGHT INTO the message buffer of the rank that owns the next array (a peer mapping): exactly the survivors cross the
+		// link -- no copy of a whole 3.1 MB buffer, no count on the host -- and ONE event per rank and round orders the hand-offs:
+		// before round r a rank waits for round r - 1 of the ranks it imports from (their export is complete) and of the ranks
+		// it exports to (they have read what it is about to overwrite).
+		{
+		u64 round_no = 0;
 		for (u64 b = 0; b < n_blocks; b++) {
 			const u64 n_in_block = std::min<u64>(blk, n_km - b * blk);
 			if (!err && n_in_block < blk && b > 0) {                         // quirk Q1 (kmodel.hpp:520-527)
 				const int row = (int)((n_in_block - 1) / KMX_BUCKET);
 				if (row + 1 < nb) note(kmx_ring_stale_dup_dev_impl(m, row + 1));
 			}
-			for (int t = 0; t < nb; t++) {
+			for (int t = 0; t < nb; t++, round_no++) {
 				kmx_ring_list lists[KMX_MAX_NB];                             // (fixed arrays: nothing in a body may throw between two barriers)
-				std::pair<int, int> recvs[KMX_MAX_NB], sends[KMX_MAX_NB];   // (list, peer rank)
-				int n_lists = 0, n_recvs = 0, n_sends = 0;
+				bool peer[KMX_MAX_RANKS_ANY] = {false};                      // ranks whose last round this one depends on
+				int n_lists = 0;
 				for (int i = 0; i < nb; i++) {
 					const int n_i = list_len(b, i), a = (i + t) % nb;
-					if (n_i == 0) continue;
-					if (own[(size_t)a] == d) {
-						kmx_ring_list l;
-						memset(&l, 0, sizeof l);
-						l.list = i;
-						l.dst_msg = t + 1 < nb ? r.msg[(size_t)i * 2 + ((t + 1) & 1)] : nullptr;
-						if (t == 0) { l.n_host = n_i; l.src_kmers = r.d_rk + pos * W; l.src_counts = r.d_rc + pos; pos += (u64)n_i; }
-						else { l.n_host = -1; l.src_msg = r.msg[(size_t)i * 2 + (t & 1)]; }
-						lists[n_lists++] = l;
-						if (t + 1 < nb && own[(size_t)((a + 1) % nb)] != d) sends[n_sends++] = {i, own[(size_t)((a + 1) % nb)]};
-					} else if (t + 1 < nb && own[(size_t)((a + 1) % nb)] == d) recvs[n_recvs++] = {i, own[(size_t)a]};
+					if (n_i == 0 || own[(size_t)a] != d) continue;
+					kmx_ring_list l;
+					memset(&l, 0, sizeof l);
+					l.list = i;
+					const int next = own[(size_t)((a + 1) % nb)], prev = own[(size_t)((a + nb - 1) % nb)];
+					l.dst_msg = t + 1 < nb ? R[(size_t)next].msg[(size_t)i * 2 + ((t + 1) & 1)] : nullptr;      // the next owner's buffer (possibly this rank's own)
+					if (t + 1 < nb && next != d) peer[next] = true;
+					if (t == 0) { l.n_host = n_i; l.src_kmers = r.d_rk + pos * W; l.src_counts = r.d_rc + pos; pos += (u64)n_i; }
+					else { l.n_host = -1; l.src_msg = r.msg[(size_t)i * 2 + (t & 1)]; if (prev != d) peer[prev] = true; }
+					lists[n_lists++] = l;
 				}
+				if (!err && round_no > 0)
+					for (int q = 0; q < P; q++) if (peer[q]) hip_ok(hipStreamWaitEvent(st, R[(size_t)q].ev[(round_no - 1) & 1], 0), "wait");
 				if (!err && n_lists) note(kmx_ring_round_dev_impl(m, t, lists, n_lists));
-				if (!err) hip_ok(hipEventRecord(r.ev_round, st), "event");
-				bar.wait();
-				if (!err) {
-					for (int e = 0; e < n_recvs; e++) {                      // the survivors of list rv.first, from the rank that just attempted it
-						const std::pair<int, int> &rv = recvs[e];
-						const Rank &sr = R[(size_t)rv.second];
-						hip_ok(hipStreamWaitEvent(st, sr.ev_round, 0), "wait");
-						hip_ok(hipMemcpyPeerAsync(r.msg[(size_t)rv.first * 2 + ((t + 1) & 1)], m->device, sr.msg[(size_t)rv.first * 2 + ((t + 1) & 1)], hs[rv.second]->device, msg_words * 8, st), "hand-off");
-					}
-					hip_ok(hipEventRecord(r.ev_copied, st), "event");
-				}
-				bar.wait();
-				if (!err) for (int e = 0; e < n_sends; e++) hip_ok(hipStreamWaitEvent(st, R[(size_t)sends[e].second].ev_copied, 0), "wait");   // before this buffer is written again
-				bar.wait();                                                 // (ev_round / ev_copied are recorded again only after everybody has enqueued its waits)
+				if (!err) hip_ok(hipEventRecord(r.ev[round_no & 1], st), "event");
+				bar.wait();                                                  // (an event is recorded again two rounds later: everybody's waits on it are enqueued by then)
 			}
+		}
 		}
 		// ---- merge: survivors to every rank, filters OR-ed (set_bit is an OR, kmodel.hpp:576-581), every array from its owner
 		if (trace && d == 0) mark(d, "rounds enqueued");
@@ -2595,14 +2605,7 @@ static int range_link(kmx_model **hs, int P, int d)
 	HIPCHK(hipSetDevice(m->device));
 	for (int q = 0; q < P; q++) {
 		if (!hs[q]->range.on || !hs[q]->range.mailbox || hs[q]->range.rd.cap != R.rd.cap) return fail(KMX_E_STATE, "handle %d is not part of this range-partitioned build", q);
-		if (hs[q]->device != m->device) {
-			int can = 0;
-			HIPCHK(hipDeviceCanAccessPeer(&can, m->device, hs[q]->device));
-			if (!can) return fail(KMX_E_NODEVICE, "device %d cannot map the memory of device %d: no peer access", m->device, hs[q]->device);
-			const hipError_t e = hipDeviceEnablePeerAccess(hs[q]->device, 0);
-			if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(KMX_E_NODEVICE, "hipDeviceEnablePeerAccess(%d): %s", hs[q]->device, hipGetErrorString(e));
-			(void)hipGetLastError();
-		}
+		TRY(peer_access(m->device, hs[q]->device));
 		R.rd.out[q] = hs[q]->range.d_inbox + (u64)d * R.rd.cap;          // sender d's region in owner q's inbox
 		R.rd.hdr_out[q] = hs[q]->range.d_in_hdr + KMX_RANGE_HDR * d;
 		R.rd.vin[q] = R.d_vbox + (u64)q * R.rd.cap;                      // owner q answers into this rank's box
