@@ -57,7 +57,8 @@ def parse():
     ap.add_argument("--no-single-model", action="store_true", help="skip the one-model-over-all-ranks leg")
     ap.add_argument("--single-model-steps", type=int, default=0, help="0: --steps when N > 1 (it is the headline there), 2 at N = 1")
     ap.add_argument("--no-other-partition", action="store_true", help="N > 1: do not also time the partition that was not selected")
-    ap.add_argument("--no-cxx-multi", action="store_true", help="N > 1: skip the C++ multi-GPU entry (kmx_build_from_kmc_multi_ex driven from rank 0's process)")
+    ap.add_argument("--no-cxx-multi", action="store_true", help="N > 1: skip the C++ multi-GPU entry (kmx_build_from_kmc_multi_ex driven from ONE process, a child of rank 0)")
+    ap.add_argument("--cxx-multi-child", type=str, default="", help=argparse.SUPPRESS)     # internal: run the C++ multi-GPU leg on these devices ("0,1,2,...") and print its JSON
     ap.add_argument("--partition", choices=("ring", "range"), default="ring",
                     help="how ONE model is spread over the ranks: ring = arrays owned whole, lists travel (send/recv); range = every array cut by "
                          "position range, commits + triples out and verdicts back by all-to-all (the north star's partition, SURVEY.md 8e(1))")
@@ -275,7 +276,6 @@ def cxx_multi_leg(a, km, cnt, world, reps=3, devices=None):
                 out[part] = {"error": repr(e)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    torch.cuda.set_device(0)
     return out
 
 
@@ -463,14 +463,31 @@ def emit_line(line):
         os.write(_REAL_STDOUT, data)
 
 
+def cxx_multi_child(a):
+    """`bench.py --cxx-multi-child 0,1,...`: the C++ multi-GPU leg in a process of its own (see main): rank 0's stream, regenerated."""
+    from kmcex_amd import dist as kd
+    from kmcex_amd import synth_torch
+    devs = [int(x) for x in a.cxx_multi_child.split(",")]
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)                                                  # (RCCL announces itself on stdout)
+    torch.cuda.set_device(devs[0])
+    seed_k, seed_c = kd.stream_seeds(0)
+    km, cnt = synth_torch.make_stream(a.n, a.k, a.ci, a.cs, torch.device("cuda", devs[0]), seed_k=seed_k, seed_c=seed_c)
+    out = cxx_multi_leg(a, km, cnt, len(devs), devices=devs)
+    os.write(real, (json.dumps(out) + "\n").encode())
+
+
 def main():
     a = parse()
+    if a.cxx_multi_child:
+        cxx_multi_child(a)
+        return
     if a.single_model_steps <= 0:
         a.single_model_steps = a.steps if a.gpus > 1 else 2
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started bare: run the N-rank job as a child (nothing has touched the GPU in this process) and pass on its status
         import socket
-        import subprocess
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
@@ -705,10 +722,19 @@ def main():
         # wait: KModel::init on rank 0's stream as a KMC database (strong scaling: the same 1e8 k-mers whatever N is), through the
         # peer-mapped inboxes, through RCCL messages, and as the ring -- the transports this pool's one GPU cannot time
         # (rehearsal on one GPU: only with KMX_BENCH_CXX_MULTI=1, every handle on cuda:0 -- the code path, not a rate)
+        # It runs in a CHILD of rank 0 (a fresh process: its own HIP context, its own RCCL communicators, a time limit): whatever
+        # happens there -- a refused peer mapping, a hung collective -- costs this leg, not the run.
         if world > 1 and (not rehearsal or os.environ.get("KMX_BENCH_CXX_MULTI") == "1") and not a.no_cxx_multi and single is not None and a.k <= 31:
             if rank == 0:
+                devs = [0] * world if rehearsal else list(range(world))
+                cmd = [sys.executable, os.path.abspath(__file__), "--cxx-multi-child", ",".join(str(d) for d in devs), "--kmers", str(a.n), "--kmer-len", str(a.k),
+                       "--ci", str(a.ci), "--cs", str(a.cs), "--nh", str(a.nh), "--nb", str(a.nb)]
                 try:
-                    single["cxx_multi"] = cxx_multi_leg(a, km, cnt, world, devices=[0] * world if rehearsal else list(range(world)))
+                    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+                    single["cxx_multi"] = json.loads(lines[-1]) if p.returncode == 0 and lines else {"error": f"child exit {p.returncode}: {p.stderr[-400:]}"}
+                except subprocess.TimeoutExpired:
+                    single["cxx_multi"] = {"error": "no result within 300 s: the child was ended"}
                 except Exception as e:  # noqa: BLE001
                     single["cxx_multi"] = {"error": repr(e)}
             dist.barrier()
