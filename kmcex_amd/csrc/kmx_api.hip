@@ -2023,8 +2023,7 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 		u32 *d_tmp = nullptr;
 		u64 n = 0, n_c = 0, n_r = 0, rec_lo = 0;
 		std::vector<u64 *> msg;                                    // [nb * 2] list i, parity
-		hipEvent_t ev_round = nullptr, ev_copied = nullptr;     // ring: the round is enqueued / the hand-offs are
-		hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // range: the regions are sealed / the verdicts shipped / the bulk of the commits is out / ... is applied
+		hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // ring: round r is enqueued (r & 1); range: the regions are sealed / the verdicts shipped / the bulk of the commits is out / ... is applied
 		hipStream_t side = nullptr;                               // range: the owner's stream for the bulk of the commits
 		u64 *x_recv = nullptr;                                    // RCCL transport: what the senders' regions arrive in, the verdict bytes
 		unsigned char *x_ver = nullptr, *x_back = nullptr;        // this rank answers with / gets back
@@ -2065,8 +2064,7 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 		if (!err) {
 			const u64 B = u64(1) << 23;
 			auto &F = m->feed;
-			bool ok = hip_ok(hipEventCreateWithFlags(&r.ev_round, hipEventDisableTiming), "event") && hip_ok(hipEventCreateWithFlags(&r.ev_copied, hipEventDisableTiming), "event") &&
-			          hip_ok(hipEventCreateWithFlags(&r.ev[0], hipEventDisableTiming), "event") && hip_ok(hipEventCreateWithFlags(&r.ev[1], hipEventDisableTiming), "event") &&
+			bool ok = hip_ok(hipEventCreateWithFlags(&r.ev[0], hipEventDisableTiming), "event") && hip_ok(hipEventCreateWithFlags(&r.ev[1], hipEventDisableTiming), "event") &&
 			          hip_ok(hipEventCreateWithFlags(&r.ev[2], hipEventDisableTiming), "event") && hip_ok(hipEventCreateWithFlags(&r.ev[3], hipEventDisableTiming), "event") &&
 			          (!by_range || hip_ok(hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking), "stream"));
 			if (ok && !feed_alloc(m, (size_t)B, rb, W, db)) { fail(KMX_E_NOMEM, "pinned / device buffers for the listing feed could not be allocated"); note(KMX_E_NOMEM); ok = false; }
@@ -2388,8 +2386,6 @@ static int kmx_build_from_kmc_multi_ex_impl(kmx_model **hs, int P, const char *d
 		hipFree(r.d_km); hipFree(r.d_cnt); hipFree(r.d_ck); hipFree(r.d_cc); hipFree(r.d_rk); hipFree(r.d_rc); hipFree(r.d_allk); hipFree(r.d_allc);
 		hipFree(r.d_tmp); hipFree(r.x_recv); hipFree(r.x_ver); hipFree(r.x_back);
 		for (u64 *p : r.msg) hipFree(p);
-		if (r.ev_round) hipEventDestroy(r.ev_round);
-		if (r.ev_copied) hipEventDestroy(r.ev_copied);
 		for (hipEvent_t e : r.ev) if (e) hipEventDestroy(e);
 		if (r.side) { hipStreamSynchronize(r.side); hipStreamDestroy(r.side); }
 	};
