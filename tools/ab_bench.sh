@@ -8,7 +8,7 @@ i=0
 for setting in "$@"; do
 	i=$((i+1))
 	echo "=== [$i] ${setting:-default}" >> $out
-	env $setting python bench.py --steps 3 --warmup 1 --no-init-db --no-single-model --no-query-strings --cpu-sample 0 > gpurun_out/${tag}_ab_$i.json 2> gpurun_out/${tag}_ab_$i.err
+	env $setting python bench.py --steps 3 --warmup 1 --no-init-db --no-single-model --no-query-strings --cpu-sample 0 --genome-bases 0 > gpurun_out/${tag}_ab_$i.json 2> gpurun_out/${tag}_ab_$i.err
 	python tools/show_bench.py gpurun_out/${tag}_ab_$i.json >> $out 2>&1
 done
 cat $out
