@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libkmx.so")
 SOURCES = ["kernels.hip", "rest_device.hip", "kmx_api.hip", "kmc_reader.cpp", "strpack.cpp"]
-HEADERS = ["device_common.h", "kmx_types.h", "kmc_reader.h", "strpack.h", "range_kernels.h", os.path.join("..", "..", "include", "kmx.h")]
+HEADERS = ["device_common.h", "kmx_types.h", "kmc_reader.h", "strpack.h", "range_kernels.h", "multi_build.h", "range_host.h", os.path.join("..", "..", "include", "kmx.h")]
 
 
 def hipcc() -> str:
